@@ -1,0 +1,139 @@
+"""Generate the golden fixtures in this directory by importing the REAL reference.
+
+Runs only in the build container (needs /root/reference).  Nothing here travels as
+reference source: the outputs are plain input/expected-output arrays (.npz).
+
+Import route: h5py / astropy are absent, and the package __init__ pulls
+in sep / skimage, so we stub the storage modules, register a bare ``regularizepsf``
+package whose __path__ points at the reference, and import the three modules we need.
+
+Usage:  python tests/golden/make_golden.py
+"""
+
+from __future__ import annotations
+
+import hashlib
+import importlib
+import pathlib
+import sys
+import types
+
+import numpy as np
+
+HERE = pathlib.Path(__file__).resolve().parent
+REPO = HERE.parent.parent
+sys.path.insert(0, str(REPO))
+
+from oracle import regpsf_oracle as orc  # noqa: E402  (synthetic input generators only)
+
+
+def load_reference(root: str = "/root/reference"):
+    import matplotlib
+
+    matplotlib.use("Agg")
+    for name in ("h5py", "astropy", "astropy.io", "astropy.io.fits"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["astropy"].io = sys.modules["astropy.io"]
+    sys.modules["astropy.io"].fits = sys.modules["astropy.io.fits"]
+    pkg = types.ModuleType("regularizepsf")
+    pkg.__path__ = [f"{root}/regularizepsf"]
+    sys.modules["regularizepsf"] = pkg
+    util = importlib.import_module("regularizepsf.util")
+    psf = importlib.import_module("regularizepsf.psf")
+    transform = importlib.import_module("regularizepsf.transform")
+    return util, psf, transform
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+from tests.helpers import APPLY_CASES, make_psfs  # noqa: E402
+
+
+def main() -> None:
+    util, psf, transform = load_reference()
+
+    # (i) calculate_covering, including order
+    cov = {}
+    for (h, w), n in [((512, 512), 32), ((2048, 2048), 128), ((300, 500), 64), ((10, 10), 5), ((4096, 4096), 256)]:
+        cov[f"cov_{h}x{w}_{n}"] = util.calculate_covering((h, w), n)
+    np.savez_compressed(HERE / "covering.npz", **cov)
+
+    # (ii) construct: known-answer table and a small random cube, float32/float64
+    out = {}
+    table_s = np.array([0, 0, 0.3 - 0.4j, 0.3 - 0.4j, 1e-12, 0.25 + 0.1j], dtype=np.complex128).reshape(1, 2, 3)
+    table_t = np.array([0, 0.5 + 0.5j, 0, 0.5 + 0.5j, 1e-12, 0.25 + 0.1j], dtype=np.complex128).reshape(1, 2, 3)
+    rng = np.random.default_rng(5)
+    vals_s = rng.random((6, 16, 16)) ** 4
+    vals_t = rng.random((6, 16, 16)) ** 4
+    coords = [(i, 2 * i) for i in range(6)]
+    out["rand_values_s"], out["rand_values_t"] = vals_s, vals_t
+    with np.errstate(all="ignore"):
+        for dt, cdt in ((np.float32, np.complex64), (np.float64, np.complex128)):
+            tag = np.dtype(dt).name
+            for alpha in (0.5, 1.0, 2.0, 3.0):
+                for eps in (0.1, 0.01):
+                    s = psf.ArrayPSF(util.IndexedCube([(0, 0)], np.zeros((1, 2, 3), dt)),
+                                     util.IndexedCube([(0, 0)], table_s.astype(cdt)))
+                    t = psf.ArrayPSF(util.IndexedCube([(0, 0)], np.zeros((1, 2, 3), dt)),
+                                     util.IndexedCube([(0, 0)], table_t.astype(cdt)))
+                    k = transform.ArrayPSFTransform.construct(s, t, alpha, eps)._transfer_kernel.values
+                    out[f"table_{tag}_a{alpha}_e{eps}"] = k
+                    s = psf.ArrayPSF(util.IndexedCube(coords, vals_s.astype(dt)))
+                    t = psf.ArrayPSF(util.IndexedCube(coords, vals_t.astype(dt)))
+                    out[f"rand_{tag}_a{alpha}_e{eps}"] = (
+                        transform.ArrayPSFTransform.construct(s, t, alpha, eps)._transfer_kernel.values
+                    )
+            out[f"rand_fft_{tag}"] = psf.ArrayPSF(util.IndexedCube(coords, vals_s.astype(dt))).fft_evaluations
+    out["table_s"], out["table_t"] = table_s, table_t
+    np.savez_compressed(HERE / "construct.npz", **out)
+
+    # (iii) apply: expected outputs from the reference on seeded inputs
+    for name, h, w, n, alpha, eps, kind, pad_mode, seed in APPLY_CASES:
+        coords = [tuple(int(v) for v in t) for t in util.calculate_covering((h, w), n)]
+        src, tgt = make_psfs(kind, coords, n, h, w)
+        s = psf.ArrayPSF(util.IndexedCube(coords, src))
+        t = s if kind == "identity" else psf.ArrayPSF(util.IndexedCube(coords, tgt))
+        tr = transform.ArrayPSFTransform.construct(s, t, alpha, eps)
+        k = tr._transfer_kernel.values
+        assert np.isfinite(k).all(), name
+        k64 = k.astype(np.complex64)
+        tr64 = transform.ArrayPSFTransform(util.IndexedCube(coords, k64))
+        if kind == "identity":
+            image = np.zeros((h, w), np.float32)
+            image[h // 4 : h // 2, w // 8 : w // 3] = 5
+        else:
+            image = orc.starfield(h, w, seed)
+        expected = tr64.apply(image, pad_mode=pad_mode)
+        np.savez_compressed(
+            HERE / f"apply_{name}.npz",
+            image=image, coords=np.array(coords, np.int64), expected=expected,
+            k_sha256=np.array(sha(k64)), k_sum=np.array(k64.sum()),
+            meta=np.array([h, w, n]), alpha=np.array(alpha), eps=np.array(eps),
+            kind=np.array(kind), pad_mode=np.array(pad_mode),
+        )
+        print(name, len(coords), expected.shape, float(np.abs(expected).max()))
+
+    # (iv) saturation, scaled down from the reference's tests/test_transform.py:52-74
+    h = w = 192
+    n = 64
+    coords = [tuple(int(v) for v in t) for t in util.calculate_covering((h, w), n)]
+    src, _ = make_psfs("identity", coords, n, h, w)
+    s = psf.ArrayPSF(util.IndexedCube(coords, src))
+    tr = transform.ArrayPSFTransform.construct(s, s, 3.0, 0.1)
+    image = np.zeros((h, w), np.float32)
+    image[50:100, 20:40] = 5
+    image[80, 80] = 100
+    image[0, 3] = 50  # a pad-edge pixel, mirrored into the padding
+    sat = {}
+    for dil, nbw in ((1, 7), (2, 5), (0, 7)):
+        sat[f"expected_d{dil}_w{nbw}"] = tr.apply(image, saturation_threshold=10, saturation_dilation=dil,
+                                                   neighborhood_width=nbw)
+    np.savez_compressed(HERE / "apply_saturation.npz", image=image, coords=np.array(coords, np.int64), **sat)
+    print("done")
+
+
+if __name__ == "__main__":
+    main()
