@@ -1,0 +1,136 @@
+/* rpsf.h - C ABI of the MI355X patch-wise PSF-correction library (librpsf_hip.so).
+ *
+ * The reference (punch-mission/regularizepsf 1.2.0) is pure Python and has no FFI seam of its
+ * own; the boundary it offers is the class API.  Each entry point below states which reference
+ * lines it stands in for, so that a reference maintainer can bind it with ctypes (see
+ * INTEGRATION.md for the stub).  Conventions:
+ *   - plain pointers and sizes only; no C++ / torch types cross the boundary;
+ *   - every function returns 0 on success or a negative RPSF_E_* code; rpsf_last_error() returns a
+ *     thread-local human-readable message for the last failure on the calling thread;
+ *   - host pointers are borrowed for the duration of the call only; a plan owns all of its device
+ *     memory; nothing returned by the library is freed by the caller except through *_destroy/_free;
+ *   - a plan is bound to one device and is not re-entrant; distinct plans may be used from
+ *     distinct threads.
+ */
+#ifndef RPSF_H
+#define RPSF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RPSF_OK 0
+#define RPSF_E_BADARG (-1)      /* null pointer, negative size, coordinate outside the padded image ... */
+#define RPSF_E_UNSUPPORTED (-2) /* patch size that has no compiled plan (supported: 16, 32, 64, 128, 256) */
+#define RPSF_E_HIP (-3)         /* HIP runtime error (message has the hipError string) */
+#define RPSF_E_NOMEM (-4)       /* device allocation failed */
+#define RPSF_E_RCCL (-5)        /* RCCL missing or failed */
+#define RPSF_E_STATE (-6)       /* call order: e.g. apply before a transfer kernel was set */
+
+/* np.pad modes evaluated inside the kernel (regularizepsf/transform.py:119-123 passes pad_mode to
+ * np.pad).  Any other np.pad mode is handled by the Python layer, which pads on the host and calls
+ * the library on the padded image with RPSF_PAD_CONSTANT. */
+#define RPSF_PAD_CONSTANT 0
+#define RPSF_PAD_SYMMETRIC 1
+#define RPSF_PAD_REFLECT 2
+#define RPSF_PAD_EDGE 3
+#define RPSF_PAD_WRAP 4
+
+typedef struct rpsf_plan rpsf_plan;
+
+const char* rpsf_last_error(void);
+int rpsf_device_count(int* count);
+/* Compute-unit count and name of a device (for reporting). */
+int rpsf_device_info(int device, int* compute_units, char* name, size_t name_len);
+
+/* A plan is the device-side form of one ArrayPSFTransform: patch size N (psf_shape, square,
+ * regularizepsf/transform.py:37-40), the patch corner list (transform.coordinates, (row, col) pairs,
+ * transform.py:141-149) and, once installed, the transfer kernel. */
+int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int n_patches, const int32_t* coords_rc);
+void rpsf_plan_destroy(rpsf_plan* plan);
+
+/* Install the transfer kernel K (IndexedCube values of ArrayPSFTransform, complex64 interleaved,
+ * shape (n_patches, N, N), transform.py:164).  The library folds it to its Hermitian part and
+ * re-orders it into the layout the patch kernel streams.  host: pageable host memory. */
+int rpsf_plan_set_transfer(rpsf_plan* plan, const float* k_c64_host);
+/* Same, from a device-resident full K (e.g. produced by rpsf_build_transfer_device). */
+int rpsf_plan_set_transfer_device(rpsf_plan* plan, const void* k_c64_device);
+/* Bytes of packed transfer kernel the patch kernel reads per apply (for roofline accounting). */
+int rpsf_plan_transfer_bytes(const rpsf_plan* plan, size_t* bytes);
+
+/* Image geometry of one apply call.  The reference pads the image by 2N on every side with
+ * np.pad(mode) and slices patch (r, c) at padded[r+2N : r+3N, c+2N : c+3N] (transform.py:119-123,
+ * 141-149); here padding is an index map evaluated inside the kernel against the FULL image shape
+ * (height, width).  origin_* is added to every patch corner (used when the caller hands over an
+ * already padded image).  image_row0/image_rows and out_row0/out_rows describe which rows of the
+ * full image / full output are resident at the device pointers (row-band sharding); for a whole
+ * image they are 0 and height. */
+typedef struct rpsf_geometry {
+  int height, width;
+  int pad_mode;
+  float pad_value;
+  int origin_row, origin_col;
+  int image_row0, image_rows, ld_image;
+  int out_row0, out_rows, ld_out;
+} rpsf_geometry;
+
+/* ArrayPSFTransform.apply, transform.py:117-177 without the saturation branch (:125-138,:171-172,
+ * done by the Python layer): float32 image (height, width) in, float32 corrected image out. */
+int rpsf_apply(rpsf_plan* plan, const float* image_host, int height, int width, int pad_mode, float pad_value,
+               float* out_host);
+/* Same with image and output already resident on the plan's device; asynchronous on `stream`
+ * (a hipStream_t, or NULL for the plan's own stream).  The output rows are cleared first. */
+int rpsf_apply_device(rpsf_plan* plan, const void* image_dev, void* out_dev, const rpsf_geometry* geom, void* stream);
+/* Run `iters` back-to-back device-resident applies on the plan's stream, timing each with HIP
+ * events: total_ms[i] covers the whole apply (output clear + patch kernel), kernel_ms[i] the patch
+ * kernel alone.  Either array may be NULL. */
+int rpsf_apply_device_timed(rpsf_plan* plan, const void* image_dev, void* out_dev, const rpsf_geometry* geom,
+                            int iters, float* total_ms, float* kernel_ms);
+/* The plan's own stream (hipStream_t), for callers that enqueue follow-up work such as the seam exchange. */
+void* rpsf_plan_stream(rpsf_plan* plan);
+
+/* ArrayPSFTransform.construct arithmetic, transform.py:78-82:
+ *   K = conj(S) |S|^(alpha-1) / (|S|^(alpha+1) + (eps |T|)^(alpha+1)) * T
+ * element-wise over `count` complex values; S, T, K are host arrays of complex64 (is_f64 = 0,
+ * evaluated in float32 like NumPy does for complex64 input) or complex128 (is_f64 = 1). */
+int rpsf_build_transfer(int device, size_t count, const void* s_host, const void* t_host, int is_f64, double alpha,
+                        double epsilon, void* k_host);
+/* Device-resident variant (pointers on `device`), asynchronous on stream. */
+int rpsf_build_transfer_device(int device, size_t count, const void* s_dev, const void* t_dev, int is_f64,
+                               double alpha, double epsilon, void* k_dev, void* stream);
+
+/* Batched un-shifted 2-D FFT of real PSF cubes (ArrayPSF.__init__, psf.py:216-219), float32 in,
+ * complex64 out, (count, N, N) host arrays. */
+int rpsf_psf_fft(int device, int patch_size, int count, const float* values_host, float* fft_c64_host);
+
+/* Device memory helpers for callers that keep frames resident (bench, tests, streaming). */
+int rpsf_dev_alloc(int device, size_t bytes, void** out);
+int rpsf_dev_free(int device, void* ptr);
+int rpsf_memcpy_h2d(int device, void* dst_dev, const void* src_host, size_t bytes);
+int rpsf_memcpy_d2h(int device, void* dst_host, const void* src_dev, size_t bytes);
+int rpsf_device_synchronize(int device);
+
+/* Multi-GPU row-band sharding (one process per GPU).  The caller splits the patch lattice into
+ * contiguous row bands; each rank builds a plan for its band only (image rows it reads, patches it
+ * owns) and, after the local apply, exchanges the seam rows its last lattice row spilled into the
+ * next rank's band.  rpsf_comm_* wraps RCCL (loaded with dlopen) for exactly that neighbour
+ * exchange; unique_id is 128 bytes, created on rank 0 and distributed by the caller. */
+typedef struct rpsf_comm rpsf_comm;
+int rpsf_comm_unique_id(void* id128);
+int rpsf_comm_create(rpsf_comm** out, int device, int rank, int world, const void* id128);
+void rpsf_comm_destroy(rpsf_comm* comm);
+/* Send `send_count` floats at send_dev to rank+1 (if any) and receive `recv_count` floats from
+ * rank-1 (if any) into recv_dev, then add recv_dev[0:recv_count] into accum_dev.  Any count may be 0. */
+int rpsf_comm_seam_exchange_add(rpsf_comm* comm, const void* send_dev, size_t send_count, void* recv_dev,
+                                size_t recv_count, void* accum_dev, void* stream);
+int rpsf_comm_barrier(rpsf_comm* comm, void* stream);
+/* max over ranks of one double (used for whole-job timing) */
+int rpsf_comm_allreduce_max(rpsf_comm* comm, double* value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RPSF_H */

@@ -1,0 +1,273 @@
+"""ctypes binding of librpsf_hip.so (the C ABI declared in include/rpsf.h).
+
+There is deliberately no CPU fallback: if the shared library has not been built, or no MI355X
+is visible, every compute entry point raises.  Build with ``python -m regularizepsf_amd.build``
+(or ``__graft_entry__.build()``).
+"""
+
+from __future__ import annotations
+
+import ctypes
+import pathlib
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_void_p
+
+import numpy as np
+
+LIB_PATH = pathlib.Path(__file__).resolve().parent / "librpsf_hip.so"
+
+PAD_MODES = {"constant": 0, "symmetric": 1, "reflect": 2, "edge": 3, "wrap": 4}
+SUPPORTED_PATCH_SIZES = (16, 32, 64, 128, 256)
+
+E_BADARG, E_UNSUPPORTED, E_HIP, E_NOMEM, E_RCCL, E_STATE = -1, -2, -3, -4, -5, -6
+
+
+class NativeError(RuntimeError):
+    """A call into librpsf_hip.so failed (HIP / RCCL / device-memory errors)."""
+
+    def __init__(self, code: int, message: str) -> None:
+        super().__init__(f"librpsf_hip error {code}: {message}")
+        self.code = code
+
+
+class Geometry(ctypes.Structure):
+    """rpsf_geometry of include/rpsf.h."""
+
+    _fields_ = [
+        ("height", c_int), ("width", c_int), ("pad_mode", c_int), ("pad_value", c_float),
+        ("origin_row", c_int), ("origin_col", c_int),
+        ("image_row0", c_int), ("image_rows", c_int), ("ld_image", c_int),
+        ("out_row0", c_int), ("out_rows", c_int), ("ld_out", c_int),
+    ]
+
+    @classmethod
+    def whole(cls, height: int, width: int, pad_mode: int, pad_value: float = 0.0) -> "Geometry":
+        return cls(height, width, pad_mode, pad_value, 0, 0, 0, height, width, 0, height, width)
+
+
+_PROTOTYPES = {
+    "rpsf_last_error": (c_char_p, []),
+    "rpsf_device_count": (c_int, [POINTER(c_int)]),
+    "rpsf_device_info": (c_int, [c_int, POINTER(c_int), c_char_p, c_size_t]),
+    "rpsf_plan_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_void_p]),
+    "rpsf_plan_destroy": (None, [c_void_p]),
+    "rpsf_plan_set_transfer": (c_int, [c_void_p, c_void_p]),
+    "rpsf_plan_set_transfer_device": (c_int, [c_void_p, c_void_p]),
+    "rpsf_plan_transfer_bytes": (c_int, [c_void_p, POINTER(c_size_t)]),
+    "rpsf_apply": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+    "rpsf_apply_device": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(Geometry), c_void_p]),
+    "rpsf_apply_device_timed": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(Geometry), c_int, c_void_p, c_void_p]),
+    "rpsf_plan_stream": (c_void_p, [c_void_p]),
+    "rpsf_build_transfer": (c_int, [c_int, c_size_t, c_void_p, c_void_p, c_int, c_double, c_double, c_void_p]),
+    "rpsf_build_transfer_device": (c_int, [c_int, c_size_t, c_void_p, c_void_p, c_int, c_double, c_double, c_void_p,
+                                           c_void_p]),
+    "rpsf_psf_fft": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rpsf_dev_alloc": (c_int, [c_int, c_size_t, POINTER(c_void_p)]),
+    "rpsf_dev_free": (c_int, [c_int, c_void_p]),
+    "rpsf_memcpy_h2d": (c_int, [c_int, c_void_p, c_void_p, c_size_t]),
+    "rpsf_memcpy_d2h": (c_int, [c_int, c_void_p, c_void_p, c_size_t]),
+    "rpsf_device_synchronize": (c_int, [c_int]),
+    "rpsf_comm_unique_id": (c_int, [c_void_p]),
+    "rpsf_comm_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_void_p]),
+    "rpsf_comm_destroy": (None, [c_void_p]),
+    "rpsf_comm_seam_exchange_add": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "rpsf_comm_barrier": (c_int, [c_void_p, c_void_p]),
+    "rpsf_comm_allreduce_max": (c_int, [c_void_p, POINTER(c_double)]),
+}
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load librpsf_hip.so once; raise ImportError (never fall back) if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            msg = (f"{LIB_PATH} not found: the HIP library has not been built. "
+                   "Run `python -m regularizepsf_amd.build` (needs hipcc); there is no CPU fallback.")
+            raise ImportError(msg)
+        handle = ctypes.CDLL(str(LIB_PATH))
+        for name, (restype, argtypes) in _PROTOTYPES.items():
+            fn = getattr(handle, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = handle
+    return _lib
+
+
+def check(code: int) -> None:
+    if code != 0:
+        text = lib().rpsf_last_error()
+        raise NativeError(code, text.decode() if text else "unknown error")
+
+
+def device_count() -> int:
+    n = c_int(0)
+    check(lib().rpsf_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def device_info(device: int = 0) -> tuple[int, str]:
+    cus = c_int(0)
+    buf = ctypes.create_string_buffer(256)
+    check(lib().rpsf_device_info(device, ctypes.byref(cus), buf, 256))
+    return cus.value, buf.value.decode()
+
+
+def _ptr(a: np.ndarray) -> c_void_p:
+    return c_void_p(a.ctypes.data)
+
+
+class DeviceBuffer:
+    """A device allocation owned by Python (frames kept resident by bench / tests / streaming callers)."""
+
+    def __init__(self, nbytes: int, device: int = 0) -> None:
+        self.device, self.nbytes = device, int(nbytes)
+        p = c_void_p()
+        check(lib().rpsf_dev_alloc(device, self.nbytes, ctypes.byref(p)))
+        self.ptr = p
+
+    def upload(self, array: np.ndarray, offset_bytes: int = 0) -> "DeviceBuffer":
+        a = np.ascontiguousarray(array)
+        if offset_bytes + a.nbytes > self.nbytes:
+            msg = "upload larger than the device buffer"
+            raise ValueError(msg)
+        check(lib().rpsf_memcpy_h2d(self.device, c_void_p(self.ptr.value + offset_bytes), _ptr(a), a.nbytes))
+        return self
+
+    def download(self, shape, dtype=np.float32, offset_bytes: int = 0) -> np.ndarray:
+        out = np.empty(shape, dtype)
+        if offset_bytes + out.nbytes > self.nbytes:
+            msg = "download larger than the device buffer"
+            raise ValueError(msg)
+        check(lib().rpsf_memcpy_d2h(self.device, _ptr(out), c_void_p(self.ptr.value + offset_bytes), out.nbytes))
+        return out
+
+    def at(self, offset_bytes: int) -> c_void_p:
+        return c_void_p(self.ptr.value + offset_bytes)
+
+    def free(self) -> None:
+        if self.ptr is not None and self.ptr.value:
+            lib().rpsf_dev_free(self.device, self.ptr)
+            self.ptr = None
+
+    def __del__(self) -> None:
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
+class Plan:
+    """Device-side form of one ArrayPSFTransform: patch size, corner list, packed transfer kernel."""
+
+    def __init__(self, patch_size: int, coordinates, device: int = 0) -> None:
+        coords = np.ascontiguousarray(np.asarray(coordinates, dtype=np.int64).reshape(-1, 2).astype(np.int32))
+        self.patch_size, self.n_patches, self.device = int(patch_size), len(coords), device
+        self._handle = c_void_p()
+        check(lib().rpsf_plan_create(ctypes.byref(self._handle), device, self.patch_size, self.n_patches, _ptr(coords)))
+
+    def set_transfer(self, kernel: np.ndarray) -> None:
+        k = np.ascontiguousarray(kernel, dtype=np.complex64)
+        if k.shape != (self.n_patches, self.patch_size, self.patch_size):
+            msg = f"transfer kernel has shape {k.shape}, expected {(self.n_patches, self.patch_size, self.patch_size)}"
+            raise ValueError(msg)
+        check(lib().rpsf_plan_set_transfer(self._handle, _ptr(k)))
+
+    def set_transfer_device(self, ptr: c_void_p) -> None:
+        check(lib().rpsf_plan_set_transfer_device(self._handle, ptr))
+
+    @property
+    def transfer_bytes(self) -> int:
+        n = c_size_t(0)
+        check(lib().rpsf_plan_transfer_bytes(self._handle, ctypes.byref(n)))
+        return n.value
+
+    @property
+    def stream(self) -> c_void_p:
+        return c_void_p(lib().rpsf_plan_stream(self._handle))
+
+    def apply(self, image: np.ndarray, pad_mode: int, pad_value: float = 0.0) -> np.ndarray:
+        img = np.ascontiguousarray(image, dtype=np.float32)
+        out = np.empty_like(img)
+        check(lib().rpsf_apply(self._handle, _ptr(img), img.shape[0], img.shape[1], pad_mode, pad_value, _ptr(out)))
+        return out
+
+    def apply_device(self, image_ptr: c_void_p, out_ptr: c_void_p, geometry: Geometry, stream: c_void_p | None = None) -> None:
+        check(lib().rpsf_apply_device(self._handle, image_ptr, out_ptr, ctypes.byref(geometry), stream))
+
+    def apply_device_timed(self, image_ptr: c_void_p, out_ptr: c_void_p, geometry: Geometry, iters: int):
+        total = np.zeros(iters, np.float32)
+        kern = np.zeros(iters, np.float32)
+        check(lib().rpsf_apply_device_timed(self._handle, image_ptr, out_ptr, ctypes.byref(geometry), iters,
+                                            _ptr(total), _ptr(kern)))
+        return total, kern
+
+    def synchronize(self) -> None:
+        check(lib().rpsf_device_synchronize(self.device))
+
+    def close(self) -> None:
+        if self._handle is not None and self._handle.value:
+            lib().rpsf_plan_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self) -> None:
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def build_transfer(source_fft: np.ndarray, target_fft: np.ndarray, alpha: float, epsilon: float, device: int = 0) -> np.ndarray:
+    """K2 on the GPU; dtype-preserving like the NumPy expression it replaces (transform.py:78-82)."""
+    dtype = np.result_type(source_fft.dtype, target_fft.dtype)
+    dtype = np.complex128 if dtype == np.complex128 else np.complex64
+    s = np.ascontiguousarray(source_fft, dtype=dtype)
+    t = np.ascontiguousarray(np.broadcast_to(target_fft, s.shape), dtype=dtype)
+    k = np.empty_like(s)
+    check(lib().rpsf_build_transfer(device, s.size, _ptr(s), _ptr(t), int(dtype == np.complex128), float(alpha),
+                                    float(epsilon), _ptr(k)))
+    return k
+
+
+def psf_fft(values: np.ndarray, device: int = 0) -> np.ndarray:
+    """K3 on the GPU: (n, N, N) real -> complex64 un-shifted 2-D spectra (psf.py:216-219)."""
+    v = np.ascontiguousarray(values, dtype=np.float32)
+    if v.ndim != 3 or v.shape[1] != v.shape[2]:
+        msg = "values must have shape (n, N, N)"
+        raise ValueError(msg)
+    out = np.empty(v.shape, np.complex64)
+    if v.shape[0]:
+        check(lib().rpsf_psf_fft(device, v.shape[1], v.shape[0], _ptr(v), _ptr(out)))
+    return out
+
+
+class Comm:
+    """RCCL neighbour exchange for the row-band split (one process per GPU)."""
+
+    def __init__(self, device: int, rank: int, world: int, unique_id: bytes) -> None:
+        self.rank, self.world, self.device = rank, world, device
+        self._handle = c_void_p()
+        buf = ctypes.create_string_buffer(unique_id, 128)
+        check(lib().rpsf_comm_create(ctypes.byref(self._handle), device, rank, world, buf))
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = ctypes.create_string_buffer(128)
+        check(lib().rpsf_comm_unique_id(buf))
+        return buf.raw
+
+    def seam_exchange_add(self, send_ptr, send_count: int, recv_ptr, recv_count: int, accum_ptr, stream=None) -> None:
+        check(lib().rpsf_comm_seam_exchange_add(self._handle, send_ptr, send_count, recv_ptr, recv_count, accum_ptr, stream))
+
+    def barrier(self, stream=None) -> None:
+        check(lib().rpsf_comm_barrier(self._handle, stream))
+
+    def allreduce_max(self, value: float) -> float:
+        v = c_double(value)
+        check(lib().rpsf_comm_allreduce_max(self._handle, ctypes.byref(v)))
+        return v.value
+
+    def close(self) -> None:
+        if self._handle is not None and self._handle.value:
+            lib().rpsf_comm_destroy(self._handle)
+            self._handle = None

@@ -1,0 +1,859 @@
+// rpsf.hip - HIP kernels (gfx950) and the C ABI of include/rpsf.h.
+//
+// Kernels:
+//   patch_kernel<C>        K1: fused gather+pad+window -> 2-D DFT -> x folded K -> inverse DFT -> window ->
+//                          overlap-add; one workgroup per patch (or several small patches per workgroup),
+//                          patch resident in registers, LDS used only for the inter-stage transposes.
+//                          Stands in for regularizepsf/transform.py:151-169.
+//   pack_kernel<C>         folds K to K_h = (K(k)+conj K(-k))/2 and re-orders it into the per-thread
+//                          streaming layout of K1 (one-time, at set_transfer).
+//   build_transfer_kernel  K2: transform.py:78-82 element-wise.
+//   psf_fft_kernel<C>      K3: psf.py:216-219, forward half of K1 written out as a full spectrum.
+//   add_rows_kernel        K4: seam accumulate for the multi-GPU row-band split.
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rpsf.h"
+#include "rpsf_core.hpp"
+
+using namespace rpsf;
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIP_TRY(expr)                                                                                   \
+  do {                                                                                                  \
+    hipError_t e_ = (expr);                                                                             \
+    if (e_ != hipSuccess)                                                                               \
+      return fail(e_ == hipErrorOutOfMemory ? RPSF_E_NOMEM : RPSF_E_HIP,                                \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                                   \
+  } while (0)
+
+extern "C" const char* rpsf_last_error(void) { return g_err.c_str(); }
+
+// ------------------------------------------------------------------------------------------------
+// K1
+// ------------------------------------------------------------------------------------------------
+struct PatchParams {
+  ImageView im;
+  OutView ov;
+  int origin_row, origin_col;
+  const int32_t* coords;
+  int n_patches;
+  const uint16_t* tab;
+  const cf* tw;
+  const float* win;
+  const cf* g;
+  const cf* gs;
+};
+
+template <class C>
+struct Launch {
+  static constexpr int WG = C::T < 64 ? 64 : C::T;
+  static constexpr int TEAMS = WG / C::T;
+  static constexpr size_t LDS_BYTES = (size_t)TEAMS * C::LDS_FLOATS * sizeof(float);
+};
+
+template <class C>
+__global__ __launch_bounds__(Launch<C>::WG) void patch_kernel(PatchParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int T = C::T;
+  const int team = threadIdx.x / T, t = threadIdx.x % T;
+  int patch = blockIdx.x * Launch<C>::TEAMS + team;
+  const bool active = patch < p.n_patches;
+  if (!active) patch = p.n_patches - 1;  // keep the team in step with the barriers; its result is dropped
+  float* lds = smem + team * C::LDS_FLOATS;
+
+  int gids[C::P];
+#pragma unroll
+  for (int i = 0; i < C::P; ++i) gids[i] = p.tab[t * C::P + i];
+
+  const int pr = p.coords[2 * patch] + p.origin_row, pc = p.coords[2 * patch + 1] + p.origin_col;
+  cf v[64];
+  load_patch<C>(t, v, p.im, pr, pc, p.win);
+  stage1<C, false>(t, v, p.tw);
+  if constexpr (C::S3) {
+    x1_write<C, 0>(t, v, lds);
+    __syncthreads();
+    x1_read<C, 0>(t, v, lds);
+    __syncthreads();
+    x1_write<C, 1>(t, v, lds);
+    __syncthreads();
+    x1_read<C, 1>(t, v, lds);
+    __syncthreads();
+    stage2<C, false>(t, v, p.tw);
+  }
+  x2_mid_write<C, 0>(t, v, lds);
+  __syncthreads();
+  x2_last_read<C, 0>(gids, v, lds);
+  __syncthreads();
+  x2_mid_write<C, 1>(t, v, lds);
+  __syncthreads();
+  x2_last_read<C, 1>(gids, v, lds);
+  __syncthreads();
+
+  stage_last<C, false>(v);
+  pointwise<C>(t, gids, v, p.g + (size_t)patch * C::G_PER_PATCH, p.gs + (size_t)patch * C::GS_PER_PATCH, p.tw);
+  stage_last<C, true>(v);
+
+  x2_last_write<C, 0>(gids, v, lds);
+  __syncthreads();
+  x2_mid_read<C, 0>(t, v, lds);
+  __syncthreads();
+  x2_last_write<C, 1>(gids, v, lds);
+  __syncthreads();
+  x2_mid_read<C, 1>(t, v, lds);
+  __syncthreads();
+  if constexpr (C::S3) {
+    stage2<C, true>(t, v, p.tw);
+    x1_write<C, 0>(t, v, lds);
+    __syncthreads();
+    x1_read<C, 0>(t, v, lds);
+    __syncthreads();
+    x1_write<C, 1>(t, v, lds);
+    __syncthreads();
+    x1_read<C, 1>(t, v, lds);
+  }
+  stage1<C, true>(t, v, p.tw);
+  if (active)
+    store_patch<C>(t, v, p.ov, pr, pc, p.win, [](float* a, float val) { unsafeAtomicAdd(a, val); });
+}
+
+// ------------------------------------------------------------------------------------------------
+// K-pack
+// ------------------------------------------------------------------------------------------------
+template <class C>
+__global__ void pack_kernel(const cf* __restrict__ kfull, int n_patches, const uint16_t* __restrict__ tab,
+                            cf* __restrict__ g, cf* __restrict__ gs) {
+  const size_t per = (size_t)C::G_PER_PATCH;
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= per * n_patches) return;
+  int patch = (int)(idx / per);
+  int rem = (int)(idx % per);
+  int b = rem & 1, t = (rem >> 1) % C::T, i = (rem >> 1) / C::T;
+  int rho = 2 * i + b;
+  const cf* kf = kfull + (size_t)patch * C::N * C::N;
+  g[idx] = pack_value<C>(kf, tab, t, rho, 0);
+  int s = rho / (2 * C::E);
+  if (slot_is_special<C>(s, t)) {
+    int r = rho % (2 * C::E);
+    gs[(size_t)patch * C::GS_PER_PATCH + (size_t)C::spec_prefix(s) * 2 * C::E + (size_t)r * C::spec_t(s) + t] =
+        pack_value<C>(kf, tab, t, rho, 1);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: transform.py:78-82.  Mirrors NumPy's evaluation order: |.| by hypot, scalar powers with
+// NumPy's fast paths (0, 1, 2, 0.5, -1), complex * real as a full complex product with (r, 0),
+// complex / real as NumPy's scaled division, then a plain complex product with T.
+// ------------------------------------------------------------------------------------------------
+template <class R>
+__device__ __forceinline__ R np_pow(R x, R e) {
+  if (e == R(0)) return R(1);
+  if (e == R(1)) return x;
+  if (e == R(2)) return x * x;
+  if (e == R(0.5)) return sqrt(x);
+  if (e == R(-1)) return R(1) / x;
+  return pow(x, e);
+}
+
+template <class R>
+__global__ void build_transfer_kernel(const R* __restrict__ s, const R* __restrict__ t, R* __restrict__ k,
+                                      size_t count, R alpha, R eps) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  R sr = s[2 * i], si = s[2 * i + 1], tr = t[2 * i], ti = t[2 * i + 1];
+  R sabs = hypot(sr, si), tabs = hypot(tr, ti);
+  R pw = np_pow(sabs, alpha - R(1));
+  // conj(S) * (pw + 0i)
+  R cr = sr, ci = -si;
+  R nr = cr * pw - ci * R(0), ni = cr * R(0) + ci * pw;
+  R den = np_pow(sabs, alpha + R(1)) + np_pow(eps * tabs, alpha + R(1));
+  // (nr + i ni) / (den + 0i), NumPy's algorithm for |re| >= |im|
+  R qr, qi;
+  if (fabs(den) == R(0)) {
+    qr = nr / fabs(den);
+    qi = ni / fabs(den);
+  } else {
+    R rat = R(0) / den;
+    R scl = R(1) / (den + R(0) * rat);
+    qr = (nr + ni * rat) * scl;
+    qi = (ni - nr * rat) * scl;
+  }
+  k[2 * i] = qr * tr - qi * ti;
+  k[2 * i + 1] = qr * ti + qi * tr;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: batched 2-D FFT of real N x N arrays -> full N x N complex spectrum (psf.py:216-219)
+// ------------------------------------------------------------------------------------------------
+template <class C>
+__global__ __launch_bounds__(Launch<C>::WG) void psf_fft_kernel(const float* __restrict__ values, int count,
+                                                                 const uint16_t* __restrict__ tab,
+                                                                 const cf* __restrict__ tw, cf* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int T = C::T, N = C::N, NC = C::NC, E = C::E;
+  const int team = threadIdx.x / T, t = threadIdx.x % T;
+  int item = blockIdx.x * Launch<C>::TEAMS + team;
+  const bool active = item < count;
+  if (!active) item = count - 1;
+  float* lds = smem + team * C::LDS_FLOATS;
+  int gids[C::P];
+#pragma unroll
+  for (int i = 0; i < C::P; ++i) gids[i] = tab[t * C::P + i];
+  const float* src = values + (size_t)item * N * N;
+  cf v[64];
+  {
+    ThreadPos<C> tp(t);
+    constexpr int NR = 1 << C::A1, NCOL = 1 << C::B1;
+    StaticFor<0, NR>::run([&]<int R1>() RPSF_AI {
+      int r = (R1 << (C::A2 + C::AL)) + tp.r_rest;
+      StaticFor<0, NCOL>::run([&]<int C1>() RPSF_AI {
+        int c = (C1 << C::B2) + tp.c_rest;
+        v[R1 * NCOL + C1] = cf{src[(size_t)r * N + 2 * c], src[(size_t)r * N + 2 * c + 1]};
+      });
+    });
+  }
+  stage1<C, false>(t, v, tw);
+  if constexpr (C::S3) {
+    x1_write<C, 0>(t, v, lds);
+    __syncthreads();
+    x1_read<C, 0>(t, v, lds);
+    __syncthreads();
+    x1_write<C, 1>(t, v, lds);
+    __syncthreads();
+    x1_read<C, 1>(t, v, lds);
+    __syncthreads();
+    stage2<C, false>(t, v, tw);
+  }
+  x2_mid_write<C, 0>(t, v, lds);
+  __syncthreads();
+  x2_last_read<C, 0>(gids, v, lds);
+  __syncthreads();
+  x2_mid_write<C, 1>(t, v, lds);
+  __syncthreads();
+  x2_last_read<C, 1>(gids, v, lds);
+  stage_last<C, false>(v);
+  if (!active) return;
+  cf* dst = out + (size_t)item * N * N;
+  // unpack X[kr][kc] = E + W^kc O and X[kr][kc + N/2] = E - W^kc O for every bin this thread holds
+  StaticFor<0, C::NSLOT>::run([&]<int S>() RPSF_AI {
+    cf* za = v + (2 * S) * E;
+    cf* zb = za + E;
+    int ga = gids[2 * S], gb = gids[2 * S + 1];
+    bool self = partner_gid<C>(ga) == ga;
+    int qa, ma, qb, mb;
+    gid_to_qm<C>(ga, qa, ma);
+    gid_to_qm<C>(gb, qb, mb);
+    cf wa = tw[ma], wb = tw[mb];
+    StaticFor<0, E>::run([&]<int EE>() RPSF_AI {
+      constexpr int R = E - 1 - EE, Z = (E - EE) % E;
+      cf az = za[Z], ar = za[R], bz = zb[Z], br = zb[R];
+      cf pa = sel(self, sel(qa == 0, az, ar), sel(qa == 0, bz, br));
+      cf pb = sel(self, sel(qb == 0, bz, br), sel(qb == 0, az, ar));
+      {
+        cf zc = cconj(pa);
+        cf e2 = (za[EE] + zc) * 0.5f, wo = cmul(wa, mul_mi(za[EE] - zc)) * 0.5f;
+        int kr = qa + C::Q * EE;
+        dst[(size_t)kr * N + ma] = e2 + wo;
+        dst[(size_t)kr * N + ma + NC] = e2 - wo;
+      }
+      {
+        cf zc = cconj(pb);
+        cf e2 = (zb[EE] + zc) * 0.5f, wo = cmul(wb, mul_mi(zb[EE] - zc)) * 0.5f;
+        int kr = qb + C::Q * EE;
+        dst[(size_t)kr * N + mb] = e2 + wo;
+        dst[(size_t)kr * N + mb + NC] = e2 - wo;
+      }
+    });
+  });
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: accum[i] += src[i]
+// ------------------------------------------------------------------------------------------------
+__global__ void add_rows_kernel(float* __restrict__ accum, const float* __restrict__ src, size_t count) {
+  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 3 < count) {
+    float4 a = *reinterpret_cast<float4*>(accum + i);
+    float4 b = *reinterpret_cast<const float4*>(src + i);
+    a.x += b.x, a.y += b.y, a.z += b.z, a.w += b.w;
+    *reinterpret_cast<float4*>(accum + i) = a;
+  } else {
+    for (; i < count; ++i) accum[i] += src[i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// plan
+// ------------------------------------------------------------------------------------------------
+struct rpsf_plan {
+  int device = 0, N = 0, n_patches = 0;
+  size_t stage_bytes = 0;
+  int32_t* d_coords = nullptr;
+  uint16_t* d_tab = nullptr;
+  cf* d_tw = nullptr;
+  float* d_win = nullptr;
+  cf* d_g = nullptr;
+  cf* d_gs = nullptr;
+  float* d_img = nullptr;  // staging for the host-pointer entry point
+  float* d_out = nullptr;
+  bool have_k = false;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  size_t g_elems = 0, gs_elems = 0;
+  std::vector<int32_t> h_coords;
+};
+
+template <class F>
+static int dispatch_n(int N, F&& f) {
+  switch (N) {
+#if defined(RPSF_ONLY_N)  // development builds: compile a single plan
+    case RPSF_ONLY_N: return f.template operator()<Cfg<RPSF_ONLY_CFG>>();
+#else
+    case 256: return f.template operator()<Cfg256>();
+    case 128: return f.template operator()<Cfg128>();
+    case 64: return f.template operator()<Cfg64>();
+    case 32: return f.template operator()<Cfg32>();
+    case 16: return f.template operator()<Cfg16>();
+#endif
+    default: return fail(RPSF_E_UNSUPPORTED, "patch size " + std::to_string(N) + " has no compiled plan (16..256, powers of two)");
+  }
+}
+
+static void host_tables(int N, std::vector<cf>& tw, std::vector<float>& win) {
+  tw.resize(N);
+  win.resize(N);
+  for (int k = 0; k < N; ++k) {
+    double a = -2.0 * M_PI * k / N;
+    tw[k] = cf{(float)std::cos(a), (float)std::sin(a)};
+    win[k] = (float)std::sin((k + 0.5) * (M_PI / N));  // transform.py:151-154
+  }
+}
+
+template <class C>
+static int upload_tables(int device, uint16_t** d_tab, cf** d_tw, float** d_win) {
+  std::vector<uint16_t> tab((size_t)C::T * C::NSLOT * 2);
+  build_slot_table<C>(tab.data());
+  std::vector<cf> tw;
+  std::vector<float> win;
+  host_tables(C::N, tw, win);
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipMalloc(d_tab, tab.size() * sizeof(uint16_t)));
+  HIP_TRY(hipMemcpy(*d_tab, tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(d_tw, tw.size() * sizeof(cf)));
+  HIP_TRY(hipMemcpy(*d_tw, tw.data(), tw.size() * sizeof(cf), hipMemcpyHostToDevice));
+  if (d_win) {
+    HIP_TRY(hipMalloc(d_win, win.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(*d_win, win.data(), win.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  return RPSF_OK;
+}
+
+extern "C" int rpsf_device_count(int* count) {
+  if (!count) return fail(RPSF_E_BADARG, "count is null");
+  HIP_TRY(hipGetDeviceCount(count));
+  return RPSF_OK;
+}
+
+extern "C" int rpsf_device_info(int device, int* compute_units, char* name, size_t name_len) {
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (compute_units) *compute_units = prop.multiProcessorCount;
+  if (name && name_len) {
+    std::snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+  }
+  return RPSF_OK;
+}
+
+extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int n_patches, const int32_t* coords_rc) {
+  if (!out || !coords_rc) return fail(RPSF_E_BADARG, "null argument");
+  if (n_patches <= 0) return fail(RPSF_E_BADARG, "n_patches must be positive");
+  const int N = patch_size;
+  int rc = dispatch_n(N, []<class C>() { return RPSF_OK; });
+  if (rc != RPSF_OK) return rc;
+  auto* p = new rpsf_plan;
+  p->device = device, p->N = N, p->n_patches = n_patches;
+  auto body = [&]() -> int {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    for (auto& e : p->ev) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipMalloc(&p->d_coords, sizeof(int32_t) * 2 * n_patches));
+    HIP_TRY(hipMemcpy(p->d_coords, coords_rc, sizeof(int32_t) * 2 * n_patches, hipMemcpyHostToDevice));
+    p->h_coords.assign(coords_rc, coords_rc + 2 * (size_t)n_patches);
+    return dispatch_n(N, [&]<class C>() -> int {
+      int r2 = upload_tables<C>(device, &p->d_tab, &p->d_tw, &p->d_win);
+      if (r2 != RPSF_OK) return r2;
+      p->g_elems = (size_t)C::G_PER_PATCH * n_patches;
+      p->gs_elems = (size_t)C::GS_PER_PATCH * n_patches;
+      HIP_TRY(hipMalloc(&p->d_g, p->g_elems * sizeof(cf)));
+      HIP_TRY(hipMalloc(&p->d_gs, (p->gs_elems + 1) * sizeof(cf)));
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_kernel<C>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)Launch<C>::LDS_BYTES));
+      return RPSF_OK;
+    });
+  };
+  rc = body();
+  if (rc != RPSF_OK) {
+    std::string keep = g_err;
+    rpsf_plan_destroy(p);
+    g_err = keep;
+    return rc;
+  }
+  *out = p;
+  return RPSF_OK;
+}
+
+extern "C" void* rpsf_plan_stream(rpsf_plan* p) { return p ? (void*)p->stream : nullptr; }
+
+extern "C" void rpsf_plan_destroy(rpsf_plan* p) {
+  if (!p) return;
+  (void)hipSetDevice(p->device);
+  if (p->stream) (void)hipStreamSynchronize(p->stream);
+  (void)hipFree(p->d_coords);
+  (void)hipFree(p->d_tab);
+  (void)hipFree(p->d_tw);
+  (void)hipFree(p->d_win);
+  (void)hipFree(p->d_g);
+  (void)hipFree(p->d_gs);
+  (void)hipFree(p->d_img);
+  (void)hipFree(p->d_out);
+  for (auto& e : p->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (p->stream) (void)hipStreamDestroy(p->stream);
+  delete p;
+}
+
+static int pack_range(rpsf_plan* p, const cf* d_kfull, int first_patch, int count) {
+  return dispatch_n(p->N, [&]<class C>() -> int {
+    size_t total = (size_t)C::G_PER_PATCH * count;
+    int block = 256;
+    size_t grid = (total + block - 1) / block;
+    pack_kernel<C><<<dim3((unsigned)grid), dim3(block), 0, p->stream>>>(
+        d_kfull, count, p->d_tab, p->d_g + (size_t)first_patch * C::G_PER_PATCH,
+        p->d_gs + (size_t)first_patch * C::GS_PER_PATCH);
+    HIP_TRY(hipGetLastError());
+    return RPSF_OK;
+  });
+}
+
+extern "C" int rpsf_plan_set_transfer(rpsf_plan* p, const float* k_host) {
+  if (!p || !k_host) return fail(RPSF_E_BADARG, "null argument");
+  HIP_TRY(hipSetDevice(p->device));
+  const size_t per = (size_t)p->N * p->N;
+  int chunk = (int)std::max<size_t>(1, (size_t)(64u << 20) / (per * sizeof(cf)));
+  if (chunk > p->n_patches) chunk = p->n_patches;
+  cf* d_tmp = nullptr;
+  HIP_TRY(hipMalloc(&d_tmp, per * sizeof(cf) * chunk));
+  int rc = RPSF_OK;
+  for (int first = 0; first < p->n_patches && rc == RPSF_OK; first += chunk) {
+    int cnt = std::min(chunk, p->n_patches - first);
+    hipError_t e = hipMemcpyAsync(d_tmp, reinterpret_cast<const cf*>(k_host) + (size_t)first * per,
+                                  per * sizeof(cf) * cnt, hipMemcpyHostToDevice, p->stream);
+    if (e != hipSuccess) { rc = fail(RPSF_E_HIP, hipGetErrorString(e)); break; }
+    rc = pack_range(p, d_tmp, first, cnt);
+    if (rc == RPSF_OK) {
+      e = hipStreamSynchronize(p->stream);
+      if (e != hipSuccess) rc = fail(RPSF_E_HIP, hipGetErrorString(e));
+    }
+  }
+  (void)hipFree(d_tmp);
+  if (rc == RPSF_OK) p->have_k = true;
+  return rc;
+}
+
+extern "C" int rpsf_plan_set_transfer_device(rpsf_plan* p, const void* k_dev) {
+  if (!p || !k_dev) return fail(RPSF_E_BADARG, "null argument");
+  HIP_TRY(hipSetDevice(p->device));
+  int rc = pack_range(p, reinterpret_cast<const cf*>(k_dev), 0, p->n_patches);
+  if (rc != RPSF_OK) return rc;
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  p->have_k = true;
+  return RPSF_OK;
+}
+
+extern "C" int rpsf_plan_transfer_bytes(const rpsf_plan* p, size_t* bytes) {
+  if (!p || !bytes) return fail(RPSF_E_BADARG, "null argument");
+  *bytes = (p->g_elems + p->gs_elems) * sizeof(cf);
+  return RPSF_OK;
+}
+
+static int check_geometry(const rpsf_plan* p, const rpsf_geometry* g) {
+  if (!g) return fail(RPSF_E_BADARG, "geometry is null");
+  if (g->height <= 0 || g->width <= 0) return fail(RPSF_E_BADARG, "image shape must be positive");
+  if (g->pad_mode < 0 || g->pad_mode > RPSF_PAD_WRAP) return fail(RPSF_E_BADARG, "unknown pad mode");
+  if (g->ld_image < g->width || g->ld_out < g->width) return fail(RPSF_E_BADARG, "row stride smaller than the image width");
+  if (g->image_row0 < 0 || g->image_rows <= 0 || g->image_row0 + g->image_rows > g->height || g->out_row0 < 0 ||
+      g->out_rows <= 0 || g->out_row0 + g->out_rows > g->height)
+    return fail(RPSF_E_BADARG, "resident row window lies outside the image");
+  const int N = p->N;
+  for (int i = 0; i < p->n_patches; ++i) {  // same reach as the reference's 2N padding (transform.py:119-123,141-149)
+    long r = (long)p->h_coords[2 * i] + g->origin_row, c = (long)p->h_coords[2 * i + 1] + g->origin_col;
+    if (r < -2L * N || r > (long)g->height + N || c < -2L * N || c > (long)g->width + N)
+      return fail(RPSF_E_BADARG, "patch corner (" + std::to_string(r) + ", " + std::to_string(c) +
+                                     ") lies outside the 2N-padded image");
+  }
+  return RPSF_OK;
+}
+
+static int launch_apply(rpsf_plan* p, const float* d_img, float* d_out, const rpsf_geometry& g, hipStream_t st,
+                        hipEvent_t mid) {
+  HIP_TRY(hipMemset2DAsync(d_out, (size_t)g.ld_out * sizeof(float), 0, (size_t)g.width * sizeof(float), g.out_rows, st));
+  if (mid) HIP_TRY(hipEventRecord(mid, st));
+  return dispatch_n(p->N, [&]<class C>() -> int {
+    PatchParams pp;
+    pp.im = ImageView{d_img, g.height, g.width, g.ld_image, g.pad_mode, g.pad_value, g.image_row0, g.image_rows};
+    pp.ov = OutView{d_out, g.height, g.width, g.ld_out, g.out_row0, g.out_rows};
+    pp.origin_row = g.origin_row, pp.origin_col = g.origin_col;
+    pp.coords = p->d_coords, pp.n_patches = p->n_patches;
+    pp.tab = p->d_tab, pp.tw = p->d_tw, pp.win = p->d_win, pp.g = p->d_g, pp.gs = p->d_gs;
+    constexpr int TEAMS = Launch<C>::TEAMS;
+    unsigned grid = (unsigned)((p->n_patches + TEAMS - 1) / TEAMS);
+    patch_kernel<C><<<dim3(grid), dim3(Launch<C>::WG), Launch<C>::LDS_BYTES, st>>>(pp);
+    HIP_TRY(hipGetLastError());
+    return RPSF_OK;
+  });
+}
+
+extern "C" int rpsf_apply_device(rpsf_plan* p, const void* image_dev, void* out_dev, const rpsf_geometry* geom,
+                                 void* stream) {
+  if (!p || !image_dev || !out_dev) return fail(RPSF_E_BADARG, "null argument");
+  if (!p->have_k) return fail(RPSF_E_STATE, "no transfer kernel installed (call rpsf_plan_set_transfer first)");
+  int rc = check_geometry(p, geom);
+  if (rc != RPSF_OK) return rc;
+  HIP_TRY(hipSetDevice(p->device));
+  hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : p->stream;
+  return launch_apply(p, reinterpret_cast<const float*>(image_dev), reinterpret_cast<float*>(out_dev), *geom, st, nullptr);
+}
+
+extern "C" int rpsf_apply(rpsf_plan* p, const float* image_host, int height, int width, int pad_mode, float pad_value,
+                          float* out_host) {
+  if (!p || !image_host || !out_host) return fail(RPSF_E_BADARG, "null argument");
+  if (!p->have_k) return fail(RPSF_E_STATE, "no transfer kernel installed (call rpsf_plan_set_transfer first)");
+  rpsf_geometry g{height, width, pad_mode, pad_value, 0, 0, 0, height, width, 0, height, width};
+  int rc = check_geometry(p, &g);
+  if (rc != RPSF_OK) return rc;
+  HIP_TRY(hipSetDevice(p->device));
+  const size_t bytes = (size_t)height * width * sizeof(float);
+  if (bytes > p->stage_bytes) {
+    (void)hipFree(p->d_img);
+    (void)hipFree(p->d_out);
+    p->d_img = p->d_out = nullptr;
+    p->stage_bytes = 0;
+    HIP_TRY(hipMalloc(&p->d_img, bytes));
+    HIP_TRY(hipMalloc(&p->d_out, bytes));
+    p->stage_bytes = bytes;
+  }
+  HIP_TRY(hipMemcpyAsync(p->d_img, image_host, bytes, hipMemcpyHostToDevice, p->stream));
+  rc = launch_apply(p, p->d_img, p->d_out, g, p->stream, nullptr);
+  if (rc != RPSF_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(out_host, p->d_out, bytes, hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return RPSF_OK;
+}
+
+extern "C" int rpsf_apply_device_timed(rpsf_plan* p, const void* image_dev, void* out_dev, const rpsf_geometry* geom,
+                                       int iters, float* total_ms, float* kernel_ms) {
+  if (!p || !image_dev || !out_dev || iters <= 0) return fail(RPSF_E_BADARG, "bad argument");
+  if (!p->have_k) return fail(RPSF_E_STATE, "no transfer kernel installed (call rpsf_plan_set_transfer first)");
+  int rc = check_geometry(p, geom);
+  if (rc != RPSF_OK) return rc;
+  HIP_TRY(hipSetDevice(p->device));
+  for (int i = 0; i < iters; ++i) {
+    HIP_TRY(hipEventRecord(p->ev[0], p->stream));
+    rc = launch_apply(p, reinterpret_cast<const float*>(image_dev), reinterpret_cast<float*>(out_dev), *geom,
+                      p->stream, p->ev[1]);
+    if (rc != RPSF_OK) return rc;
+    HIP_TRY(hipEventRecord(p->ev[2], p->stream));
+    HIP_TRY(hipEventSynchronize(p->ev[2]));
+    float ms = 0.f;
+    if (total_ms) {
+      HIP_TRY(hipEventElapsedTime(&ms, p->ev[0], p->ev[2]));
+      total_ms[i] = ms;
+    }
+    if (kernel_ms) {
+      HIP_TRY(hipEventElapsedTime(&ms, p->ev[1], p->ev[2]));
+      kernel_ms[i] = ms;
+    }
+  }
+  return RPSF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2 entry points
+// ------------------------------------------------------------------------------------------------
+extern "C" int rpsf_build_transfer_device(int device, size_t count, const void* s_dev, const void* t_dev, int is_f64,
+                                          double alpha, double epsilon, void* k_dev, void* stream) {
+  if (!s_dev || !t_dev || !k_dev) return fail(RPSF_E_BADARG, "null argument");
+  if (count == 0) return RPSF_OK;
+  HIP_TRY(hipSetDevice(device));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int block = 256;
+  size_t grid = (count + block - 1) / block;
+  if (is_f64)
+    build_transfer_kernel<double><<<dim3((unsigned)grid), dim3(block), 0, st>>>(
+        (const double*)s_dev, (const double*)t_dev, (double*)k_dev, count, alpha, epsilon);
+  else
+    build_transfer_kernel<float><<<dim3((unsigned)grid), dim3(block), 0, st>>>(
+        (const float*)s_dev, (const float*)t_dev, (float*)k_dev, count, (float)alpha, (float)epsilon);
+  HIP_TRY(hipGetLastError());
+  return RPSF_OK;
+}
+
+extern "C" int rpsf_build_transfer(int device, size_t count, const void* s_host, const void* t_host, int is_f64,
+                                   double alpha, double epsilon, void* k_host) {
+  if (!s_host || !t_host || !k_host) return fail(RPSF_E_BADARG, "null argument");
+  if (count == 0) return RPSF_OK;
+  HIP_TRY(hipSetDevice(device));
+  const size_t esz = is_f64 ? 16 : 8;
+  const size_t chunk = std::min<size_t>(count, (size_t)8 << 20);  // 8 Mi elements per round
+  char *ds = nullptr, *dt = nullptr, *dk = nullptr;
+  HIP_TRY(hipMalloc(&ds, chunk * esz));
+  HIP_TRY(hipMalloc(&dt, chunk * esz));
+  HIP_TRY(hipMalloc(&dk, chunk * esz));
+  int rc = RPSF_OK;
+  for (size_t first = 0; first < count && rc == RPSF_OK; first += chunk) {
+    size_t cnt = std::min(chunk, count - first);
+    hipError_t e = hipMemcpy(ds, (const char*)s_host + first * esz, cnt * esz, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dt, (const char*)t_host + first * esz, cnt * esz, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { rc = fail(RPSF_E_HIP, hipGetErrorString(e)); break; }
+    rc = rpsf_build_transfer_device(device, cnt, ds, dt, is_f64, alpha, epsilon, dk, nullptr);
+    if (rc != RPSF_OK) break;
+    e = hipMemcpy((char*)k_host + first * esz, dk, cnt * esz, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(RPSF_E_HIP, hipGetErrorString(e));
+  }
+  (void)hipFree(ds);
+  (void)hipFree(dt);
+  (void)hipFree(dk);
+  return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3 entry point
+// ------------------------------------------------------------------------------------------------
+extern "C" int rpsf_psf_fft(int device, int patch_size, int count, const float* values_host, float* fft_host) {
+  if (!values_host || !fft_host) return fail(RPSF_E_BADARG, "null argument");
+  if (count <= 0) return count == 0 ? RPSF_OK : fail(RPSF_E_BADARG, "negative count");
+  return dispatch_n(patch_size, [&]<class C>() -> int {
+    HIP_TRY(hipSetDevice(device));
+    uint16_t* d_tab = nullptr;
+    cf* d_tw = nullptr;
+    int rc = upload_tables<C>(device, &d_tab, &d_tw, nullptr);
+    if (rc != RPSF_OK) return rc;
+    const size_t per = (size_t)C::N * C::N;
+    int chunk = (int)std::max<size_t>(1, (size_t)(64u << 20) / (per * sizeof(cf)));
+    if (chunk > count) chunk = count;
+    float* d_in = nullptr;
+    cf* d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_in, per * sizeof(float) * chunk));
+    HIP_TRY(hipMalloc(&d_out, per * sizeof(cf) * chunk));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&psf_fft_kernel<C>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)Launch<C>::LDS_BYTES));
+    for (int first = 0; first < count && rc == RPSF_OK; first += chunk) {
+      int cnt = std::min(chunk, count - first);
+      hipError_t e = hipMemcpy(d_in, values_host + (size_t)first * per, per * sizeof(float) * cnt, hipMemcpyHostToDevice);
+      if (e != hipSuccess) { rc = fail(RPSF_E_HIP, hipGetErrorString(e)); break; }
+      constexpr int TEAMS = Launch<C>::TEAMS;
+      unsigned grid = (unsigned)((cnt + TEAMS - 1) / TEAMS);
+      psf_fft_kernel<C><<<dim3(grid), dim3(Launch<C>::WG), Launch<C>::LDS_BYTES, nullptr>>>(d_in, cnt, d_tab, d_tw, d_out);
+      e = hipGetLastError();
+      if (e == hipSuccess)
+        e = hipMemcpy(reinterpret_cast<cf*>(fft_host) + (size_t)first * per, d_out, per * sizeof(cf) * cnt, hipMemcpyDeviceToHost);
+      if (e != hipSuccess) rc = fail(RPSF_E_HIP, hipGetErrorString(e));
+    }
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    (void)hipFree(d_tab);
+    (void)hipFree(d_tw);
+    return rc;
+  });
+}
+
+// ------------------------------------------------------------------------------------------------
+// device memory helpers
+// ------------------------------------------------------------------------------------------------
+extern "C" int rpsf_dev_alloc(int device, size_t bytes, void** out) {
+  if (!out) return fail(RPSF_E_BADARG, "null argument");
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipMalloc(out, bytes ? bytes : 1));
+  return RPSF_OK;
+}
+extern "C" int rpsf_dev_free(int device, void* ptr) {
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipFree(ptr));
+  return RPSF_OK;
+}
+extern "C" int rpsf_memcpy_h2d(int device, void* dst, const void* src, size_t bytes) {
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+  return RPSF_OK;
+}
+extern "C" int rpsf_memcpy_d2h(int device, void* dst, const void* src, size_t bytes) {
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return RPSF_OK;
+}
+extern "C" int rpsf_device_synchronize(int device) {
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipDeviceSynchronize());
+  return RPSF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RCCL neighbour exchange (loaded lazily so that single-GPU use has no RCCL dependency)
+// ------------------------------------------------------------------------------------------------
+struct NcclId { char b[128]; };
+typedef int (*fn_get_uid)(NcclId*);
+typedef int (*fn_comm_init)(void**, int, NcclId, int);
+typedef int (*fn_comm_destroy)(void*);
+typedef int (*fn_sendrecv)(const void*, size_t, int, int, void*, hipStream_t);
+typedef int (*fn_recv)(void*, size_t, int, int, void*, hipStream_t);
+typedef int (*fn_group)(void);
+typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef const char* (*fn_errstr)(int);
+
+static struct {
+  void* h;
+  fn_get_uid get_uid;
+  fn_comm_init comm_init;
+  fn_comm_destroy comm_destroy;
+  fn_sendrecv send;
+  fn_recv recv;
+  fn_group group_start, group_end;
+  fn_allreduce allreduce;
+  fn_errstr errstr;
+} g_rccl;
+
+static int load_rccl() {
+  if (g_rccl.h) return RPSF_OK;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* h = nullptr;
+  for (const char* n : names) {
+    h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (h) break;
+  }
+  if (!h) return fail(RPSF_E_RCCL, std::string("cannot load librccl: ") + dlerror());
+  g_rccl.get_uid = (fn_get_uid)dlsym(h, "ncclGetUniqueId");
+  g_rccl.comm_init = (fn_comm_init)dlsym(h, "ncclCommInitRank");
+  g_rccl.comm_destroy = (fn_comm_destroy)dlsym(h, "ncclCommDestroy");
+  g_rccl.send = (fn_sendrecv)dlsym(h, "ncclSend");
+  g_rccl.recv = (fn_recv)dlsym(h, "ncclRecv");
+  g_rccl.group_start = (fn_group)dlsym(h, "ncclGroupStart");
+  g_rccl.group_end = (fn_group)dlsym(h, "ncclGroupEnd");
+  g_rccl.allreduce = (fn_allreduce)dlsym(h, "ncclAllReduce");
+  g_rccl.errstr = (fn_errstr)dlsym(h, "ncclGetErrorString");
+  if (!g_rccl.get_uid || !g_rccl.comm_init || !g_rccl.comm_destroy || !g_rccl.send || !g_rccl.recv ||
+      !g_rccl.group_start || !g_rccl.group_end || !g_rccl.allreduce)
+    return fail(RPSF_E_RCCL, "librccl is missing expected symbols");
+  g_rccl.h = h;
+  return RPSF_OK;
+}
+#define NCCL_TRY(expr)                                                                               \
+  do {                                                                                               \
+    int r_ = (expr);                                                                                 \
+    if (r_ != 0)                                                                                     \
+      return fail(RPSF_E_RCCL, std::string(#expr) + ": " + (g_rccl.errstr ? g_rccl.errstr(r_) : "rccl error")); \
+  } while (0)
+
+struct rpsf_comm {
+  void* comm = nullptr;
+  int device = 0, rank = 0, world = 1;
+  hipStream_t stream = nullptr;
+  double* d_scalar = nullptr;
+};
+
+extern "C" int rpsf_comm_unique_id(void* id128) {
+  if (!id128) return fail(RPSF_E_BADARG, "null argument");
+  int rc = load_rccl();
+  if (rc != RPSF_OK) return rc;
+  NCCL_TRY(g_rccl.get_uid(reinterpret_cast<NcclId*>(id128)));
+  return RPSF_OK;
+}
+
+extern "C" int rpsf_comm_create(rpsf_comm** out, int device, int rank, int world, const void* id128) {
+  if (!out || !id128 || rank < 0 || rank >= world) return fail(RPSF_E_BADARG, "bad argument");
+  int rc = load_rccl();
+  if (rc != RPSF_OK) return rc;
+  HIP_TRY(hipSetDevice(device));
+  auto* c = new rpsf_comm;
+  c->device = device, c->rank = rank, c->world = world;
+  NcclId id;
+  std::memcpy(&id, id128, sizeof(id));
+  int r = g_rccl.comm_init(&c->comm, world, id, rank);
+  if (r != 0) {
+    delete c;
+    return fail(RPSF_E_RCCL, std::string("ncclCommInitRank: ") + (g_rccl.errstr ? g_rccl.errstr(r) : "error"));
+  }
+  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMalloc(&c->d_scalar, 2 * sizeof(double));
+  if (e != hipSuccess) {
+    rpsf_comm_destroy(c);
+    return fail(RPSF_E_HIP, hipGetErrorString(e));
+  }
+  *out = c;
+  return RPSF_OK;
+}
+
+extern "C" void rpsf_comm_destroy(rpsf_comm* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->comm && g_rccl.comm_destroy) g_rccl.comm_destroy(c->comm);
+  (void)hipFree(c->d_scalar);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" int rpsf_comm_seam_exchange_add(rpsf_comm* c, const void* send_dev, size_t send_count, void* recv_dev,
+                                           size_t recv_count, void* accum_dev, void* stream) {
+  if (!c) return fail(RPSF_E_BADARG, "null comm");
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : c->stream;
+  const bool do_send = c->rank + 1 < c->world && send_count > 0;
+  const bool do_recv = c->rank > 0 && recv_count > 0;
+  if (do_send || do_recv) {
+    NCCL_TRY(g_rccl.group_start());
+    if (do_send) NCCL_TRY(g_rccl.send(send_dev, send_count, /*ncclFloat32*/ 7, c->rank + 1, c->comm, st));
+    if (do_recv) NCCL_TRY(g_rccl.recv(recv_dev, recv_count, 7, c->rank - 1, c->comm, st));
+    NCCL_TRY(g_rccl.group_end());
+  }
+  if (do_recv) {
+    if (!accum_dev) return fail(RPSF_E_BADARG, "accum_dev is null");
+    int block = 256;
+    size_t grid = ((recv_count + 3) / 4 + block - 1) / block;
+    add_rows_kernel<<<dim3((unsigned)grid), dim3(block), 0, st>>>(reinterpret_cast<float*>(accum_dev),
+                                                                 reinterpret_cast<const float*>(recv_dev), recv_count);
+    HIP_TRY(hipGetLastError());
+  }
+  return RPSF_OK;
+}
+
+extern "C" int rpsf_comm_allreduce_max(rpsf_comm* c, double* value) {
+  if (!c || !value) return fail(RPSF_E_BADARG, "null argument");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpyAsync(c->d_scalar, value, sizeof(double), hipMemcpyHostToDevice, c->stream));
+  NCCL_TRY(g_rccl.allreduce(c->d_scalar, c->d_scalar + 1, 1, /*ncclFloat64*/ 8, /*ncclMax*/ 2, c->comm, c->stream));
+  HIP_TRY(hipMemcpyAsync(value, c->d_scalar + 1, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RPSF_OK;
+}
+
+extern "C" int rpsf_comm_barrier(rpsf_comm* c, void* stream) {
+  if (!c) return fail(RPSF_E_BADARG, "null comm");
+  HIP_TRY(hipSetDevice(c->device));
+  if (stream) HIP_TRY(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+  double v = 0.0;
+  return rpsf_comm_allreduce_max(c, &v);
+}

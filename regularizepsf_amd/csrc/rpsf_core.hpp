@@ -1,0 +1,591 @@
+// rpsf_core.hpp - per-thread building blocks of the fused patch kernel (K1), written once and
+// used twice: by the HIP kernels in rpsf.hip and, compiled as plain C++, by the CPU thread
+// emulator in tests/emu/ (which drives these phases thread by thread to check the index algebra
+// without a GPU).  Nothing here is a port of reference code: the reference path
+// (regularizepsf/transform.py:151-169) is pad -> gather -> window -> fft2 -> *K -> ifft2 -> real ->
+// window -> overlap-add on NumPy arrays; this file restructures it for one workgroup per patch with
+// the whole patch resident in the register file.
+//
+// Algorithm (N x N real patch x, N = 2^LOGN):
+//   * pack column pairs:  z[r][c] = x[r][2c] + i x[r][2c+1],  r < N, c < N/2          (N*N/2 complex)
+//   * Z = 2-D complex DFT of z, done as 2 or 3 "stages"; every thread owns 64 complex values in
+//     registers and a stage is a small in-register DFT along the row digit and the column digit it
+//     owns, followed by twiddles; between stages the block transposes through LDS (two passes, real
+//     parts then imaginary parts, because a 256x256 patch is 256 KiB and LDS is 160 KiB).
+//   * in the last layout every thread holds, for each of its "slots", the two groups of bins
+//     {(q,m)} and {(-q,-m)} so that the bins p and -p needed to unpack the real-input spectrum
+//     X[kr][kc] = E + W^kc O,  X[kr][kc+N/2] = E - W^kc O   (E,O from Z[p], conj Z[-p])
+//     sit in the same thread.  There X is multiplied by the Hermitian-folded transfer kernel
+//     K_h(k) = (K(k) + conj K(-k))/2  (legal for any K because only Re(ifft2) is kept,
+//     transform.py:164) and re-packed; the inverse DFT then retraces the stages backwards.
+//   * the result is windowed again and overlap-added into the output image (transform.py:165-169).
+//
+// Index algebra.  Row index r has LR = LOGN bits split in digits (A1 | A2 | AL), most significant
+// first; packed-column index c has LC = LOGN-1 bits split in (B1 | B2).  Decimation in frequency:
+//   r = r1*2^(A2+AL) + r2*2^AL + r3      ->  kr = k1 + k2*2^A1 + k3*2^(A1+A2)
+//   c = c1*2^B2 + c2                     ->  kc = l1 + l2*2^B1
+// stage 1 owns (r1,c1) in registers, stage 2 (r2,c2), the last stage r3 (and no column digit, so
+// that -p maps element e of a group to element E-1-e of the partner group, for every group with
+// q != 0).  A1+B1 = 6 and A2+B2 = 6 (three-stage plans, N >= 128) or 0 (two-stage plans, N <= 64).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define RPSF_HD __host__ __device__ __forceinline__
+#else
+#define RPSF_HD inline
+#endif
+// lambdas passed to StaticFor must be inlined, or the register tile they touch is forced to memory
+#define RPSF_AI __attribute__((always_inline))
+
+namespace rpsf {
+
+typedef float cf __attribute__((ext_vector_type(2)));
+
+RPSF_HD cf cmul(cf a, cf b) { return cf{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+RPSF_HD cf cmulc(cf a, cf b) { return cf{a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y}; }  // a * conj(b)
+RPSF_HD cf cconj(cf a) { return cf{a.x, -a.y}; }
+RPSF_HD cf mul_pi(cf a) { return cf{-a.y, a.x}; }   // a * (+i)
+RPSF_HD cf mul_mi(cf a) { return cf{a.y, -a.x}; }   // a * (-i)
+// select on VALUES: `c ? arr[i] : arr[j]` would become a load through a selected pointer and
+// push the whole register tile into scratch
+RPSF_HD cf sel(bool c, cf a, cf b) { return cf{c ? a.x : b.x, c ? a.y : b.y}; }
+
+// cos(2 pi k / 64) for the first quadrant; everything else by symmetry so that 0 and +-1 are exact.
+constexpr float kCosQ[17] = {1.0f,          0.99518472f, 0.98078525f, 0.95694035f, 0.92387950f, 0.88192129f,
+                             0.83146960f,   0.77301043f, 0.70710677f, 0.63439327f, 0.55557024f, 0.47139674f,
+                             0.38268343f,   0.29028466f, 0.19509032f, 0.09801714f, 0.0f};
+constexpr float cos64(int k) {
+  k &= 63;
+  return k <= 16 ? kCosQ[k] : k <= 32 ? -kCosQ[32 - k] : k <= 48 ? -kCosQ[k - 32] : kCosQ[64 - k];
+}
+constexpr float sin64(int k) { return cos64(k - 16); }
+
+// d * W_n^i (forward, W = exp(-2 pi i / n)) or d * conj(W_n^i) (inverse); n = 2^LOG <= 64, i compile time.
+template <int I, int LOG, bool INV>
+RPSF_HD cf tw_const(cf d) {
+  constexpr int n = 1 << LOG;
+  constexpr int k = (I & (n - 1)) * (64 / n);  // index on the 64-point circle
+  if constexpr (k == 0) {
+    return d;
+  } else if constexpr (k == 16) {
+    return INV ? mul_pi(d) : mul_mi(d);
+  } else if constexpr (k == 32) {
+    return -d;
+  } else if constexpr (k == 48) {
+    return INV ? mul_mi(d) : mul_pi(d);
+  } else {
+    constexpr float c = cos64(k);
+    constexpr float s = INV ? sin64(k) : -sin64(k);  // W = c + i s
+    return cf{d.x * c - d.y * s, d.x * s + d.y * c};
+  }
+}
+
+template <int I, int CNT>
+struct StaticFor {
+  template <class F>
+  static RPSF_HD void run(F&& f) {
+    f.template operator()<I>();
+    StaticFor<I + 1, CNT>::run(f);
+  }
+};
+template <int CNT>
+struct StaticFor<CNT, CNT> {
+  template <class F>
+  static RPSF_HD void run(F&&) {}
+};
+
+// In-register DFT of 2^LOG points, natural order in and out, radix-2 decimation in frequency with
+// compile-time twiddles.  All indices are compile-time, so x[] lives in registers.
+template <int LOG, bool INV>
+struct FftSmall {
+  static RPSF_HD void run(cf* x) {
+    constexpr int h = 1 << (LOG - 1);
+    cf lo[h], hi[h];
+    StaticFor<0, h>::run([&]<int I>() RPSF_AI {
+      cf a = x[I], b = x[I + h];
+      lo[I] = a + b;
+      hi[I] = tw_const<I, LOG, INV>(a - b);
+    });
+    FftSmall<LOG - 1, INV>::run(lo);
+    FftSmall<LOG - 1, INV>::run(hi);
+    StaticFor<0, h>::run([&]<int I>() RPSF_AI {
+      x[2 * I] = lo[I];
+      x[2 * I + 1] = hi[I];
+    });
+  }
+};
+template <bool INV>
+struct FftSmall<0, INV> {
+  static RPSF_HD void run(cf*) {}
+};
+
+// DFT along one axis of the thread's register tile: for every "other" index o < OTHER,
+// elements v[BASE + o*OSTRIDE + i*STRIDE], i < 2^LOG.
+template <int LOG, int STRIDE, int OTHER, int OSTRIDE, bool INV, int BASE = 0>
+RPSF_HD void fft_axis(cf* v) {
+  if constexpr (LOG > 0) {
+    constexpr int n = 1 << LOG;
+    StaticFor<0, OTHER>::run([&]<int O>() RPSF_AI {
+      cf x[n];
+      StaticFor<0, n>::run([&]<int I>() RPSF_AI { x[I] = v[BASE + O * OSTRIDE + I * STRIDE]; });
+      FftSmall<LOG, INV>::run(x);
+      StaticFor<0, n>::run([&]<int I>() RPSF_AI { v[BASE + O * OSTRIDE + I * STRIDE] = x[I]; });
+    });
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Plan geometry
+// ------------------------------------------------------------------------------------------
+template <int LOGN_, int A1_, int A2_, int AL_, int B1_, int B2_>
+struct Cfg {
+  static constexpr int LOGN = LOGN_, N = 1 << LOGN_, NC = N / 2, LR = LOGN_, LC = LOGN_ - 1;
+  static constexpr int A1 = A1_, A2 = A2_, AL = AL_, B1 = B1_, B2 = B2_;
+  static constexpr bool S3 = (A2_ + B2_) != 0;  // three stages
+  static_assert(A1_ + A2_ + AL_ == LOGN_ && B1_ + B2_ == LOGN_ - 1, "digits must cover the index");
+  static_assert(A1_ + B1_ == 6 && (A2_ + B2_ == 6 || A2_ + B2_ == 0) && AL_ >= 1, "64 values per thread per stage");
+  static constexpr int E = 1 << AL_;          // bins per group (last-stage DFT length)
+  static constexpr int P = 64 / E;            // groups per thread in the last layout
+  static constexpr int NSLOT = P / 2;         // pair slots per thread
+  static constexpr int T = N * NC / 64;       // threads per patch
+  static constexpr int LQ = A1_ + A2_, Q = 1 << LQ, M = NC, G = Q * M;  // group (q,m): kr = q + Q*e, kc = m
+  static constexpr int NSPEC = (Q + M) / 2;   // slots whose groups have q == 0, m == 0 or are self-paired
+  static constexpr int WAVE = T < 64 ? T : 64;  // threads that share the special/general decision
+  // threads t' < spec_t(s) of slot s use the "special" K format (natural K_h plus the Nyquist-side array)
+  static constexpr int spec_t(int s) {
+    int left = NSPEC - s * T;
+    if (left <= 0) return 0;
+    int r = (left + WAVE - 1) / WAVE * WAVE;
+    return r > T ? T : r;
+  }
+  static constexpr int spec_prefix(int s) {  // threads in special format in slots < s
+    int acc = 0;
+    for (int i = 0; i < s; ++i) acc += spec_t(i);
+    return acc;
+  }
+  static constexpr int NSPEC_THREADSLOTS = spec_prefix(NSLOT);
+  static constexpr int GS_PER_PATCH = NSPEC_THREADSLOTS * 2 * E;  // complex values
+  static constexpr int G_PER_PATCH = N * NC;                      // complex values
+  // LDS floats for one exchange pass
+  static constexpr int X1_FLOATS = S3 ? (T / 64) * 64 * 65 : 0;
+  static constexpr int X2_STRIDE = S3 ? G : G + 1;
+  static constexpr int X2_FLOATS = E * X2_STRIDE;
+  static constexpr int LDS_FLOATS = X1_FLOATS > X2_FLOATS ? X1_FLOATS : X2_FLOATS;
+  static constexpr float SCALE = 1.0f / (2.0f * (float)N * (float)N);  // 1/4 (pair algebra) * 1/(N*N/2) (inverse DFT)
+};
+
+// gid' (the LDS-friendly group numbering) <-> (q, m)
+template <class C>
+RPSF_HD void gid_to_qm(int gid, int& q, int& m) {
+  if constexpr (C::S3) {
+    int lane = gid & 63, j = gid >> 6;
+    int k1 = lane >> C::B1, l1 = lane & ((1 << C::B1) - 1);
+    int k2 = j >> C::B2, l2 = j & ((1 << C::B2) - 1);
+    q = k1 + (k2 << C::A1);
+    m = l1 + (l2 << C::B1);
+  } else {
+    q = gid >> C::B1;
+    m = gid & ((1 << C::B1) - 1);
+  }
+}
+template <class C>
+RPSF_HD int qm_to_gid(int q, int m) {
+  if constexpr (C::S3) {
+    int k1 = q & ((1 << C::A1) - 1), k2 = q >> C::A1;
+    int l1 = m & ((1 << C::B1) - 1), l2 = m >> C::B1;
+    return (((k2 << C::B2) + l2) << 6) + (k1 << C::B1) + l1;
+  } else {
+    return (q << C::B1) + m;
+  }
+}
+template <class C>
+RPSF_HD int partner_gid(int gid) {
+  int q, m;
+  gid_to_qm<C>(gid, q, m);
+  return qm_to_gid<C>((C::Q - q) & (C::Q - 1), (C::M - m) & (C::M - 1));
+}
+
+// Slot table: tab[(t*NSLOT + s)*2 + member] = gid' of the group.  Special slots (self-paired groups,
+// q == 0 or m == 0) come first so they land in the leading threads of slot 0.  Host only.
+template <class C>
+inline void build_slot_table(uint16_t* tab) {
+  static_assert(C::G <= 65536, "gid must fit uint16");
+  const int G = C::G;
+  bool* seen = new bool[G]();
+  int* slots = new int[G];  // pairs, flattened
+  int ns = 0;
+  int selfs[4], nself = 0;
+  for (int g = 0; g < G; ++g)
+    if (partner_gid<C>(g) == g) selfs[nself++] = g;
+  for (int i = 0; i + 1 < nself; i += 2) {
+    slots[2 * ns] = selfs[i], slots[2 * ns + 1] = selfs[i + 1], ++ns;
+    seen[selfs[i]] = seen[selfs[i + 1]] = true;
+  }
+  for (int pass = 0; pass < 2; ++pass)  // pass 0: special pairs, pass 1: the rest
+    for (int g = 0; g < G; ++g) {
+      if (seen[g]) continue;
+      int q, m;
+      gid_to_qm<C>(g, q, m);
+      if (pass == 0 && q != 0 && m != 0) continue;
+      int p = partner_gid<C>(g);
+      slots[2 * ns] = g, slots[2 * ns + 1] = p, ++ns;
+      seen[g] = seen[p] = true;
+    }
+  for (int sigma = 0; sigma < ns; ++sigma) {
+    int s = sigma / C::T, t = sigma % C::T;
+    tab[(t * C::NSLOT + s) * 2 + 0] = (uint16_t)slots[2 * sigma];
+    tab[(t * C::NSLOT + s) * 2 + 1] = (uint16_t)slots[2 * sigma + 1];
+  }
+  delete[] seen;
+  delete[] slots;
+}
+
+// ------------------------------------------------------------------------------------------
+// Padding index maps (np.pad modes the kernel evaluates itself; transform.py:119-123)
+// ------------------------------------------------------------------------------------------
+enum PadMode : int { PAD_CONSTANT = 0, PAD_SYMMETRIC = 1, PAD_REFLECT = 2, PAD_EDGE = 3, PAD_WRAP = 4 };
+
+RPSF_HD int pad_index(int i, int n, int mode) {  // returns -1 for "constant value"
+  if (i >= 0 && i < n) return i;
+  switch (mode) {
+    case PAD_SYMMETRIC: {
+      int p = 2 * n, k = i % p;
+      if (k < 0) k += p;
+      return k < n ? k : p - 1 - k;
+    }
+    case PAD_REFLECT: {
+      if (n == 1) return 0;
+      int p = 2 * n - 2, k = i % p;
+      if (k < 0) k += p;
+      return k < n ? k : p - k;
+    }
+    case PAD_EDGE: return i < 0 ? 0 : n - 1;
+    case PAD_WRAP: {
+      int k = i % n;
+      return k < 0 ? k + n : k;
+    }
+    default: return -1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Thread coordinates in the stage-1 / stage-2 layouts
+// ------------------------------------------------------------------------------------------
+template <class C>
+struct ThreadPos {
+  int r_rest, c_rest;  // stage-1 layout: r = r1*2^(A2+AL) + r_rest, c = c1*2^B2 + c_rest
+  int r3;              // last row digit (same thread bits in the stage-1 and stage-2 layouts)
+  RPSF_HD explicit ThreadPos(int t) {
+    if constexpr (C::S3) {
+      r3 = t >> 6;
+      int r2 = (t >> C::B2) & ((1 << C::A2) - 1);
+      c_rest = t & ((1 << C::B2) - 1);
+      r_rest = (r2 << C::AL) + r3;
+    } else {
+      r3 = t;
+      r_rest = t;
+      c_rest = 0;
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// Stage 1 (digits r1, c1) and stage 2 (digits r2, c2); tw[k] = exp(-2 pi i k / N), k < N
+// ------------------------------------------------------------------------------------------
+template <class C, bool INV>
+RPSF_HD void stage1(int t, cf* v, const cf* __restrict__ tw) {
+  constexpr int NR = 1 << C::A1, NCOL = 1 << C::B1;
+  ThreadPos<C> tp(t);
+  if constexpr (!INV) {
+    fft_axis<C::A1, NCOL, NCOL, 1, false>(v);
+    StaticFor<1, NR>::run([&]<int K1>() RPSF_AI {
+      cf w = tw[(K1 * tp.r_rest) & (C::N - 1)];
+      StaticFor<0, NCOL>::run([&]<int C1>() RPSF_AI { v[K1 * NCOL + C1] = cmul(v[K1 * NCOL + C1], w); });
+    });
+    fft_axis<C::B1, 1, NR, NCOL, false>(v);
+    if constexpr (C::B2 > 0) {
+      StaticFor<1, NCOL>::run([&]<int L1>() RPSF_AI {
+        cf w = tw[(2 * L1 * tp.c_rest) & (C::N - 1)];
+        StaticFor<0, NR>::run([&]<int K1>() RPSF_AI { v[K1 * NCOL + L1] = cmul(v[K1 * NCOL + L1], w); });
+      });
+    }
+  } else {
+    if constexpr (C::B2 > 0) {
+      StaticFor<1, NCOL>::run([&]<int L1>() RPSF_AI {
+        cf w = tw[(2 * L1 * tp.c_rest) & (C::N - 1)];
+        StaticFor<0, NR>::run([&]<int K1>() RPSF_AI { v[K1 * NCOL + L1] = cmulc(v[K1 * NCOL + L1], w); });
+      });
+    }
+    fft_axis<C::B1, 1, NR, NCOL, true>(v);
+    StaticFor<1, NR>::run([&]<int K1>() RPSF_AI {
+      cf w = tw[(K1 * tp.r_rest) & (C::N - 1)];
+      StaticFor<0, NCOL>::run([&]<int C1>() RPSF_AI { v[K1 * NCOL + C1] = cmulc(v[K1 * NCOL + C1], w); });
+    });
+    fft_axis<C::A1, NCOL, NCOL, 1, true>(v);
+  }
+}
+
+template <class C, bool INV>
+RPSF_HD void stage2(int t, cf* v, const cf* __restrict__ tw) {
+  if constexpr (C::S3) {
+    constexpr int NR = 1 << C::A2, NCOL = 1 << C::B2;
+    ThreadPos<C> tp(t);
+    if constexpr (!INV) {
+      fft_axis<C::A2, NCOL, NCOL, 1, false>(v);
+      StaticFor<1, NR>::run([&]<int K2>() RPSF_AI {
+        cf w = tw[((K2 * tp.r3) << C::A1) & (C::N - 1)];  // W_{2^(A2+AL)}^(k2 r3)
+        StaticFor<0, NCOL>::run([&]<int C2>() RPSF_AI { v[K2 * NCOL + C2] = cmul(v[K2 * NCOL + C2], w); });
+      });
+      fft_axis<C::B2, 1, NR, NCOL, false>(v);
+    } else {
+      fft_axis<C::B2, 1, NR, NCOL, true>(v);
+      StaticFor<1, NR>::run([&]<int K2>() RPSF_AI {
+        cf w = tw[((K2 * tp.r3) << C::A1) & (C::N - 1)];
+        StaticFor<0, NCOL>::run([&]<int C2>() RPSF_AI { v[K2 * NCOL + C2] = cmulc(v[K2 * NCOL + C2], w); });
+      });
+      fft_axis<C::A2, NCOL, NCOL, 1, true>(v);
+    }
+  }
+}
+
+// Last stage: DFT over r3 inside every group (register index rho = group*E + e).
+template <class C, bool INV>
+RPSF_HD void stage_last(cf* v) {
+  fft_axis<C::AL, 1, C::P, C::E, INV>(v);
+}
+
+// ------------------------------------------------------------------------------------------
+// LDS exchanges.  PART 0 moves real parts, PART 1 imaginary parts.
+// X1: 64x64 transpose between register index and lane inside each 64-thread team (stage 1 <-> stage 2).
+// X2: stage-2 layout (or stage-1 layout for two-stage plans) <-> last layout, element-major:
+//     address = e * X2_STRIDE + gid'.
+// ------------------------------------------------------------------------------------------
+template <class C, int PART>
+RPSF_HD void x1_write(int t, const cf* v, float* lds) {
+  int base = (t >> 6) * (64 * 65) + (t & 63);
+  StaticFor<0, 64>::run([&]<int J>() RPSF_AI { lds[base + J * 65] = PART ? v[J].y : v[J].x; });
+}
+template <class C, int PART>
+RPSF_HD void x1_read(int t, cf* v, const float* lds) {
+  int base = (t >> 6) * (64 * 65) + (t & 63) * 65;
+  StaticFor<0, 64>::run([&]<int J>() RPSF_AI {
+    float f = lds[base + J];
+    if (PART) v[J].y = f; else v[J].x = f;
+  });
+}
+
+template <class C>
+RPSF_HD int x2_mid_base(int t) {  // address of register 0 of a stage-2-layout (or stage-1-layout) thread
+  if constexpr (C::S3) return (t >> 6) * C::X2_STRIDE + (t & 63);
+  else return t * C::X2_STRIDE;
+}
+template <class C, int PART>
+RPSF_HD void x2_mid_write(int t, const cf* v, float* lds) {
+  int base = x2_mid_base<C>(t);
+  constexpr int RS = C::S3 ? 64 : 1;
+  StaticFor<0, 64>::run([&]<int J>() RPSF_AI { lds[base + J * RS] = PART ? v[J].y : v[J].x; });
+}
+template <class C, int PART>
+RPSF_HD void x2_mid_read(int t, cf* v, const float* lds) {
+  int base = x2_mid_base<C>(t);
+  constexpr int RS = C::S3 ? 64 : 1;
+  StaticFor<0, 64>::run([&]<int J>() RPSF_AI {
+    float f = lds[base + J * RS];
+    if (PART) v[J].y = f; else v[J].x = f;
+  });
+}
+// last layout: gids[g] for the thread's P groups (slot-major, member minor)
+template <class C, int PART>
+RPSF_HD void x2_last_read(const int* gids, cf* v, const float* lds) {
+  StaticFor<0, C::P>::run([&]<int GI>() RPSF_AI {
+    StaticFor<0, C::E>::run([&]<int EE>() RPSF_AI {
+      float f = lds[EE * C::X2_STRIDE + gids[GI]];
+      if (PART) v[GI * C::E + EE].y = f; else v[GI * C::E + EE].x = f;
+    });
+  });
+}
+template <class C, int PART>
+RPSF_HD void x2_last_write(const int* gids, const cf* v, float* lds) {
+  StaticFor<0, C::P>::run([&]<int GI>() RPSF_AI {
+    StaticFor<0, C::E>::run([&]<int EE>() RPSF_AI {
+      lds[EE * C::X2_STRIDE + gids[GI]] = PART ? v[GI * C::E + EE].y : v[GI * C::E + EE].x;
+    });
+  });
+}
+
+// ------------------------------------------------------------------------------------------
+// Frequency-domain step: unpack real spectrum, multiply by folded K, re-pack.
+// ------------------------------------------------------------------------------------------
+struct PairOut { cf a, b; };
+// two-sided: bins p (value za) and -p (value zb); ka = K'_h(p), kb = K'_h(p + (0,N/2)); w = W_N^kc(p)
+RPSF_HD PairOut pair_op(cf za, cf zb, cf ka, cf kb, cf w) {
+  cf zbc = cconj(zb);
+  cf e2 = za + zbc;
+  cf o2 = mul_mi(za - zbc);
+  cf wo = cmul(w, o2);
+  cf y1 = cmul(e2 + wo, ka);
+  cf y2 = cmul(e2 - wo, kb);
+  cf ep = y1 + y2;
+  cf op = cmulc(y1 - y2, w);
+  PairOut r;
+  r.a = ep + mul_pi(op);
+  r.b = cconj(ep) + mul_pi(cconj(op));
+  return r;
+}
+
+// K layout in device memory, per patch:
+//   g  [i][t][2]            i < 32          -> registers rho = 2i, 2i+1 of thread t      (cf units)
+//   gs [prefix(s)*2E + r*spec_t(s) + t]     r < 2E, slot s, t < spec_t(s)
+template <class C>
+RPSF_HD void pointwise(int t, const int* gids, cf* v, const cf* __restrict__ g, const cf* __restrict__ gs,
+                       const cf* __restrict__ tw) {
+  StaticFor<0, C::NSLOT>::run([&]<int S>() RPSF_AI {
+    constexpr int E = C::E;
+    constexpr int ST = C::spec_t(S);
+    cf* za = v + (2 * S) * E;
+    cf* zb = za + E;
+    cf k[2 * E];
+    StaticFor<0, E>::run([&]<int I>() RPSF_AI {  // 2E values = E float4 loads
+      const cf* src = g + ((size_t)((2 * S * E) / 2 + I) * C::T + t) * 2;
+      k[2 * I] = src[0];
+      k[2 * I + 1] = src[1];
+    });
+    bool special = false;
+    if constexpr (ST > 0) special = (t & ~(C::WAVE - 1)) < ST;  // uniform over a 64-thread team
+    if (!special) {
+      int qa, ma;
+      gid_to_qm<C>(gids[2 * S], qa, ma);
+      cf w = tw[ma];
+      StaticFor<0, E>::run([&]<int EE>() RPSF_AI {
+        PairOut r = pair_op(za[EE], zb[E - 1 - EE], k[EE], k[E + (E - 1 - EE)], w);
+        za[EE] = r.a;
+        zb[E - 1 - EE] = r.b;
+      });
+    } else if constexpr (ST > 0) {
+      int ga = gids[2 * S], gb = gids[2 * S + 1];
+      bool self = partner_gid<C>(ga) == ga;
+      int qa, ma, qb, mb;
+      gid_to_qm<C>(ga, qa, ma);
+      gid_to_qm<C>(gb, qb, mb);
+      bool qza = qa == 0, qzb = qb == 0;
+      cf wa = tw[ma], wb = tw[mb];
+      const cf* gsp = gs + (size_t)C::spec_prefix(S) * 2 * E + t;
+      cf na[E], nb[E];
+      StaticFor<0, E>::run([&]<int EE>() RPSF_AI {
+        constexpr int R = E - 1 - EE, Z = (E - EE) % E;
+        cf az = za[Z], ar = za[R], bz = zb[Z], br = zb[R];
+        cf pa = sel(self, sel(qza, az, ar), sel(qza, bz, br));
+        cf pb = sel(self, sel(qzb, bz, br), sel(qzb, az, ar));
+        na[EE] = pair_op(za[EE], pa, k[EE], gsp[(size_t)EE * ST], wa).a;
+        nb[EE] = pair_op(zb[EE], pb, k[E + EE], gsp[(size_t)(E + EE) * ST], wb).a;
+      });
+      StaticFor<0, E>::run([&]<int EE>() RPSF_AI { za[EE] = na[EE]; zb[EE] = nb[EE]; });
+    }
+  });
+}
+
+// Value of the packed K arrays at (thread t, register rho).  kfull = one patch of the caller's
+// transfer kernel, N x N complex64 (IndexedCube values, transform.py:164).  which = 0: g, 1: gs.
+template <class C>
+RPSF_HD cf kh_at(const cf* __restrict__ kfull, int kr, int kc) {
+  cf a = kfull[kr * C::N + kc];
+  cf b = kfull[((C::N - kr) & (C::N - 1)) * C::N + ((C::N - kc) & (C::N - 1))];
+  return cf{(a.x + b.x) * (0.5f * C::SCALE), (a.y - b.y) * (0.5f * C::SCALE)};
+}
+template <class C>
+RPSF_HD bool slot_is_special(int s, int t) {
+  return (t & ~(C::WAVE - 1)) < C::spec_t(s);
+}
+template <class C>
+RPSF_HD cf pack_value(const cf* __restrict__ kfull, const uint16_t* __restrict__ tab, int t, int rho, int which) {
+  int s = rho / (2 * C::E), h = (rho / C::E) & 1, e = rho % C::E;
+  int gid = tab[(t * C::NSLOT + s) * 2 + h];
+  int q, m;
+  gid_to_qm<C>(gid, q, m);
+  int kr = q + C::Q * e, kc = m;
+  if (which == 1) return kh_at<C>(kfull, kr, kc + C::NC);
+  if (slot_is_special<C>(s, t) || h == 0) return kh_at<C>(kfull, kr, kc);
+  // general slot, member B: store K'_h(p_A + (0, N/2)) of the partner bin p_A = -p
+  int kra = (C::N - kr) & (C::N - 1), kca = (C::NC - kc) & (C::NC - 1);
+  return kh_at<C>(kfull, kra, kca + C::NC);
+}
+
+// ------------------------------------------------------------------------------------------
+// Image side: gather + window (transform.py:151-163) and window + overlap-add (transform.py:165-169)
+// ------------------------------------------------------------------------------------------
+struct ImageView {
+  const float* img;  // rows [row0, row0 + rows) of the H x W image, row stride ld
+  int H, W, ld;
+  int pad_mode;
+  float pad_value;
+  int row0, rows;
+};
+struct OutView {
+  float* out;  // rows [row0, row0 + rows) of the H x W output, row stride ld
+  int H, W, ld;
+  int row0, rows;
+};
+
+template <class C>
+RPSF_HD void load_patch(int t, cf* v, const ImageView& im, int pr, int pc, const float* __restrict__ win) {
+  ThreadPos<C> tp(t);
+  constexpr int NR = 1 << C::A1, NCOL = 1 << C::B1;
+  const bool inside = pr >= 0 && pc >= 0 && pr + C::N <= im.H && pc + C::N <= im.W && pr >= im.row0 &&
+                      pr + C::N <= im.row0 + im.rows;
+  StaticFor<0, NR>::run([&]<int R1>() RPSF_AI {
+    int r = (R1 << (C::A2 + C::AL)) + tp.r_rest;
+    float wr = win[r];
+    int y = pr + r;
+    int yy = inside ? y : pad_index(y, im.H, im.pad_mode);
+    int yl = yy - im.row0;
+    if (!inside && (yl < 0 || yl >= im.rows)) yy = -1;  // not resident (or constant padding): pad value
+    const float* row = im.img + (size_t)(yy < 0 ? 0 : yl) * im.ld;
+    StaticFor<0, NCOL>::run([&]<int C1>() RPSF_AI {
+      int c = (C1 << C::B2) + tp.c_rest;
+      int x0 = pc + 2 * c;
+      float p0, p1;
+      if (inside) {
+        p0 = row[x0];
+        p1 = row[x0 + 1];
+      } else {
+        int xa = pad_index(x0, im.W, im.pad_mode), xb = pad_index(x0 + 1, im.W, im.pad_mode);
+        p0 = (yy < 0 || xa < 0) ? im.pad_value : row[xa];
+        p1 = (yy < 0 || xb < 0) ? im.pad_value : row[xb];
+      }
+      v[R1 * NCOL + C1] = cf{p0 * (wr * win[2 * c]), p1 * (wr * win[2 * c + 1])};
+    });
+  });
+}
+
+// ADD(ptr, value) accumulates one pixel (atomic on the device, plain in the emulator)
+template <class C, class ADD>
+RPSF_HD void store_patch(int t, const cf* v, const OutView& ov, int pr, int pc, const float* __restrict__ win,
+                         ADD&& add) {
+  ThreadPos<C> tp(t);
+  constexpr int NR = 1 << C::A1, NCOL = 1 << C::B1;
+  StaticFor<0, NR>::run([&]<int R1>() RPSF_AI {
+    int r = (R1 << (C::A2 + C::AL)) + tp.r_rest;
+    float wr = win[r];
+    int y = pr + r, yl = y - ov.row0;
+    if (y >= 0 && y < ov.H && yl >= 0 && yl < ov.rows) {
+      float* row = ov.out + (size_t)yl * ov.ld;
+      StaticFor<0, NCOL>::run([&]<int C1>() RPSF_AI {
+        int c = (C1 << C::B2) + tp.c_rest;
+        int x0 = pc + 2 * c;
+        cf val = v[R1 * NCOL + C1];
+        if (x0 >= 0 && x0 < ov.W) add(row + x0, val.x * (wr * win[2 * c]));
+        if (x0 + 1 >= 0 && x0 + 1 < ov.W) add(row + x0 + 1, val.y * (wr * win[2 * c + 1]));
+      });
+    }
+  });
+}
+
+// Plans compiled into the library
+using Cfg256 = Cfg<8, 3, 2, 3, 3, 4>;
+using Cfg128 = Cfg<7, 4, 2, 1, 2, 4>;
+using Cfg64 = Cfg<6, 1, 0, 5, 5, 0>;
+using Cfg32 = Cfg<5, 2, 0, 3, 4, 0>;
+using Cfg16 = Cfg<4, 3, 0, 1, 3, 0>;
+
+}  // namespace rpsf

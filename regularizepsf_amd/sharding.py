@@ -1,0 +1,151 @@
+"""Row-band sharding of one apply across GPUs (one process per GPU).
+
+Patches are independent; the only coupling is the overlap-add across the seam between two bands of
+lattice rows (regularizepsf/transform.py:167-169 adds every patch into one image).  A band owns a
+contiguous run of lattice rows and the output rows from its first patch row down to the next band's
+first patch row.  Its last lattice row spills below that line; the spill (N/2 rows on the regular
+lattice) is sent to the next rank, which adds it to the top of its own band.  Nothing flows upwards,
+so the exchange is a single one-directional neighbour send/recv - no all-reduce.
+
+This module is geometry only (NumPy); the transport is supplied by the caller: RCCL through
+``_native.Comm`` in production, ``torch.distributed`` (gloo) in the CPU tests.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+from regularizepsf_amd import _native
+
+
+def pad_rows(rows: np.ndarray, height: int, pad_mode: str) -> np.ndarray:
+    """Image row that padded row index ``rows`` reads under np.pad ``pad_mode`` (-1: constant fill)."""
+    r = np.asarray(rows, dtype=np.int64)
+    inside = (r >= 0) & (r < height)
+    if pad_mode == "symmetric":
+        k = np.mod(r, 2 * height)
+        m = np.where(k < height, k, 2 * height - 1 - k)
+    elif pad_mode == "reflect":
+        if height == 1:
+            m = np.zeros_like(r)
+        else:
+            k = np.mod(r, 2 * height - 2)
+            m = np.where(k < height, k, 2 * height - 2 - k)
+    elif pad_mode == "edge":
+        m = np.clip(r, 0, height - 1)
+    elif pad_mode == "wrap":
+        m = np.mod(r, height)
+    elif pad_mode == "constant":
+        m = np.full_like(r, -1)
+    else:
+        msg = f"pad mode {pad_mode!r} is not evaluated by the kernel"
+        raise ValueError(msg)
+    return np.where(inside, r, m)
+
+
+@dataclass
+class BandPlan:
+    """What one rank holds and exchanges.  Row numbers are rows of the full image / full output."""
+
+    rank: int
+    patch_index: list[int]   # indices into the full coordinate list, in their original order
+    image_row0: int          # image rows [image_row0, image_row0 + image_rows) must be resident
+    image_rows: int
+    out_row0: int            # the rank's output buffer holds rows [out_row0, out_row0 + out_rows)
+    out_rows: int
+    own_rows: int            # of which the first own_rows are final after the exchange
+    send_offset_rows: int    # spill = buffer rows [send_offset_rows, send_offset_rows + send_rows) -> rank + 1
+    send_rows: int
+    recv_rows: int           # rows received from rank - 1, added to buffer rows [0, recv_rows)
+
+    def geometry(self, height: int, width: int, pad_mode: int, pad_value: float = 0.0) -> _native.Geometry:
+        return _native.Geometry(height, width, pad_mode, pad_value, 0, 0, self.image_row0, self.image_rows, width,
+                                self.out_row0, self.out_rows, width)
+
+
+def make_band_plans(coordinates, patch_size: int, height: int, world: int, pad_mode: str = "symmetric") -> list[BandPlan]:
+    """Split the patch list into ``world`` bands of whole lattice rows with (almost) equal patch counts."""
+    coords = np.asarray(coordinates, dtype=np.int64).reshape(-1, 2)
+    n = int(patch_size)
+    lattice_rows = np.unique(coords[:, 0])
+    if world < 1 or world > len(lattice_rows):
+        msg = f"cannot split {len(lattice_rows)} lattice rows into {world} bands"
+        raise ValueError(msg)
+    counts = np.array([(coords[:, 0] == r).sum() for r in lattice_rows])
+    cum = np.concatenate([[0], np.cumsum(counts)])
+    cuts = [0]
+    for g in range(1, world):  # cut where the cumulative patch count is closest to g/world of the total
+        target = cum[-1] * g / world
+        j = int(np.argmin(np.abs(cum - target)))
+        cuts.append(min(max(j, cuts[-1] + 1), len(lattice_rows) - (world - g)))
+    cuts.append(len(lattice_rows))
+
+    first = [int(lattice_rows[cuts[g]]) for g in range(world)]
+    last = [int(lattice_rows[cuts[g + 1] - 1]) for g in range(world)]
+    own0 = [0] + [min(max(first[g], 0), height) for g in range(1, world)] + [height]
+    plans = []
+    for g in range(world):
+        index = [i for i, r in enumerate(coords[:, 0]) if first[g] <= r <= last[g]]
+        reach_end = min(height, last[g] + n)  # last output row this band's patches touch, exclusive
+        if g + 1 < world and reach_end > own0[g + 2]:
+            msg = "band too thin: a patch would spill past the next band; use fewer ranks"
+            raise ValueError(msg)
+        out_row0 = own0[g]
+        out_end = max(reach_end, own0[g + 1]) if g + 1 < world else height
+        touched = pad_rows(np.arange(first[g], last[g] + n), height, pad_mode)
+        touched = touched[touched >= 0]
+        lo, hi = (int(touched.min()), int(touched.max()) + 1) if touched.size else (0, 1)
+        plans.append(BandPlan(
+            rank=g, patch_index=index, image_row0=lo, image_rows=hi - lo, out_row0=out_row0,
+            out_rows=out_end - out_row0, own_rows=own0[g + 1] - own0[g],
+            send_offset_rows=own0[g + 1] - out_row0, send_rows=out_end - own0[g + 1] if g + 1 < world else 0,
+            recv_rows=0))
+    for g in range(1, world):
+        plans[g].recv_rows = plans[g - 1].send_rows
+        if plans[g].recv_rows > plans[g].out_rows:
+            msg = "band too thin for the incoming seam rows; use fewer ranks"
+            raise ValueError(msg)
+    return plans
+
+
+class ShardedApply:
+    """One rank's share of a row-band-sharded apply: local K1 launch, then the RCCL seam exchange."""
+
+    def __init__(self, coordinates, kernel_for, patch_size: int, height: int, width: int, rank: int, world: int,
+                 device: int, comm: "_native.Comm | None", pad_mode: str = "symmetric") -> None:
+        """``kernel_for(index_list)`` returns the (len, N, N) complex64 transfer kernels of those patches."""
+        self.height, self.width, self.rank, self.world = height, width, rank, world
+        self.band = make_band_plans(coordinates, patch_size, height, world, pad_mode)[rank]
+        coords = [tuple(int(v) for v in coordinates[i]) for i in self.band.patch_index]
+        self.plan = _native.Plan(patch_size, coords, device=device)
+        self.plan.set_transfer(kernel_for(self.band.patch_index))
+        self.geometry = self.band.geometry(height, width, _native.PAD_MODES[pad_mode])
+        self.comm = comm
+        self.d_img = _native.DeviceBuffer(self.band.image_rows * width * 4, device)
+        self.d_out = _native.DeviceBuffer(self.band.out_rows * width * 4, device)
+        self.d_recv = _native.DeviceBuffer(max(1, self.band.recv_rows) * width * 4, device)
+
+    def upload_rows(self, band_image: np.ndarray) -> None:
+        """``band_image`` = image rows [image_row0, image_row0 + image_rows) as float32."""
+        if band_image.shape != (self.band.image_rows, self.width):
+            msg = f"expected image rows of shape {(self.band.image_rows, self.width)}, got {band_image.shape}"
+            raise ValueError(msg)
+        self.d_img.upload(np.ascontiguousarray(band_image, np.float32))
+
+    def step(self) -> None:
+        """Enqueue one apply + seam exchange on the plan's stream (asynchronous)."""
+        b, w = self.band, self.width
+        self.plan.apply_device(self.d_img.ptr, self.d_out.ptr, self.geometry)
+        if self.comm is not None and self.world > 1:
+            self.comm.seam_exchange_add(self.d_out.at(b.send_offset_rows * w * 4), b.send_rows * w,
+                                        self.d_recv.ptr, b.recv_rows * w, self.d_out.ptr, self.plan.stream)
+
+    def synchronize(self) -> None:
+        self.plan.synchronize()
+
+    def owned_rows(self) -> np.ndarray:
+        """The final output rows this rank owns: rows [out_row0, out_row0 + own_rows) of the full result."""
+        self.synchronize()
+        return self.d_out.download((self.band.own_rows, self.width))

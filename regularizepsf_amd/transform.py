@@ -1,0 +1,196 @@
+"""PSF-to-PSF transform applied patch-wise in the Fourier domain (API of regularizepsf/transform.py:25-177,284-289).
+
+``construct`` evaluates the regularized transfer kernel with the K2 HIP kernel and ``apply`` runs the
+fused K1 patch kernel; both go through the C ABI of include/rpsf.h.  There is no CPU fallback.
+Differences from the reference that a caller can observe are listed in INTEGRATION.md (float32
+arithmetic inside the kernel, patch sizes limited to 16..256 powers of two).
+"""
+
+from __future__ import annotations
+
+import math
+import numbers
+import pathlib
+
+import numpy as np
+
+from regularizepsf_amd import _native
+from regularizepsf_amd.exceptions import InvalidCoordinateError
+from regularizepsf_amd.util import IndexedCube
+
+
+class ArrayPSFTransform:
+    """Transformation from a source PSF to a target PSF that can be applied to images."""
+
+    def __init__(self, transfer_kernel: IndexedCube, device: int = 0) -> None:
+        self._transfer_kernel = transfer_kernel
+        self._device = device
+        self._plan: _native.Plan | None = None
+        self._plan_stamp: tuple | None = None
+
+    # ------------------------------------------------------------------ accessors (transform.py:37-51)
+    @property
+    def psf_shape(self) -> tuple[int, int]:
+        return self._transfer_kernel.sample_shape
+
+    @property
+    def coordinates(self) -> list[tuple[int, int]]:
+        return self._transfer_kernel.coordinates
+
+    def __len__(self) -> int:
+        return len(self._transfer_kernel)
+
+    def __eq__(self, other: object) -> bool:
+        if not isinstance(other, ArrayPSFTransform):
+            msg = "Can only compare ArrayPSFTransform to another ArrayPSFTransform."
+            raise TypeError(msg)
+        return self._transfer_kernel == other._transfer_kernel
+
+    __hash__ = None
+
+    # ------------------------------------------------------------------ construct (transform.py:53-83)
+    @classmethod
+    def construct(cls, source, target, alpha: float, epsilon: float, device: int = 0) -> "ArrayPSFTransform":
+        """Build the transform taking ``source`` to ``target``.
+
+        ``alpha`` controls the hardness of the transition from amplification to attenuation and
+        ``epsilon`` the maximum amplification.  Raises :class:`InvalidCoordinateError` when the two
+        models are not sampled at the same coordinates (transform.py:74-76).  The kernel keeps the
+        dtype of the PSF spectra (complex64 for float32 PSFs, complex128 for float64 ones).
+        """
+        if np.any(np.array(source.coordinates) != np.array(target.coordinates)):
+            msg = "Source PSF coordinates do not match target PSF coordinates."
+            raise InvalidCoordinateError(msg)
+        kernel = _native.build_transfer(source.fft_evaluations, target.fft_evaluations, alpha, epsilon, device=device)
+        return cls(IndexedCube(source.coordinates, kernel), device=device)
+
+    # ------------------------------------------------------------------ device plan
+    def invalidate(self) -> None:
+        """Drop the device copy of the transfer kernel (call after editing ``values`` in place)."""
+        if self._plan is not None:
+            self._plan.close()
+        self._plan, self._plan_stamp = None, None
+
+    def _checked_patch_size(self) -> int:
+        n0, n1 = self.psf_shape
+        if n0 != n1:
+            msg = f"operands could not be broadcast together: PSF samples must be square, got {self.psf_shape}"
+            raise ValueError(msg)
+        if n0 not in _native.SUPPORTED_PATCH_SIZES:
+            msg = f"patch size {n0} has no compiled kernel; supported sizes are {_native.SUPPORTED_PATCH_SIZES}"
+            raise NotImplementedError(msg)
+        return n0
+
+    def _device_plan(self) -> _native.Plan:
+        cube = self._transfer_kernel
+        stamp = (id(cube.values), cube._edits, len(cube))
+        if self._plan is None or self._plan_stamp != stamp:
+            self.invalidate()
+            n = self._checked_patch_size()
+            for coordinate in cube.coordinates:  # the reference slices with these (transform.py:141-149)
+                if not all(isinstance(v, numbers.Integral) for v in coordinate):
+                    msg = "slice indices must be integers: patch coordinates must be integral"
+                    raise TypeError(msg)
+            plan = _native.Plan(n, cube.coordinates, device=self._device)
+            plan.set_transfer(cube.values)
+            self._plan, self._plan_stamp = plan, stamp
+        return self._plan
+
+    # ------------------------------------------------------------------ apply (transform.py:85-177)
+    def apply(self, image: np.ndarray, workers: int | None = None, pad_mode: str = "symmetric",
+              saturation_threshold: float = math.inf, saturation_dilation: int = 1,
+              neighborhood_width: int = 7) -> np.ndarray:
+        """Apply the transform to an image and return the corrected image (float64, same shape).
+
+        Parameters follow the reference: ``pad_mode`` is any ``np.pad`` mode; pixels brighter than
+        ``saturation_threshold`` are replaced by their neighbourhood mean before correction and
+        restored afterwards.  ``workers`` is accepted for compatibility and ignored (the FFTs run
+        on the GPU).  The input is never modified.
+        """
+        del workers
+        image = np.asarray(image)
+        if image.ndim != 2:
+            msg = f"image must be two dimensional, got shape {image.shape}"
+            raise ValueError(msg)
+        n = self._checked_patch_size()
+        plan = self._device_plan()
+        height, width = image.shape
+        for r, c in self.coordinates:  # outside the 2N pad the reference's np.stack is ragged -> ValueError
+            if r < -2 * n or r > height + n or c < -2 * n or c > width + n:
+                msg = f"patch corner {(r, c)} lies outside the padded image"
+                raise ValueError(msg)
+
+        if saturation_threshold == math.inf and pad_mode in _native.PAD_MODES:  # nothing can exceed +inf
+            out = plan.apply(image.astype(np.float32, copy=False), _native.PAD_MODES[pad_mode])
+            return out.astype(np.float64)
+
+        # Host-side padding: np.pad modes the kernel does not evaluate, and the saturation branch,
+        # which works on the padded image (transform.py:119-138,171-172).
+        padded = np.pad(image.astype(float), ((2 * n, 2 * n), (2 * n, 2 * n)), mode=pad_mode)
+        raw = padded.copy()
+        mask = padded > saturation_threshold
+        if np.any(mask):
+            from scipy.ndimage import binary_dilation
+
+            mask = binary_dilation(mask, iterations=saturation_dilation)
+            padded[mask] = np.nan
+            half = neighborhood_width // 2
+            with np.errstate(all="ignore"):
+                for i, j in zip(*np.where(mask)):  # sequential: later pixels see earlier fills
+                    padded[i, j] = np.nanmean(padded[i - half : i + half, j - half : j + half])
+        corrected = self._apply_prepadded(padded.astype(np.float32), 2 * n)
+        corrected = corrected.astype(np.float64)
+        corrected[mask] = raw[mask]
+        return corrected[2 * n : height + 2 * n, 2 * n : width + 2 * n]
+
+    def _apply_prepadded(self, padded: np.ndarray, shift: int) -> np.ndarray:
+        """Run K1 on an image the host already padded by ``shift`` on every side (constant mode, shifted corners)."""
+        plan = self._device_plan()
+        h, w = padded.shape
+        img = _native.DeviceBuffer(padded.nbytes, self._device).upload(padded)
+        out = _native.DeviceBuffer(padded.nbytes, self._device)
+        try:
+            geom = _native.Geometry.whole(h, w, _native.PAD_MODES["constant"], 0.0)
+            geom.origin_row = geom.origin_col = shift
+            plan.apply_device(img.ptr, out.ptr, geom)
+            plan.synchronize()
+            return out.download((h, w))
+        finally:
+            img.free()
+            out.free()
+
+    #: pre-1.0 name of :meth:`apply` (the task description refers to it)
+    correct_image = apply
+
+    # ------------------------------------------------------------------ persistence (transform.py:220-282)
+    def save(self, path: pathlib.Path, overwrite: bool = False) -> None:
+        """Save to ``.h5`` (datasets ``coordinates`` and ``transfer_kernel``, as the reference writes them)."""
+        path = pathlib.Path(path)
+        if path.suffix == ".h5":
+            import h5py  # optional dependency, absent from the build image
+
+            with h5py.File(path, "w" if overwrite else "w-") as f:
+                f.create_dataset("coordinates", data=self.coordinates)
+                f.create_dataset("transfer_kernel", data=self._transfer_kernel.values)
+        elif path.suffix == ".fits":
+            msg = "FITS persistence is not implemented in this package yet (see DESIGN.md, out of scope)"
+            raise NotImplementedError(msg)
+        else:
+            msg = f"Unsupported file type {path.suffix}. Change to .h5 or .fits."
+            raise NotImplementedError(msg)
+
+    @classmethod
+    def load(cls, path: pathlib.Path, device: int = 0) -> "ArrayPSFTransform":
+        path = pathlib.Path(path)
+        if path.suffix == ".h5":
+            import h5py
+
+            with h5py.File(path, "r") as f:
+                coordinates = [tuple(c) for c in f["coordinates"][:]]
+                kernel = f["transfer_kernel"][:]
+            return cls(IndexedCube(coordinates, kernel), device=device)
+        if path.suffix == ".fits":
+            msg = "FITS persistence is not implemented in this package yet (see DESIGN.md, out of scope)"
+            raise NotImplementedError(msg)
+        msg = f"Unsupported file type {path.suffix}. Change to .h5 or .fits."
+        raise NotImplementedError(msg)

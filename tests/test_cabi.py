@@ -1,0 +1,68 @@
+"""The C-ABI shared library loads and exports every symbol include/rpsf.h declares; with no GPU the
+product path fails loudly instead of falling back to anything."""
+
+import ctypes
+import pathlib
+import re
+
+import numpy as np
+import pytest
+
+import regularizepsf_amd as rp
+from regularizepsf_amd import _native
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+
+
+def declared_functions():
+    text = (ROOT / "include" / "rpsf.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rpsf_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    handle = _native.lib()
+    names = declared_functions()
+    assert len(names) >= 25
+    for name in names:
+        assert hasattr(handle, name), f"{name} is declared in include/rpsf.h but not exported"
+    assert set(names) == set(_native._PROTOTYPES), "ctypes prototypes and header disagree"
+
+
+def test_geometry_struct_matches_header_layout():
+    assert ctypes.sizeof(_native.Geometry) == 12 * 4
+    g = _native.Geometry.whole(10, 20, 1)
+    assert (g.height, g.width, g.image_rows, g.ld_image, g.out_rows, g.ld_out) == (10, 20, 10, 20, 10, 20)
+
+
+def test_bad_arguments_are_reported_not_crashed():
+    handle = _native.lib()
+    assert handle.rpsf_plan_create(None, 0, 64, 1, None) == _native.E_BADARG
+    assert b"null" in handle.rpsf_last_error()
+    out = ctypes.c_void_p()
+    coords = np.zeros((1, 2), np.int32)
+    rc = handle.rpsf_plan_create(ctypes.byref(out), 0, 24, 1, coords.ctypes.data_as(ctypes.c_void_p))
+    assert rc == _native.E_UNSUPPORTED and b"24" in handle.rpsf_last_error()
+
+
+def _gpu_present():
+    try:
+        return _native.device_count() > 0
+    except _native.NativeError:
+        return False
+
+
+@pytest.mark.skipif(_gpu_present(), reason="only meaningful on a machine without a GPU")
+def test_no_gpu_means_loud_failure_not_cpu_fallback():
+    k = np.ones((1, 32, 32), np.complex64)
+    with pytest.raises(_native.NativeError):
+        rp.ArrayPSFTransform(rp.IndexedCube([(0, 0)], k)).apply(np.zeros((64, 64), np.float32))
+    src = rp.ArrayPSF(rp.IndexedCube([(0, 0)], np.ones((1, 16, 16))))
+    with pytest.raises(_native.NativeError):
+        rp.ArrayPSFTransform.construct(src, src, 3.0, 0.1)
+
+
+def test_product_never_imports_the_oracle():
+    for path in (ROOT / "regularizepsf_amd").rglob("*"):
+        if path.suffix in {".py", ".hip", ".hpp"}:
+            assert "oracle" not in path.read_text().replace("# oracle", ""), f"{path} mentions the oracle"
