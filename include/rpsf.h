@@ -58,6 +58,12 @@ void rpsf_plan_destroy(rpsf_plan* plan);
 int rpsf_plan_set_transfer(rpsf_plan* plan, const float* k_c64_host);
 /* Same, from a device-resident full K (e.g. produced by rpsf_build_transfer_device). */
 int rpsf_plan_set_transfer_device(rpsf_plan* plan, const void* k_c64_device);
+/* Overlap-add strategy (transform.py:167-169).  0 = automatic: on a regular half-overlap lattice of
+ * corners (calculate_covering output) patches of equal lattice parity never overlap, so each patch
+ * stores into one of four colour planes with plain coalesced stores and a small kernel sums the
+ * planes in a fixed order (deterministic); any other corner list falls back to float atomics.
+ * 1 = force atomics, 2 = force planes (error if the corners are not a lattice). */
+int rpsf_plan_set_overlap_mode(rpsf_plan* plan, int mode);
 /* Bytes of packed transfer kernel the patch kernel reads per apply (for roofline accounting). */
 int rpsf_plan_transfer_bytes(const rpsf_plan* plan, size_t* bytes);
 

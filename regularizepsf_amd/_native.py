@@ -13,7 +13,10 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_size_
 
 import numpy as np
 
-LIB_PATH = pathlib.Path(__file__).resolve().parent / "librpsf_hip.so"
+import os
+
+# RPSF_LIB points development / ablation builds at another build of the same library
+LIB_PATH = pathlib.Path(os.environ.get("RPSF_LIB") or pathlib.Path(__file__).resolve().parent / "librpsf_hip.so")
 
 PAD_MODES = {"constant": 0, "symmetric": 1, "reflect": 2, "edge": 3, "wrap": 4}
 SUPPORTED_PATCH_SIZES = (16, 32, 64, 128, 256)
@@ -53,6 +56,7 @@ _PROTOTYPES = {
     "rpsf_plan_set_transfer": (c_int, [c_void_p, c_void_p]),
     "rpsf_plan_set_transfer_device": (c_int, [c_void_p, c_void_p]),
     "rpsf_plan_transfer_bytes": (c_int, [c_void_p, POINTER(c_size_t)]),
+    "rpsf_plan_set_overlap_mode": (c_int, [c_void_p, c_int]),
     "rpsf_apply": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "rpsf_apply_device": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(Geometry), c_void_p]),
     "rpsf_apply_device_timed": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(Geometry), c_int, c_void_p, c_void_p]),
@@ -175,6 +179,10 @@ class Plan:
 
     def set_transfer_device(self, ptr: c_void_p) -> None:
         check(lib().rpsf_plan_set_transfer_device(self._handle, ptr))
+
+    def set_overlap_mode(self, mode: str) -> None:
+        """'auto' (colour planes on lattices, atomics otherwise), 'atomic' or 'planes'."""
+        check(lib().rpsf_plan_set_overlap_mode(self._handle, {"auto": 0, "atomic": 1, "planes": 2}[mode]))
 
     @property
     def transfer_bytes(self) -> int:

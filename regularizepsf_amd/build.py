@@ -25,7 +25,7 @@ def build(force: bool = False, verbose: bool = True) -> pathlib.Path:
     if not force and not is_stale():
         return TARGET
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-std=c++20", "-O3", "-munsafe-fp-atomics", "-shared", "-fPIC",
+    cmd = [hipcc, "--offload-arch=gfx950", "-std=c++20", "-O3", "-fno-slp-vectorize", "-munsafe-fp-atomics", "-shared", "-fPIC",
            "-o", str(TARGET), *[str(s) for s in SOURCES], "-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -14,6 +14,7 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -51,6 +52,9 @@ struct PatchParams {
   OutView ov;
   int origin_row, origin_col;
   const int32_t* coords;
+  const uint8_t* plane_of;  // colour-plane class per patch (plane mode only)
+  const int32_t* order;     // processing order (Z-order of the lattice), see patch_kernel
+  int chunk;                // patches per XCD chunk
   int n_patches;
   const uint16_t* tab;
   const cf* tw;
@@ -66,14 +70,25 @@ struct Launch {
   static constexpr size_t LDS_BYTES = (size_t)TEAMS * C::LDS_FLOATS * sizeof(float);
 };
 
+#if defined(RPSF_ABL_NOXCHG)
+template <class C, int PART, class A, class B, class D>
+__device__ __forceinline__ void x1_nop(A, B, D) {}
+template <class C, int PART, class A, class B, class D>
+__device__ __forceinline__ void x2_nop(A, B, D) {}
+#endif
+
 template <class C>
 __global__ __launch_bounds__(Launch<C>::WG) void patch_kernel(PatchParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int T = C::T;
   const int team = threadIdx.x / T, t = threadIdx.x % T;
-  int patch = blockIdx.x * Launch<C>::TEAMS + team;
-  const bool active = patch < p.n_patches;
-  if (!active) patch = p.n_patches - 1;  // keep the team in step with the barriers; its result is dropped
+  // Blocks are dealt round-robin over the 8 XCDs (b and b+8 share one).  `order` lists the patches
+  // along a Z-order curve of the lattice, cut into 8 contiguous chunks: XCD x works through chunk x,
+  // so the four patches that overlap a pixel usually read it through the same L2.  Speed only.
+  const int slot = (blockIdx.x >> 3) * Launch<C>::TEAMS + team;
+  const int seq = (blockIdx.x & 7) * p.chunk + slot;
+  const bool active = slot < p.chunk && seq < p.n_patches;
+  const int patch = p.order[active ? seq : p.n_patches - 1];  // inactive teams stay in step with the barriers
   float* lds = smem + team * C::LDS_FLOATS;
 
   int gids[C::P];
@@ -82,7 +97,28 @@ __global__ __launch_bounds__(Launch<C>::WG) void patch_kernel(PatchParams p) {
 
   const int pr = p.coords[2 * patch] + p.origin_row, pc = p.coords[2 * patch + 1] + p.origin_col;
   cf v[64];
-  load_patch<C>(t, v, p.im, pr, pc, p.win);
+#if defined(RPSF_ABL_NOLOAD)
+#pragma unroll
+  for (int j = 0; j < 64; ++j) v[j] = cf{(float)(t + j), (float)(t - j)};
+#else
+  {
+    const bool fast = patch_inside<C>(pr, pc, p.im.H, p.im.W, p.im.row0, p.im.rows) && pairs_aligned(p.im.img, p.im.ld, pc);
+    int* maps = reinterpret_cast<int*>(lds);
+    if (!fast) build_pad_maps<C>(t, maps, p.im, pr, pc);
+    __syncthreads();
+    load_patch<C>(t, v, p.im, pr, pc, p.win, fast, maps);
+    __syncthreads();  // the maps share LDS with the exchange buffer
+  }
+#endif
+#if defined(RPSF_ABL_NOXCHG)
+#define x1_write x1_nop
+#define x1_read x1_nop
+#define x2_mid_write x2_nop
+#define x2_mid_read x2_nop
+#define x2_last_write x2_nop
+#define x2_last_read x2_nop
+#define __syncthreads() ((void)0)
+#endif
   stage1<C, false>(t, v, p.tw);
   if constexpr (C::S3) {
     x1_write<C, 0>(t, v, lds);
@@ -104,9 +140,14 @@ __global__ __launch_bounds__(Launch<C>::WG) void patch_kernel(PatchParams p) {
   x2_last_read<C, 1>(gids, v, lds);
   __syncthreads();
 
-  stage_last<C, false>(v);
-  pointwise<C>(t, gids, v, p.g + (size_t)patch * C::G_PER_PATCH, p.gs + (size_t)patch * C::GS_PER_PATCH, p.tw);
-  stage_last<C, true>(v);
+  {
+    const cf* g = p.g + (size_t)patch * C::G_PER_PATCH;
+    cf k0[2 * C::E];
+    load_slot_k<C, 0>(t, k0, g);  // in flight during the last-stage DFT
+    stage_last<C, false>(v);
+    pointwise<C>(t, gids, v, k0, g, p.gs + (size_t)patch * C::GS_PER_PATCH, p.tw);
+    stage_last<C, true>(v);
+  }
 
   x2_last_write<C, 0>(gids, v, lds);
   __syncthreads();
@@ -127,8 +168,30 @@ __global__ __launch_bounds__(Launch<C>::WG) void patch_kernel(PatchParams p) {
     x1_read<C, 1>(t, v, lds);
   }
   stage1<C, true>(t, v, p.tw);
-  if (active)
-    store_patch<C>(t, v, p.ov, pr, pc, p.win, [](float* a, float val) { unsafeAtomicAdd(a, val); });
+  if (active) {
+    const int plane = p.ov.plane_stride ? p.plane_of[patch] : 0;
+#if defined(RPSF_ABL_NOSTORE)
+    {  // keep every value live but store (almost) nothing
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < 64; ++j) acc += v[j].x * v[j].y;
+      if (acc == 123456.789f) p.ov.out[threadIdx.x] = acc;
+    }
+#elif defined(RPSF_ABL_NOATOMIC)
+    store_patch<C>(t, v, p.ov, plane, pr, pc, p.win, [](float* a, float val) { *a = val; });
+#else
+    store_patch<C>(t, v, p.ov, plane, pr, pc, p.win, [](float* a, float val) { unsafeAtomicAdd(a, val); });
+#endif
+  }
+#if defined(RPSF_ABL_NOXCHG)
+#undef x1_write
+#undef x1_read
+#undef x2_mid_write
+#undef x2_mid_read
+#undef x2_last_write
+#undef x2_last_read
+#undef __syncthreads
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -297,6 +360,52 @@ __global__ void add_rows_kernel(float* __restrict__ accum, const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
+// K5: out = sum of the colour planes that have a patch over the pixel (fixed order: deterministic)
+// ------------------------------------------------------------------------------------------------
+struct SumParams {
+  const float* planes;
+  size_t plane_stride;
+  float* out;
+  int rows, W, ld_planes, ld_out;
+  int row0;            // full-image row of window row 0
+  int lat_r0, lat_c0;  // full-image coordinates of lattice tile (0, 0)
+  int half_shift;      // log2(N/2)
+  int nti, ntj;
+  const uint8_t* cover;  // nti x ntj, 4-bit class masks
+};
+
+__device__ __forceinline__ int cover_at(const SumParams& p, int y, int x) {
+  int ty = (y - p.lat_r0) >> p.half_shift, tx = (x - p.lat_c0) >> p.half_shift;
+  if (y < p.lat_r0 || x < p.lat_c0 || ty >= p.nti || tx >= p.ntj) return 0;
+  return p.cover[ty * p.ntj + tx];
+}
+
+__global__ void sum_planes_kernel(SumParams p) {
+  const int groups = (p.W + 3) >> 2;
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)groups * p.rows) return;
+  int yl = (int)(idx / groups), x = (int)(idx % groups) * 4;
+  int y = yl + p.row0;
+  size_t off = (size_t)yl * p.ld_planes + x;
+  float* o = p.out + (size_t)yl * p.ld_out + x;
+  int c0 = cover_at(p, y, x), c3 = cover_at(p, y, x + 3);
+  const bool vec = x + 3 < p.W && c0 == c3 && ((p.ld_planes | p.ld_out) & 3) == 0 &&
+                   ((reinterpret_cast<uintptr_t>(p.planes) | reinterpret_cast<uintptr_t>(p.out) | (p.plane_stride * 4)) & 15) == 0;
+  if (vec) {  // one tile, aligned: four 16-byte loads, one 16-byte store
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (c0 & (1 << k)) {
+        float4 a = *reinterpret_cast<const float4*>(p.planes + k * p.plane_stride + off);
+        acc.x += a.x, acc.y += a.y, acc.z += a.z, acc.w += a.w;
+      }
+    *reinterpret_cast<float4*>(o) = acc;
+  } else {
+    for (int i = 0; i < 4 && x + i < p.W; ++i) o[i] = sum_planes_at(p.planes, p.plane_stride, off + i, cover_at(p, y, x + i));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // plan
 // ------------------------------------------------------------------------------------------------
 struct rpsf_plan {
@@ -312,10 +421,81 @@ struct rpsf_plan {
   float* d_out = nullptr;
   bool have_k = false;
   hipStream_t stream = nullptr;
-  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t g_elems = 0, gs_elems = 0;
   std::vector<int32_t> h_coords;
+  // overlap-add strategy: colour planes on regular half-overlap lattices, float atomics otherwise
+  int overlap_mode = 0;  // 0 auto, 1 atomics, 2 planes
+  bool lattice = false;
+  int lat_r0 = 0, lat_c0 = 0, nti = 0, ntj = 0;
+  uint8_t* d_plane_of = nullptr;
+  uint8_t* d_cover = nullptr;
+  int32_t* d_order = nullptr;
+  float* d_planes = nullptr;
+  size_t planes_floats = 0;  // per plane
 };
+
+static uint64_t morton2(uint32_t a, uint32_t b) {
+  auto spread = [](uint64_t x) {
+    x &= 0xffffffffull;
+    x = (x | (x << 16)) & 0x0000ffff0000ffffull;
+    x = (x | (x << 8)) & 0x00ff00ff00ff00ffull;
+    x = (x | (x << 4)) & 0x0f0f0f0f0f0f0f0full;
+    x = (x | (x << 2)) & 0x3333333333333333ull;
+    x = (x | (x << 1)) & 0x5555555555555555ull;
+    return x;
+  };
+  return (spread(a) << 1) | spread(b);
+}
+
+// Regular lattice test + colour classes + tile coverage + processing order (host, at plan creation)
+static int setup_lattice(rpsf_plan* p) {
+  const int n = p->n_patches, half = p->N / 2;
+  int r0 = p->h_coords[0], c0 = p->h_coords[1], r1 = r0, c1 = c0;
+  for (int i = 0; i < n; ++i) {
+    r0 = std::min(r0, p->h_coords[2 * i]), r1 = std::max(r1, p->h_coords[2 * i]);
+    c0 = std::min(c0, p->h_coords[2 * i + 1]), c1 = std::max(c1, p->h_coords[2 * i + 1]);
+  }
+  {
+    std::vector<std::pair<uint64_t, int32_t>> keyed(n);
+    for (int i = 0; i < n; ++i)
+      keyed[i] = {morton2((uint32_t)((p->h_coords[2 * i] - r0) / half), (uint32_t)((p->h_coords[2 * i + 1] - c0) / half)), i};
+    std::sort(keyed.begin(), keyed.end());
+    std::vector<int32_t> order(n);
+    for (int i = 0; i < n; ++i) order[i] = keyed[i].second;
+    HIP_TRY(hipMalloc(&p->d_order, sizeof(int32_t) * n));
+    HIP_TRY(hipMemcpy(p->d_order, order.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+  }
+  bool ok = true;
+  for (int i = 0; i < n && ok; ++i)
+    ok = (p->h_coords[2 * i] - r0) % half == 0 && (p->h_coords[2 * i + 1] - c0) % half == 0;
+  std::vector<uint8_t> cls(n, 0), cover;
+  int nti = 0, ntj = 0;
+  if (ok) {
+    nti = (r1 - r0) / half + 2, ntj = (c1 - c0) / half + 2;
+    if ((size_t)nti * ntj > ((size_t)1 << 26)) ok = false;
+  }
+  if (ok) {
+    std::vector<uint8_t> seen((size_t)nti * ntj, 0);
+    cover.assign((size_t)nti * ntj, 0);
+    for (int i = 0; i < n && ok; ++i) {
+      int li = (p->h_coords[2 * i] - r0) / half, lj = (p->h_coords[2 * i + 1] - c0) / half;
+      if (seen[(size_t)li * ntj + lj]) ok = false;  // duplicate corner: two patches in one plane cell
+      seen[(size_t)li * ntj + lj] = 1;
+      cls[i] = (uint8_t)(((li & 1) << 1) | (lj & 1));
+      for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b) cover[(size_t)(li + a) * ntj + lj + b] |= (uint8_t)(1u << cls[i]);
+    }
+  }
+  p->lattice = ok;
+  if (!ok) return RPSF_OK;
+  p->lat_r0 = r0, p->lat_c0 = c0, p->nti = nti, p->ntj = ntj;
+  HIP_TRY(hipMalloc(&p->d_plane_of, n));
+  HIP_TRY(hipMemcpy(p->d_plane_of, cls.data(), n, hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&p->d_cover, cover.size()));
+  HIP_TRY(hipMemcpy(p->d_cover, cover.data(), cover.size(), hipMemcpyHostToDevice));
+  return RPSF_OK;
+}
 
 template <class F>
 static int dispatch_n(int N, F&& f) {
@@ -393,6 +573,8 @@ extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int
     HIP_TRY(hipMalloc(&p->d_coords, sizeof(int32_t) * 2 * n_patches));
     HIP_TRY(hipMemcpy(p->d_coords, coords_rc, sizeof(int32_t) * 2 * n_patches, hipMemcpyHostToDevice));
     p->h_coords.assign(coords_rc, coords_rc + 2 * (size_t)n_patches);
+    int rl = setup_lattice(p);
+    if (rl != RPSF_OK) return rl;
     return dispatch_n(N, [&]<class C>() -> int {
       int r2 = upload_tables<C>(device, &p->d_tab, &p->d_tw, &p->d_win);
       if (r2 != RPSF_OK) return r2;
@@ -430,6 +612,10 @@ extern "C" void rpsf_plan_destroy(rpsf_plan* p) {
   (void)hipFree(p->d_gs);
   (void)hipFree(p->d_img);
   (void)hipFree(p->d_out);
+  (void)hipFree(p->d_plane_of);
+  (void)hipFree(p->d_cover);
+  (void)hipFree(p->d_order);
+  (void)hipFree(p->d_planes);
   for (auto& e : p->ev)
     if (e) (void)hipEventDestroy(e);
   if (p->stream) (void)hipStreamDestroy(p->stream);
@@ -509,22 +695,63 @@ static int check_geometry(const rpsf_plan* p, const rpsf_geometry* g) {
 }
 
 static int launch_apply(rpsf_plan* p, const float* d_img, float* d_out, const rpsf_geometry& g, hipStream_t st,
-                        hipEvent_t mid) {
-  HIP_TRY(hipMemset2DAsync(d_out, (size_t)g.ld_out * sizeof(float), 0, (size_t)g.width * sizeof(float), g.out_rows, st));
+                        hipEvent_t mid, hipEvent_t mid2 = nullptr) {
+  const bool planes = p->overlap_mode == 2 || (p->overlap_mode == 0 && p->lattice);
+  if (planes && !p->lattice) return fail(RPSF_E_STATE, "colour planes need a regular half-overlap lattice of patch corners");
+  if (planes) {
+    size_t need = (size_t)g.out_rows * g.width;
+    need = (need + 3) & ~(size_t)3;
+    if (need > p->planes_floats) {
+      HIP_TRY(hipStreamSynchronize(st));
+      (void)hipFree(p->d_planes);
+      p->d_planes = nullptr, p->planes_floats = 0;
+      HIP_TRY(hipMalloc(&p->d_planes, 4 * need * sizeof(float)));
+      p->planes_floats = need;
+    }
+  } else {
+    HIP_TRY(hipMemset2DAsync(d_out, (size_t)g.ld_out * sizeof(float), 0, (size_t)g.width * sizeof(float), g.out_rows, st));
+  }
   if (mid) HIP_TRY(hipEventRecord(mid, st));
-  return dispatch_n(p->N, [&]<class C>() -> int {
+  int rc = dispatch_n(p->N, [&]<class C>() -> int {
     PatchParams pp;
     pp.im = ImageView{d_img, g.height, g.width, g.ld_image, g.pad_mode, g.pad_value, g.image_row0, g.image_rows};
-    pp.ov = OutView{d_out, g.height, g.width, g.ld_out, g.out_row0, g.out_rows};
+    if (planes)
+      pp.ov = OutView{p->d_planes, g.height, g.width, g.width, g.out_row0, g.out_rows, p->planes_floats};
+    else
+      pp.ov = OutView{d_out, g.height, g.width, g.ld_out, g.out_row0, g.out_rows, 0};
     pp.origin_row = g.origin_row, pp.origin_col = g.origin_col;
-    pp.coords = p->d_coords, pp.n_patches = p->n_patches;
+    pp.coords = p->d_coords, pp.plane_of = p->d_plane_of, pp.n_patches = p->n_patches;
     pp.tab = p->d_tab, pp.tw = p->d_tw, pp.win = p->d_win, pp.g = p->d_g, pp.gs = p->d_gs;
     constexpr int TEAMS = Launch<C>::TEAMS;
-    unsigned grid = (unsigned)((p->n_patches + TEAMS - 1) / TEAMS);
+    pp.order = p->d_order;
+    pp.chunk = ((p->n_patches + 7) / 8 + TEAMS - 1) / TEAMS * TEAMS;  // patches per XCD, whole workgroups
+    unsigned grid = (unsigned)(8 * (pp.chunk / TEAMS));
     patch_kernel<C><<<dim3(grid), dim3(Launch<C>::WG), Launch<C>::LDS_BYTES, st>>>(pp);
     HIP_TRY(hipGetLastError());
     return RPSF_OK;
   });
+  if (rc != RPSF_OK) return rc;
+  if (mid2) HIP_TRY(hipEventRecord(mid2, st));
+  if (planes) {
+    SumParams sp;
+    sp.planes = p->d_planes, sp.plane_stride = p->planes_floats, sp.out = d_out;
+    sp.rows = g.out_rows, sp.W = g.width, sp.ld_planes = g.width, sp.ld_out = g.ld_out, sp.row0 = g.out_row0;
+    sp.lat_r0 = p->lat_r0 + g.origin_row, sp.lat_c0 = p->lat_c0 + g.origin_col;
+    sp.half_shift = 0;
+    while ((1 << (sp.half_shift + 1)) < p->N) ++sp.half_shift;
+    sp.nti = p->nti, sp.ntj = p->ntj, sp.cover = p->d_cover;
+    size_t total = (size_t)((g.width + 3) / 4) * g.out_rows;
+    sum_planes_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(sp);
+    HIP_TRY(hipGetLastError());
+  }
+  return RPSF_OK;
+}
+
+extern "C" int rpsf_plan_set_overlap_mode(rpsf_plan* p, int mode) {
+  if (!p || mode < 0 || mode > 2) return fail(RPSF_E_BADARG, "mode must be 0 (auto), 1 (atomics) or 2 (colour planes)");
+  if (mode == 2 && !p->lattice) return fail(RPSF_E_STATE, "colour planes need a regular half-overlap lattice of patch corners");
+  p->overlap_mode = mode;
+  return RPSF_OK;
 }
 
 extern "C" int rpsf_apply_device(rpsf_plan* p, const void* image_dev, void* out_dev, const rpsf_geometry* geom,
@@ -574,16 +801,16 @@ extern "C" int rpsf_apply_device_timed(rpsf_plan* p, const void* image_dev, void
   for (int i = 0; i < iters; ++i) {
     HIP_TRY(hipEventRecord(p->ev[0], p->stream));
     rc = launch_apply(p, reinterpret_cast<const float*>(image_dev), reinterpret_cast<float*>(out_dev), *geom,
-                      p->stream, p->ev[1]);
+                      p->stream, p->ev[1], p->ev[2]);
     if (rc != RPSF_OK) return rc;
-    HIP_TRY(hipEventRecord(p->ev[2], p->stream));
-    HIP_TRY(hipEventSynchronize(p->ev[2]));
+    HIP_TRY(hipEventRecord(p->ev[3], p->stream));
+    HIP_TRY(hipEventSynchronize(p->ev[3]));
     float ms = 0.f;
     if (total_ms) {
-      HIP_TRY(hipEventElapsedTime(&ms, p->ev[0], p->ev[2]));
+      HIP_TRY(hipEventElapsedTime(&ms, p->ev[0], p->ev[3]));
       total_ms[i] = ms;
     }
-    if (kernel_ms) {
+    if (kernel_ms) {  // the patch kernel alone
       HIP_TRY(hipEventElapsedTime(&ms, p->ev[1], p->ev[2]));
       kernel_ms[i] = ms;
     }

@@ -40,7 +40,22 @@
 
 namespace rpsf {
 
+#if !defined(RPSF_PACKED_CF)
+// Scalar complex.  Measured on MI355X: v_pk_{add,mul,fma}_f32 issue at half the rate of the scalar
+// forms (no throughput gain) and need their operands in aligned register pairs, which cost the
+// packed build ~1800 v_mov and ~800 s_nop per thread; scalar code lets re/im be renamed freely.
+// Build with -fno-slp-vectorize so the compiler does not re-pack.
+struct alignas(8) cf {
+  float x, y;
+};
+RPSF_HD cf operator+(cf a, cf b) { return cf{a.x + b.x, a.y + b.y}; }
+RPSF_HD cf operator-(cf a, cf b) { return cf{a.x - b.x, a.y - b.y}; }
+RPSF_HD cf operator*(cf a, cf b) { return cf{a.x * b.x, a.y * b.y}; }
+RPSF_HD cf operator*(cf a, float b) { return cf{a.x * b, a.y * b}; }
+RPSF_HD cf operator-(cf a) { return cf{-a.x, -a.y}; }
+#else
 typedef float cf __attribute__((ext_vector_type(2)));
+#endif
 
 RPSF_HD cf cmul(cf a, cf b) { return cf{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
 RPSF_HD cf cmulc(cf a, cf b) { return cf{a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y}; }  // a * conj(b)
@@ -437,51 +452,78 @@ RPSF_HD PairOut pair_op(cf za, cf zb, cf ka, cf kb, cf w) {
 // K layout in device memory, per patch:
 //   g  [i][t][2]            i < 32          -> registers rho = 2i, 2i+1 of thread t      (cf units)
 //   gs [prefix(s)*2E + r*spec_t(s) + t]     r < 2E, slot s, t < spec_t(s)
-template <class C>
-RPSF_HD void pointwise(int t, const int* gids, cf* v, const cf* __restrict__ g, const cf* __restrict__ gs,
-                       const cf* __restrict__ tw) {
-  StaticFor<0, C::NSLOT>::run([&]<int S>() RPSF_AI {
-    constexpr int E = C::E;
-    constexpr int ST = C::spec_t(S);
-    cf* za = v + (2 * S) * E;
-    cf* zb = za + E;
-    cf k[2 * E];
-    StaticFor<0, E>::run([&]<int I>() RPSF_AI {  // 2E values = E float4 loads
-      const cf* src = g + ((size_t)((2 * S * E) / 2 + I) * C::T + t) * 2;
-      k[2 * I] = src[0];
-      k[2 * I + 1] = src[1];
+// K values of slot S (2E complex values, E 16-byte loads).  Issued one slot ahead of their use so the
+// HBM latency of the next slot hides behind the arithmetic of the current one.
+template <class C, int S>
+RPSF_HD void load_slot_k(int t, cf* k, const cf* __restrict__ g) {
+  constexpr int E = C::E;
+  StaticFor<0, E>::run([&]<int I>() RPSF_AI {
+#if defined(RPSF_ABL_NOK)
+    k[2 * I] = cf{1.0f + (float)I, 0.5f};
+    k[2 * I + 1] = cf{0.25f, (float)t};
+#else
+    struct alignas(16) Quad { cf a, b; };  // one 16-byte load per lane
+    Quad q = *reinterpret_cast<const Quad*>(g + ((size_t)(S * E + I) * C::T + t) * 2);
+    k[2 * I] = q.a;
+    k[2 * I + 1] = q.b;
+#endif
+  });
+}
+
+template <class C, int S>
+RPSF_HD void pointwise_slot(int t, const int* gids, cf* v, const cf* k, const cf* __restrict__ gs,
+                            const cf* __restrict__ tw) {
+  constexpr int E = C::E;
+  constexpr int ST = C::spec_t(S);
+  cf* za = v + (2 * S) * E;
+  cf* zb = za + E;
+  bool special = false;
+  if constexpr (ST > 0) special = (t & ~(C::WAVE - 1)) < ST;  // uniform over a 64-thread team
+  if (!special) {
+    int qa, ma;
+    gid_to_qm<C>(gids[2 * S], qa, ma);
+    cf w = tw[ma];
+    StaticFor<0, E>::run([&]<int EE>() RPSF_AI {
+      PairOut r = pair_op(za[EE], zb[E - 1 - EE], k[EE], k[E + (E - 1 - EE)], w);
+      za[EE] = r.a;
+      zb[E - 1 - EE] = r.b;
     });
-    bool special = false;
-    if constexpr (ST > 0) special = (t & ~(C::WAVE - 1)) < ST;  // uniform over a 64-thread team
-    if (!special) {
-      int qa, ma;
-      gid_to_qm<C>(gids[2 * S], qa, ma);
-      cf w = tw[ma];
-      StaticFor<0, E>::run([&]<int EE>() RPSF_AI {
-        PairOut r = pair_op(za[EE], zb[E - 1 - EE], k[EE], k[E + (E - 1 - EE)], w);
-        za[EE] = r.a;
-        zb[E - 1 - EE] = r.b;
-      });
-    } else if constexpr (ST > 0) {
-      int ga = gids[2 * S], gb = gids[2 * S + 1];
-      bool self = partner_gid<C>(ga) == ga;
-      int qa, ma, qb, mb;
-      gid_to_qm<C>(ga, qa, ma);
-      gid_to_qm<C>(gb, qb, mb);
-      bool qza = qa == 0, qzb = qb == 0;
-      cf wa = tw[ma], wb = tw[mb];
-      const cf* gsp = gs + (size_t)C::spec_prefix(S) * 2 * E + t;
-      cf na[E], nb[E];
-      StaticFor<0, E>::run([&]<int EE>() RPSF_AI {
-        constexpr int R = E - 1 - EE, Z = (E - EE) % E;
-        cf az = za[Z], ar = za[R], bz = zb[Z], br = zb[R];
-        cf pa = sel(self, sel(qza, az, ar), sel(qza, bz, br));
-        cf pb = sel(self, sel(qzb, bz, br), sel(qzb, az, ar));
-        na[EE] = pair_op(za[EE], pa, k[EE], gsp[(size_t)EE * ST], wa).a;
-        nb[EE] = pair_op(zb[EE], pb, k[E + EE], gsp[(size_t)(E + EE) * ST], wb).a;
-      });
-      StaticFor<0, E>::run([&]<int EE>() RPSF_AI { za[EE] = na[EE]; zb[EE] = nb[EE]; });
-    }
+  } else if constexpr (ST > 0) {
+    int ga = gids[2 * S], gb = gids[2 * S + 1];
+    bool self = partner_gid<C>(ga) == ga;
+    int qa, ma, qb, mb;
+    gid_to_qm<C>(ga, qa, ma);
+    gid_to_qm<C>(gb, qb, mb);
+    bool qza = qa == 0, qzb = qb == 0;
+    cf wa = tw[ma], wb = tw[mb];
+    const cf* gsp = gs + (size_t)C::spec_prefix(S) * 2 * E + t;
+    cf na[E], nb[E];
+    StaticFor<0, E>::run([&]<int EE>() RPSF_AI {
+      constexpr int R = E - 1 - EE, Z = (E - EE) % E;
+      cf az = za[Z], ar = za[R], bz = zb[Z], br = zb[R];
+      cf pa = sel(self, sel(qza, az, ar), sel(qza, bz, br));
+      cf pb = sel(self, sel(qzb, bz, br), sel(qzb, az, ar));
+      na[EE] = pair_op(za[EE], pa, k[EE], gsp[(size_t)EE * ST], wa).a;
+      nb[EE] = pair_op(zb[EE], pb, k[E + EE], gsp[(size_t)(E + EE) * ST], wb).a;
+    });
+    StaticFor<0, E>::run([&]<int EE>() RPSF_AI { za[EE] = na[EE]; zb[EE] = nb[EE]; });
+  }
+}
+
+// K layout in device memory, per patch:
+//   g  [i][t][2]            i < 32          -> registers rho = 2i, 2i+1 of thread t      (cf units)
+//   gs [prefix(s)*2E + r*spec_t(s) + t]     r < 2E, slot s, t < spec_t(s)
+// k0 = K values of slot 0, already loaded by the caller (before the last-stage DFT).
+template <class C>
+RPSF_HD void pointwise(int t, const int* gids, cf* v, cf* k0, const cf* __restrict__ g, const cf* __restrict__ gs,
+                       const cf* __restrict__ tw) {
+  constexpr int E = C::E;
+  cf k1[2 * E];
+  StaticFor<0, C::NSLOT>::run([&]<int S>() RPSF_AI {
+    cf* cur = (S & 1) ? k1 : k0;
+    cf* nxt = (S & 1) ? k0 : k1;
+    if constexpr (S + 1 < C::NSLOT) load_slot_k<C, S + 1>(t, nxt, g);
+    pointwise_slot<C, S>(t, gids, v, cur, gs, tw);
   });
 }
 
@@ -521,69 +563,141 @@ struct ImageView {
   float pad_value;
   int row0, rows;
 };
+// Overlap-add target.  plane_stride == 0: one H x W image accumulated with float atomics (any
+// corner list).  plane_stride != 0: four "colour planes"; a patch stores (plain, coalesced) into
+// the plane of its lattice parity class, inside which patches never overlap, and a small kernel
+// sums the planes afterwards (regular half-overlap lattices only).
 struct OutView {
-  float* out;  // rows [row0, row0 + rows) of the H x W output, row stride ld
+  float* out;  // rows [row0, row0 + rows) of the H x W output (plane 0 in plane mode), row stride ld
   int H, W, ld;
   int row0, rows;
+  size_t plane_stride;  // floats
 };
 
+// A patch may use 8-byte vector accesses when it lies inside the resident window and pixel pairs are aligned.
 template <class C>
-RPSF_HD void load_patch(int t, cf* v, const ImageView& im, int pr, int pc, const float* __restrict__ win) {
-  ThreadPos<C> tp(t);
-  constexpr int NR = 1 << C::A1, NCOL = 1 << C::B1;
-  const bool inside = pr >= 0 && pc >= 0 && pr + C::N <= im.H && pc + C::N <= im.W && pr >= im.row0 &&
-                      pr + C::N <= im.row0 + im.rows;
-  StaticFor<0, NR>::run([&]<int R1>() RPSF_AI {
-    int r = (R1 << (C::A2 + C::AL)) + tp.r_rest;
-    float wr = win[r];
-    int y = pr + r;
-    int yy = inside ? y : pad_index(y, im.H, im.pad_mode);
-    int yl = yy - im.row0;
-    if (!inside && (yl < 0 || yl >= im.rows)) yy = -1;  // not resident (or constant padding): pad value
-    const float* row = im.img + (size_t)(yy < 0 ? 0 : yl) * im.ld;
-    StaticFor<0, NCOL>::run([&]<int C1>() RPSF_AI {
-      int c = (C1 << C::B2) + tp.c_rest;
-      int x0 = pc + 2 * c;
-      float p0, p1;
-      if (inside) {
-        p0 = row[x0];
-        p1 = row[x0 + 1];
-      } else {
-        int xa = pad_index(x0, im.W, im.pad_mode), xb = pad_index(x0 + 1, im.W, im.pad_mode);
-        p0 = (yy < 0 || xa < 0) ? im.pad_value : row[xa];
-        p1 = (yy < 0 || xb < 0) ? im.pad_value : row[xb];
-      }
-      v[R1 * NCOL + C1] = cf{p0 * (wr * win[2 * c]), p1 * (wr * win[2 * c + 1])};
-    });
-  });
+RPSF_HD bool patch_inside(int pr, int pc, int H, int W, int row0, int rows) {
+  return pr >= 0 && pc >= 0 && pr + C::N <= H && pc + C::N <= W && pr >= row0 && pr + C::N <= row0 + rows;
+}
+RPSF_HD bool pairs_aligned(const void* base, int ld, int pc) {
+  return ((ld | pc) & 1) == 0 && (reinterpret_cast<uintptr_t>(base) & 7) == 0;
 }
 
-// ADD(ptr, value) accumulates one pixel (atomic on the device, plain in the emulator)
-template <class C, class ADD>
-RPSF_HD void store_patch(int t, const cf* v, const OutView& ov, int pr, int pc, const float* __restrict__ win,
-                         ADD&& add) {
+// Boundary patches: the np.pad index maps of the patch's N rows and N columns, built once per patch
+// in LDS (maps[0..N) = resident row index or -1, maps[N..2N) = column or -1).
+template <class C>
+RPSF_HD void build_pad_maps(int t, int* maps, const ImageView& im, int pr, int pc) {
+  for (int i = t; i < 2 * C::N; i += C::T) {
+    int v;
+    if (i < C::N) {
+      v = pad_index(pr + i, im.H, im.pad_mode);
+      if (v >= 0) {
+        v -= im.row0;
+        if (v < 0 || v >= im.rows) v = -1;  // not resident: treated as constant fill
+      }
+    } else {
+      v = pad_index(pc + (i - C::N), im.W, im.pad_mode);
+    }
+    maps[i] = v;
+  }
+}
+
+template <class C>
+RPSF_HD void load_patch(int t, cf* v, const ImageView& im, int pr, int pc, const float* __restrict__ win,
+                        bool fast, const int* maps) {
   ThreadPos<C> tp(t);
   constexpr int NR = 1 << C::A1, NCOL = 1 << C::B1;
+  if (fast) {
+    const float* base = im.img + (size_t)(pr - im.row0) * im.ld + pc;
+    StaticFor<0, NR>::run([&]<int R1>() RPSF_AI {
+      int r = (R1 << (C::A2 + C::AL)) + tp.r_rest;
+      float wr = win[r];
+      const float* row = base + (size_t)r * im.ld;
+      StaticFor<0, NCOL>::run([&]<int C1>() RPSF_AI {
+        int c = (C1 << C::B2) + tp.c_rest;
+        cf px = *reinterpret_cast<const cf*>(row + 2 * c);
+        cf w2 = *reinterpret_cast<const cf*>(win + 2 * c);
+        v[R1 * NCOL + C1] = px * (w2 * wr);
+      });
+    });
+  } else {
+    StaticFor<0, NR>::run([&]<int R1>() RPSF_AI {
+      int r = (R1 << (C::A2 + C::AL)) + tp.r_rest;
+      float wr = win[r];
+      int yl = maps[r];
+      const float* row = im.img + (size_t)(yl < 0 ? 0 : yl) * im.ld;
+      StaticFor<0, NCOL>::run([&]<int C1>() RPSF_AI {
+        int c = (C1 << C::B2) + tp.c_rest;
+        int xa = maps[C::N + 2 * c], xb = maps[C::N + 2 * c + 1];
+        float p0 = row[xa < 0 ? 0 : xa], p1 = row[xb < 0 ? 0 : xb];  // always in bounds; select afterwards
+        p0 = (yl < 0 || xa < 0) ? im.pad_value : p0;
+        p1 = (yl < 0 || xb < 0) ? im.pad_value : p1;
+        v[R1 * NCOL + C1] = cf{p0 * (wr * win[2 * c]), p1 * (wr * win[2 * c + 1])};
+      });
+    });
+  }
+}
+
+// ADD(ptr, value): accumulate one pixel (float atomic on the device, plain add in the emulator).
+template <class C, class ADD>
+RPSF_HD void store_patch(int t, const cf* v, const OutView& ov, int plane, int pr, int pc,
+                         const float* __restrict__ win, ADD&& add) {
+  ThreadPos<C> tp(t);
+  constexpr int NR = 1 << C::A1, NCOL = 1 << C::B1;
+  const bool planes = ov.plane_stride != 0;
+  float* dst = ov.out + (size_t)plane * ov.plane_stride;
+  if (planes && patch_inside<C>(pr, pc, ov.H, ov.W, ov.row0, ov.rows) && pairs_aligned(dst, ov.ld, pc)) {
+    float* base = dst + (size_t)(pr - ov.row0) * ov.ld + pc;
+    StaticFor<0, NR>::run([&]<int R1>() RPSF_AI {
+      int r = (R1 << (C::A2 + C::AL)) + tp.r_rest;
+      float wr = win[r];
+      float* row = base + (size_t)r * ov.ld;
+      StaticFor<0, NCOL>::run([&]<int C1>() RPSF_AI {
+        int c = (C1 << C::B2) + tp.c_rest;
+        cf w2 = *reinterpret_cast<const cf*>(win + 2 * c);
+        *reinterpret_cast<cf*>(row + 2 * c) = v[R1 * NCOL + C1] * (w2 * wr);
+      });
+    });
+    return;
+  }
   StaticFor<0, NR>::run([&]<int R1>() RPSF_AI {
     int r = (R1 << (C::A2 + C::AL)) + tp.r_rest;
     float wr = win[r];
     int y = pr + r, yl = y - ov.row0;
     if (y >= 0 && y < ov.H && yl >= 0 && yl < ov.rows) {
-      float* row = ov.out + (size_t)yl * ov.ld;
+      float* row = dst + (size_t)yl * ov.ld;
       StaticFor<0, NCOL>::run([&]<int C1>() RPSF_AI {
         int c = (C1 << C::B2) + tp.c_rest;
         int x0 = pc + 2 * c;
         cf val = v[R1 * NCOL + C1];
-        if (x0 >= 0 && x0 < ov.W) add(row + x0, val.x * (wr * win[2 * c]));
-        if (x0 + 1 >= 0 && x0 + 1 < ov.W) add(row + x0 + 1, val.y * (wr * win[2 * c + 1]));
+        float a0 = val.x * (wr * win[2 * c]), a1 = val.y * (wr * win[2 * c + 1]);
+        if (planes) {
+          if (x0 >= 0 && x0 < ov.W) row[x0] = a0;
+          if (x0 + 1 >= 0 && x0 + 1 < ov.W) row[x0 + 1] = a1;
+        } else {
+          if (x0 >= 0 && x0 < ov.W) add(row + x0, a0);
+          if (x0 + 1 >= 0 && x0 + 1 < ov.W) add(row + x0 + 1, a1);
+        }
       });
     }
   });
 }
 
+// Sum of the colour planes at one pixel.  cover = 4-bit mask of the classes that have a patch over the
+// pixel's lattice tile (planes are never cleared, so classes without a patch must not be read).
+RPSF_HD float sum_planes_at(const float* planes, size_t plane_stride, size_t offset, int cover) {
+  float acc = 0.0f;
+  if (cover & 1) acc += planes[offset];
+  if (cover & 2) acc += planes[plane_stride + offset];
+  if (cover & 4) acc += planes[2 * plane_stride + offset];
+  if (cover & 8) acc += planes[3 * plane_stride + offset];
+  return acc;
+}
+
 // Plans compiled into the library
-using Cfg256 = Cfg<8, 3, 2, 3, 3, 4>;
-using Cfg128 = Cfg<7, 4, 2, 1, 2, 4>;
+// digits chosen so that the 64 lanes of a wave cover 2 rows x 32 packed columns (2 x 256 B contiguous)
+using Cfg256 = Cfg<8, 4, 1, 3, 2, 5>;
+using Cfg128 = Cfg<7, 5, 1, 1, 1, 5>;
 using Cfg64 = Cfg<6, 1, 0, 5, 5, 0>;
 using Cfg32 = Cfg<5, 2, 0, 3, 4, 0>;
 using Cfg16 = Cfg<4, 3, 0, 1, 3, 0>;

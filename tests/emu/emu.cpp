@@ -31,7 +31,7 @@ static int emu_apply_t(int n_patches, const int32_t* coords, int H, int W, int p
   for (int t = 0; t < T; ++t)
     for (int i = 0; i < C::P; ++i) gids[(size_t)t * C::P + i] = tab[(size_t)t * C::P + i];
   ImageView im{img, H, W, W, pad_mode, pad_value, 0, H};
-  OutView ov{out, H, W, W, 0, H};
+  OutView ov{out, H, W, W, 0, H, 0};
   memset(out, 0, sizeof(float) * (size_t)H * W);
   auto add = [](float* p, float v) { *p += v; };
   for (int p = 0; p < n_patches; ++p) {
@@ -48,11 +48,12 @@ static int emu_apply_t(int n_patches, const int32_t* coords, int H, int W, int p
         }
       }
     int pr = coords[2 * p], pc = coords[2 * p + 1];
-    for (int t = 0; t < T; ++t) {
-      cf* v = &regs[(size_t)t * 64];
-      load_patch<C>(t, v, im, pr, pc, win.data());
-      stage1<C, false>(t, v, tw.data());
-    }
+    const bool fast = patch_inside<C>(pr, pc, H, W, 0, H) && pairs_aligned(img, W, pc);
+    int* maps = reinterpret_cast<int*>(lds.data());
+    if (!fast)
+      for (int t = 0; t < T; ++t) build_pad_maps<C>(t, maps, im, pr, pc);
+    for (int t = 0; t < T; ++t) load_patch<C>(t, &regs[(size_t)t * 64], im, pr, pc, win.data(), fast, maps);
+    for (int t = 0; t < T; ++t) stage1<C, false>(t, &regs[(size_t)t * 64], tw.data());
     if constexpr (C::S3) {
       for (int t = 0; t < T; ++t) x1_write<C, 0>(t, &regs[(size_t)t * 64], lds.data());
       for (int t = 0; t < T; ++t) x1_read<C, 0>(t, &regs[(size_t)t * 64], lds.data());
@@ -66,8 +67,10 @@ static int emu_apply_t(int n_patches, const int32_t* coords, int H, int W, int p
     for (int t = 0; t < T; ++t) x2_last_read<C, 1>(&gids[(size_t)t * C::P], &regs[(size_t)t * 64], lds.data());
     for (int t = 0; t < T; ++t) {
       cf* v = &regs[(size_t)t * 64];
+      cf k0[2 * C::E];
+      load_slot_k<C, 0>(t, k0, g.data());
       stage_last<C, false>(v);
-      pointwise<C>(t, &gids[(size_t)t * C::P], v, g.data(), gs.data(), tw.data());
+      pointwise<C>(t, &gids[(size_t)t * C::P], v, k0, g.data(), gs.data(), tw.data());
       stage_last<C, true>(v);
     }
     for (int t = 0; t < T; ++t) x2_last_write<C, 0>(&gids[(size_t)t * C::P], &regs[(size_t)t * 64], lds.data());
@@ -84,7 +87,7 @@ static int emu_apply_t(int n_patches, const int32_t* coords, int H, int W, int p
     for (int t = 0; t < T; ++t) {
       cf* v = &regs[(size_t)t * 64];
       stage1<C, true>(t, v, tw.data());
-      store_patch<C>(t, v, ov, pr, pc, win.data(), add);
+      store_patch<C>(t, v, ov, 0, pr, pc, win.data(), add);
     }
   }
   return 0;
