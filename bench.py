@@ -201,6 +201,11 @@ def main() -> None:
             "apply_avg_ms_events": round(float(np.mean(total_ms)), 4), "patches_this_rank": my_patches,
         },
     }
+    traffic_file = ROOT / "profiles" / "traffic_latest.json"
+    if world == 1 and args.config == 3 and traffic_file.exists():  # PMC counters cannot be read from inside the process
+        tr = json.loads(traffic_file.read_text())
+        line["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
+        line["roofline"]["traffic_source"] = tr["source"]
     if not args.no_cpu and world == 1:
         line["cpu_baseline"] = cpu_baseline(band_image, coords, kernel_for(list(range(len(coords)))))
     print(json.dumps(line), flush=True)

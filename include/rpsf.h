@@ -64,6 +64,12 @@ int rpsf_plan_set_transfer_device(rpsf_plan* plan, const void* k_c64_device);
  * planes in a fixed order (deterministic); any other corner list falls back to float atomics.
  * 1 = force atomics, 2 = force planes (error if the corners are not a lattice). */
 int rpsf_plan_set_overlap_mode(rpsf_plan* plan, int mode);
+/* Start-up stagger of the patch kernel's first resident workgroups (microseconds, 0 = off): spreads
+ * the gather / K-stream / store phases of different CUs in time so that HBM traffic overlaps compute. */
+int rpsf_plan_set_stagger(rpsf_plan* plan, int microseconds);
+/* Development aid: in builds compiled with -DRPSF_STAMPS the patch kernel records 16 phase
+ * timestamps per patch (10 ns ticks); this copies them out.  All zeros in a normal build. */
+int rpsf_plan_debug_stamps(rpsf_plan* plan, unsigned long long* host, size_t count);
 /* Bytes of packed transfer kernel the patch kernel reads per apply (for roofline accounting). */
 int rpsf_plan_transfer_bytes(const rpsf_plan* plan, size_t* bytes);
 

@@ -57,6 +57,8 @@ _PROTOTYPES = {
     "rpsf_plan_set_transfer_device": (c_int, [c_void_p, c_void_p]),
     "rpsf_plan_transfer_bytes": (c_int, [c_void_p, POINTER(c_size_t)]),
     "rpsf_plan_set_overlap_mode": (c_int, [c_void_p, c_int]),
+    "rpsf_plan_set_stagger": (c_int, [c_void_p, c_int]),
+    "rpsf_plan_debug_stamps": (c_int, [c_void_p, c_void_p, c_size_t]),
     "rpsf_apply": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "rpsf_apply_device": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(Geometry), c_void_p]),
     "rpsf_apply_device_timed": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(Geometry), c_int, c_void_p, c_void_p]),
@@ -183,6 +185,14 @@ class Plan:
     def set_overlap_mode(self, mode: str) -> None:
         """'auto' (colour planes on lattices, atomics otherwise), 'atomic' or 'planes'."""
         check(lib().rpsf_plan_set_overlap_mode(self._handle, {"auto": 0, "atomic": 1, "planes": 2}[mode]))
+
+    def debug_stamps(self) -> np.ndarray:
+        out = np.zeros((self.n_patches, 16), np.uint64)
+        check(lib().rpsf_plan_debug_stamps(self._handle, _ptr(out), out.size))
+        return out
+
+    def set_stagger(self, microseconds: int) -> None:
+        check(lib().rpsf_plan_set_stagger(self._handle, int(microseconds)))
 
     @property
     def transfer_bytes(self) -> int:

@@ -55,6 +55,9 @@ struct PatchParams {
   const uint8_t* plane_of;  // colour-plane class per patch (plane mode only)
   const int32_t* order;     // processing order (Z-order of the lattice), see patch_kernel
   int chunk;                // patches per XCD chunk
+  unsigned long long* stamps;  // diagnostic builds (RPSF_STAMPS): 16 phase timestamps per patch
+  int stagger_ticks;        // start-up stagger of the first resident workgroups, in 10 ns ticks (0 = off)
+  int stagger_blocks;       // how many leading blocks are staggered (= resident workgroup capacity)
   int n_patches;
   const uint16_t* tab;
   const cf* tw;
@@ -67,7 +70,8 @@ template <class C>
 struct Launch {
   static constexpr int WG = C::T < 64 ? 64 : C::T;
   static constexpr int TEAMS = WG / C::T;
-  static constexpr size_t LDS_BYTES = (size_t)TEAMS * C::LDS_FLOATS * sizeof(float);
+  static constexpr int TABLE_FLOATS = 3 * C::N;  // twiddles (N complex) + window (N), shared by the workgroup
+  static constexpr size_t LDS_BYTES = (size_t)(TABLE_FLOATS + TEAMS * C::LDS_FLOATS) * sizeof(float);
 };
 
 #if defined(RPSF_ABL_NOXCHG)
@@ -75,6 +79,22 @@ template <class C, int PART, class A, class B, class D>
 __device__ __forceinline__ void x1_nop(A, B, D) {}
 template <class C, int PART, class A, class B, class D>
 __device__ __forceinline__ void x2_nop(A, B, D) {}
+#endif
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also makes hipcc drain every
+// outstanding global load/store (s_waitcnt vmcnt(0)), which would expose the HBM latency of the K
+// prefetch and of the plane stores at each of the ~20 exchange barriers of a patch.
+// Orders one wave's own LDS traffic (a wave's DS operations complete in order; no other wave is involved).
+__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+#if defined(RPSF_STAMPS)
+#define STAMP(i)                                                                                         \
+  do {                                                                                                   \
+    if (threadIdx.x == 0) p.stamps[(size_t)patch * 16 + (i)] = __builtin_amdgcn_s_memrealtime();          \
+  } while (0)
+#else
+#define STAMP(i) ((void)0)
 #endif
 
 template <class C>
@@ -89,13 +109,31 @@ __global__ __launch_bounds__(Launch<C>::WG) void patch_kernel(PatchParams p) {
   const int seq = (blockIdx.x & 7) * p.chunk + slot;
   const bool active = slot < p.chunk && seq < p.n_patches;
   const int patch = p.order[active ? seq : p.n_patches - 1];  // inactive teams stay in step with the barriers
-  float* lds = smem + team * C::LDS_FLOATS;
+  // De-phase the chip: without this every CU gathers, streams K and stores at the same instants, HBM
+  // alternates between saturated and idle, and no memory phase overlaps any compute phase.  Delaying
+  // the first resident workgroup of each CU by a different amount spreads the phases for the whole
+  // launch (later workgroups inherit the offset of the one they replace).  Speed only.
+  if (p.stagger_ticks > 0 && (int)blockIdx.x < p.stagger_blocks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long wait = (unsigned long long)(((blockIdx.x >> 3) * 0x9E3779B1u >> 22) & 1023) * p.stagger_ticks >> 10;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+  }
+  // twiddle and window tables live in LDS: their reads must not queue behind the patch's global loads
+  cf* tw = reinterpret_cast<cf*>(smem);
+  float* win = smem + 2 * C::N;
+  for (int i = threadIdx.x; i < C::N; i += Launch<C>::WG) {
+    tw[i] = p.tw[i];
+    win[i] = p.win[i];
+  }
+  float* lds = smem + Launch<C>::TABLE_FLOATS + team * C::LDS_FLOATS;
+  STAMP(0);
 
   int gids[C::P];
 #pragma unroll
   for (int i = 0; i < C::P; ++i) gids[i] = p.tab[t * C::P + i];
 
   const int pr = p.coords[2 * patch] + p.origin_row, pc = p.coords[2 * patch + 1] + p.origin_col;
+  const cf* g = p.g + (size_t)patch * C::G_PER_PATCH;
   cf v[64];
 #if defined(RPSF_ABL_NOLOAD)
 #pragma unroll
@@ -105,10 +143,17 @@ __global__ __launch_bounds__(Launch<C>::WG) void patch_kernel(PatchParams p) {
     const bool fast = patch_inside<C>(pr, pc, p.im.H, p.im.W, p.im.row0, p.im.rows) && pairs_aligned(p.im.img, p.im.ld, pc);
     int* maps = reinterpret_cast<int*>(lds);
     if (!fast) build_pad_maps<C>(t, maps, p.im, pr, pc);
-    __syncthreads();
-    load_patch<C>(t, v, p.im, pr, pc, p.win, fast, maps);
-    __syncthreads();  // the maps share LDS with the exchange buffer
+    lds_barrier();
+    load_patch<C>(t, v, p.im, pr, pc, win, fast, maps);
+    lds_barrier();  // the maps share LDS with the exchange buffer
   }
+#endif
+#if defined(RPSF_KPREFETCH) && !defined(RPSF_ABL_NOK)
+  // Touch every 128-byte line of this patch's packed K now (4 per thread): HBM delivers it to L2 /
+  // Infinity Cache while the forward DFT runs, so the real loads below do not each pay an HBM round trip.
+  float kpf[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) kpf[i] = reinterpret_cast<const float*>(g)[(size_t)(i * T + t) * 32];
 #endif
 #if defined(RPSF_ABL_NOXCHG)
 #define x1_write x1_nop
@@ -117,57 +162,73 @@ __global__ __launch_bounds__(Launch<C>::WG) void patch_kernel(PatchParams p) {
 #define x2_mid_read x2_nop
 #define x2_last_write x2_nop
 #define x2_last_read x2_nop
-#define __syncthreads() ((void)0)
+#define lds_barrier() ((void)0)
+#define wave_lds_sync() ((void)0)
 #endif
-  stage1<C, false>(t, v, p.tw);
+  STAMP(1);
+  stage1<C, false>(t, v, tw);
+  STAMP(2);
   if constexpr (C::S3) {
+    // X1 is a register<->lane transpose inside each wave (private LDS region): wave-level ordering is enough
     x1_write<C, 0>(t, v, lds);
-    __syncthreads();
+    wave_lds_sync();
     x1_read<C, 0>(t, v, lds);
-    __syncthreads();
+    wave_lds_sync();
     x1_write<C, 1>(t, v, lds);
-    __syncthreads();
+    wave_lds_sync();
     x1_read<C, 1>(t, v, lds);
-    __syncthreads();
-    stage2<C, false>(t, v, p.tw);
+    STAMP(3);
+    stage2<C, false>(t, v, tw);
+    STAMP(4);
   }
+  KRing<C> kring;
+  kring_fill<C>(t, kring, g);  // first K slots: in flight across the exchange below (raw barriers do not drain VMEM)
+  lds_barrier();  // every wave has left its X1 region (X2 uses the whole buffer)
   x2_mid_write<C, 0>(t, v, lds);
-  __syncthreads();
+  lds_barrier();
   x2_last_read<C, 0>(gids, v, lds);
-  __syncthreads();
+  lds_barrier();
   x2_mid_write<C, 1>(t, v, lds);
-  __syncthreads();
+  lds_barrier();
   x2_last_read<C, 1>(gids, v, lds);
-  __syncthreads();
+  // no barrier: every X2 word is read by exactly one thread, the same one that rewrites it below
 
-  {
-    const cf* g = p.g + (size_t)patch * C::G_PER_PATCH;
-    cf k0[2 * C::E];
-    load_slot_k<C, 0>(t, k0, g);  // in flight during the last-stage DFT
-    stage_last<C, false>(v);
-    pointwise<C>(t, gids, v, k0, g, p.gs + (size_t)patch * C::GS_PER_PATCH, p.tw);
-    stage_last<C, true>(v);
-  }
+  STAMP(5);
+  stage_last<C, false>(v);
+  STAMP(6);
+  pointwise<C>(t, gids, v, kring, g, p.gs + (size_t)patch * C::GS_PER_PATCH, tw);
+  STAMP(7);
+  stage_last<C, true>(v);
+  STAMP(8);
+
+#if defined(RPSF_KPREFETCH) && !defined(RPSF_ABL_NOK)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(kpf[i]));  // keep the prefetch loads alive
+#endif
 
   x2_last_write<C, 0>(gids, v, lds);
-  __syncthreads();
+  lds_barrier();
   x2_mid_read<C, 0>(t, v, lds);
-  __syncthreads();
+  lds_barrier();
   x2_last_write<C, 1>(gids, v, lds);
-  __syncthreads();
+  lds_barrier();
   x2_mid_read<C, 1>(t, v, lds);
-  __syncthreads();
+  lds_barrier();
+  STAMP(9);
   if constexpr (C::S3) {
-    stage2<C, true>(t, v, p.tw);
+    stage2<C, true>(t, v, tw);
+    STAMP(10);
     x1_write<C, 0>(t, v, lds);
-    __syncthreads();
+    wave_lds_sync();
     x1_read<C, 0>(t, v, lds);
-    __syncthreads();
+    wave_lds_sync();
     x1_write<C, 1>(t, v, lds);
-    __syncthreads();
+    wave_lds_sync();
     x1_read<C, 1>(t, v, lds);
   }
-  stage1<C, true>(t, v, p.tw);
+  STAMP(11);
+  stage1<C, true>(t, v, tw);
+  STAMP(12);
   if (active) {
     const int plane = p.ov.plane_stride ? p.plane_of[patch] : 0;
 #if defined(RPSF_ABL_NOSTORE)
@@ -178,9 +239,9 @@ __global__ __launch_bounds__(Launch<C>::WG) void patch_kernel(PatchParams p) {
       if (acc == 123456.789f) p.ov.out[threadIdx.x] = acc;
     }
 #elif defined(RPSF_ABL_NOATOMIC)
-    store_patch<C>(t, v, p.ov, plane, pr, pc, p.win, [](float* a, float val) { *a = val; });
+    store_patch<C>(t, v, p.ov, plane, pr, pc, win, [](float* a, float val) { *a = val; });
 #else
-    store_patch<C>(t, v, p.ov, plane, pr, pc, p.win, [](float* a, float val) { unsafeAtomicAdd(a, val); });
+    store_patch<C>(t, v, p.ov, plane, pr, pc, win, [](float* a, float val) { unsafeAtomicAdd(a, val); });
 #endif
   }
 #if defined(RPSF_ABL_NOXCHG)
@@ -190,8 +251,10 @@ __global__ __launch_bounds__(Launch<C>::WG) void patch_kernel(PatchParams p) {
 #undef x2_mid_read
 #undef x2_last_write
 #undef x2_last_read
-#undef __syncthreads
+#undef lds_barrier
+#undef wave_lds_sync
 #endif
+  STAMP(13);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -426,11 +489,13 @@ struct rpsf_plan {
   std::vector<int32_t> h_coords;
   // overlap-add strategy: colour planes on regular half-overlap lattices, float atomics otherwise
   int overlap_mode = 0;  // 0 auto, 1 atomics, 2 planes
+  int stagger_us = 0, cu_count = 256;
   bool lattice = false;
   int lat_r0 = 0, lat_c0 = 0, nti = 0, ntj = 0;
   uint8_t* d_plane_of = nullptr;
   uint8_t* d_cover = nullptr;
   int32_t* d_order = nullptr;
+  unsigned long long* d_stamps = nullptr;
   float* d_planes = nullptr;
   size_t planes_floats = 0;  // per plane
 };
@@ -570,9 +635,16 @@ extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     for (auto& e : p->ev) HIP_TRY(hipEventCreate(&e));
+    {
+      hipDeviceProp_t prop;
+      HIP_TRY(hipGetDeviceProperties(&prop, device));
+      p->cu_count = prop.multiProcessorCount;
+    }
     HIP_TRY(hipMalloc(&p->d_coords, sizeof(int32_t) * 2 * n_patches));
     HIP_TRY(hipMemcpy(p->d_coords, coords_rc, sizeof(int32_t) * 2 * n_patches, hipMemcpyHostToDevice));
     p->h_coords.assign(coords_rc, coords_rc + 2 * (size_t)n_patches);
+    HIP_TRY(hipMalloc(&p->d_stamps, sizeof(unsigned long long) * 16 * (size_t)n_patches));
+    HIP_TRY(hipMemset(p->d_stamps, 0, sizeof(unsigned long long) * 16 * (size_t)n_patches));
     int rl = setup_lattice(p);
     if (rl != RPSF_OK) return rl;
     return dispatch_n(N, [&]<class C>() -> int {
@@ -615,6 +687,7 @@ extern "C" void rpsf_plan_destroy(rpsf_plan* p) {
   (void)hipFree(p->d_plane_of);
   (void)hipFree(p->d_cover);
   (void)hipFree(p->d_order);
+  (void)hipFree(p->d_stamps);
   (void)hipFree(p->d_planes);
   for (auto& e : p->ev)
     if (e) (void)hipEventDestroy(e);
@@ -724,6 +797,9 @@ static int launch_apply(rpsf_plan* p, const float* d_img, float* d_out, const rp
     pp.tab = p->d_tab, pp.tw = p->d_tw, pp.win = p->d_win, pp.g = p->d_g, pp.gs = p->d_gs;
     constexpr int TEAMS = Launch<C>::TEAMS;
     pp.order = p->d_order;
+    pp.stamps = p->d_stamps;
+    pp.stagger_ticks = p->stagger_us * 100;
+    pp.stagger_blocks = p->cu_count * std::max(1, 512 / Launch<C>::WG);
     pp.chunk = ((p->n_patches + 7) / 8 + TEAMS - 1) / TEAMS * TEAMS;  // patches per XCD, whole workgroups
     unsigned grid = (unsigned)(8 * (pp.chunk / TEAMS));
     patch_kernel<C><<<dim3(grid), dim3(Launch<C>::WG), Launch<C>::LDS_BYTES, st>>>(pp);
@@ -744,6 +820,22 @@ static int launch_apply(rpsf_plan* p, const float* d_img, float* d_out, const rp
     sum_planes_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(sp);
     HIP_TRY(hipGetLastError());
   }
+  return RPSF_OK;
+}
+
+// Diagnostic builds only (-DRPSF_STAMPS): copy out the 16 per-patch phase timestamps (10 ns ticks).
+extern "C" int rpsf_plan_debug_stamps(rpsf_plan* p, unsigned long long* host, size_t count) {
+  if (!p || !host) return fail(RPSF_E_BADARG, "null argument");
+  HIP_TRY(hipSetDevice(p->device));
+  HIP_TRY(hipDeviceSynchronize());
+  count = std::min(count, (size_t)16 * p->n_patches);
+  HIP_TRY(hipMemcpy(host, p->d_stamps, count * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return RPSF_OK;
+}
+
+extern "C" int rpsf_plan_set_stagger(rpsf_plan* p, int microseconds) {
+  if (!p || microseconds < 0 || microseconds > 1000) return fail(RPSF_E_BADARG, "stagger must be 0..1000 us");
+  p->stagger_us = microseconds;
   return RPSF_OK;
 }
 

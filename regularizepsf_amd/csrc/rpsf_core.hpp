@@ -66,6 +66,28 @@ RPSF_HD cf mul_mi(cf a) { return cf{a.y, -a.x}; }   // a * (-i)
 // push the whole register tile into scratch
 RPSF_HD cf sel(bool c, cf a, cf b) { return cf{c ? a.x : b.x, c ? a.y : b.y}; }
 
+// Streaming (non-temporal) accesses for data that is touched exactly once per apply - the packed K
+// stream and the colour-plane stores - so they do not evict the image tiles that four patches share in L2.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+RPSF_HD void load_stream16(const void* p, cf& a, cf& b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RPSF_NO_NT)
+  f32x4 q = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+#else
+  f32x4 q = *reinterpret_cast<const f32x4*>(p);
+#endif
+  a = cf{q.x, q.y};
+  b = cf{q.z, q.w};
+}
+RPSF_HD void store_stream8(void* p, cf v) {
+  f32x2 q = {v.x, v.y};
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RPSF_NO_NT)
+  __builtin_nontemporal_store(q, reinterpret_cast<f32x2*>(p));
+#else
+  *reinterpret_cast<f32x2*>(p) = q;
+#endif
+}
+
 // cos(2 pi k / 64) for the first quadrant; everything else by symmetry so that 0 and +-1 are exact.
 constexpr float kCosQ[17] = {1.0f,          0.99518472f, 0.98078525f, 0.95694035f, 0.92387950f, 0.88192129f,
                              0.83146960f,   0.77301043f, 0.70710677f, 0.63439327f, 0.55557024f, 0.47139674f,
@@ -449,9 +471,6 @@ RPSF_HD PairOut pair_op(cf za, cf zb, cf ka, cf kb, cf w) {
   return r;
 }
 
-// K layout in device memory, per patch:
-//   g  [i][t][2]            i < 32          -> registers rho = 2i, 2i+1 of thread t      (cf units)
-//   gs [prefix(s)*2E + r*spec_t(s) + t]     r < 2E, slot s, t < spec_t(s)
 // K values of slot S (2E complex values, E 16-byte loads).  Issued one slot ahead of their use so the
 // HBM latency of the next slot hides behind the arithmetic of the current one.
 template <class C, int S>
@@ -462,10 +481,7 @@ RPSF_HD void load_slot_k(int t, cf* k, const cf* __restrict__ g) {
     k[2 * I] = cf{1.0f + (float)I, 0.5f};
     k[2 * I + 1] = cf{0.25f, (float)t};
 #else
-    struct alignas(16) Quad { cf a, b; };  // one 16-byte load per lane
-    Quad q = *reinterpret_cast<const Quad*>(g + ((size_t)(S * E + I) * C::T + t) * 2);
-    k[2 * I] = q.a;
-    k[2 * I + 1] = q.b;
+    load_stream16(g + ((size_t)(S * E + I) * C::T + t) * 2, k[2 * I], k[2 * I + 1]);  // one 16-byte load per lane
 #endif
   });
 }
@@ -497,14 +513,16 @@ RPSF_HD void pointwise_slot(int t, const int* gids, cf* v, const cf* k, const cf
     bool qza = qa == 0, qzb = qb == 0;
     cf wa = tw[ma], wb = tw[mb];
     const cf* gsp = gs + (size_t)C::spec_prefix(S) * 2 * E + t;
+    cf ks[2 * E];  // all Nyquist-side values first: one latency, not 2E of them
+    StaticFor<0, 2 * E>::run([&]<int I>() RPSF_AI { ks[I] = gsp[(size_t)I * ST]; });
     cf na[E], nb[E];
     StaticFor<0, E>::run([&]<int EE>() RPSF_AI {
       constexpr int R = E - 1 - EE, Z = (E - EE) % E;
       cf az = za[Z], ar = za[R], bz = zb[Z], br = zb[R];
       cf pa = sel(self, sel(qza, az, ar), sel(qza, bz, br));
       cf pb = sel(self, sel(qzb, bz, br), sel(qzb, az, ar));
-      na[EE] = pair_op(za[EE], pa, k[EE], gsp[(size_t)EE * ST], wa).a;
-      nb[EE] = pair_op(zb[EE], pb, k[E + EE], gsp[(size_t)(E + EE) * ST], wb).a;
+      na[EE] = pair_op(za[EE], pa, k[EE], ks[EE], wa).a;
+      nb[EE] = pair_op(zb[EE], pb, k[E + EE], ks[E + EE], wb).a;
     });
     StaticFor<0, E>::run([&]<int EE>() RPSF_AI { za[EE] = na[EE]; zb[EE] = nb[EE]; });
   }
@@ -513,17 +531,28 @@ RPSF_HD void pointwise_slot(int t, const int* gids, cf* v, const cf* k, const cf
 // K layout in device memory, per patch:
 //   g  [i][t][2]            i < 32          -> registers rho = 2i, 2i+1 of thread t      (cf units)
 //   gs [prefix(s)*2E + r*spec_t(s) + t]     r < 2E, slot s, t < spec_t(s)
-// k0 = K values of slot 0, already loaded by the caller (before the last-stage DFT).
+// K is streamed through a ring of KDEPTH slot buffers in registers.  The caller fills the ring
+// (slots 0..KDEPTH-1) BEFORE the exchange into the last layout, so those loads are in flight during
+// the exchange's barriers; each slot's buffer is refilled with slot S+KDEPTH as soon as it is consumed.
 template <class C>
-RPSF_HD void pointwise(int t, const int* gids, cf* v, cf* k0, const cf* __restrict__ g, const cf* __restrict__ gs,
-                       const cf* __restrict__ tw) {
-  constexpr int E = C::E;
-  cf k1[2 * E];
+struct KRing {
+  #if !defined(RPSF_KDEPTH)
+#define RPSF_KDEPTH 1  // deeper rings spill: 128 data registers + 32 per slot buffer + butterfly temporaries > 256
+#endif
+  static constexpr int DEPTH = C::NSLOT < RPSF_KDEPTH ? C::NSLOT : RPSF_KDEPTH;
+  cf k[DEPTH][2 * C::E];
+};
+template <class C>
+RPSF_HD void kring_fill(int t, KRing<C>& r, const cf* __restrict__ g) {
+  StaticFor<0, KRing<C>::DEPTH>::run([&]<int S>() RPSF_AI { load_slot_k<C, S>(t, r.k[S], g); });
+}
+template <class C>
+RPSF_HD void pointwise(int t, const int* gids, cf* v, KRing<C>& r, const cf* __restrict__ g,
+                       const cf* __restrict__ gs, const cf* __restrict__ tw) {
+  constexpr int D = KRing<C>::DEPTH;
   StaticFor<0, C::NSLOT>::run([&]<int S>() RPSF_AI {
-    cf* cur = (S & 1) ? k1 : k0;
-    cf* nxt = (S & 1) ? k0 : k1;
-    if constexpr (S + 1 < C::NSLOT) load_slot_k<C, S + 1>(t, nxt, g);
-    pointwise_slot<C, S>(t, gids, v, cur, gs, tw);
+    pointwise_slot<C, S>(t, gids, v, r.k[S % D], gs, tw);
+    if constexpr (S + D < C::NSLOT) load_slot_k<C, S + D>(t, r.k[S % D], g);
   });
 }
 
@@ -655,7 +684,7 @@ RPSF_HD void store_patch(int t, const cf* v, const OutView& ov, int plane, int p
       StaticFor<0, NCOL>::run([&]<int C1>() RPSF_AI {
         int c = (C1 << C::B2) + tp.c_rest;
         cf w2 = *reinterpret_cast<const cf*>(win + 2 * c);
-        *reinterpret_cast<cf*>(row + 2 * c) = v[R1 * NCOL + C1] * (w2 * wr);
+        store_stream8(row + 2 * c, v[R1 * NCOL + C1] * (w2 * wr));
       });
     });
     return;

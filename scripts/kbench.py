@@ -18,6 +18,7 @@ ap.add_argument("--size", type=int, default=4096)
 ap.add_argument("--iters", type=int, default=50)
 ap.add_argument("--tag", default="")
 ap.add_argument("--overlap", default="auto")
+ap.add_argument("--stagger", type=int, default=0)
 a = ap.parse_args()
 rng = np.random.default_rng(0)
 coords = [tuple(int(v) for v in t) for t in calculate_covering((a.size, a.size), a.n)]
@@ -27,6 +28,7 @@ k.real = rng.standard_normal(k.shape, dtype=np.float32)
 k.imag = rng.standard_normal(k.shape, dtype=np.float32)
 plan.set_transfer(k)
 plan.set_overlap_mode(a.overlap)
+plan.set_stagger(a.stagger)
 img = (100 + 5 * rng.standard_normal((a.size, a.size), dtype=np.float32)).astype(np.float32)
 d_img = _native.DeviceBuffer(img.nbytes).upload(img)
 d_out = _native.DeviceBuffer(img.nbytes)
@@ -34,6 +36,6 @@ geom = _native.Geometry.whole(a.size, a.size, 1)
 plan.apply_device_timed(d_img.ptr, d_out.ptr, geom, 5)
 tot, ker = plan.apply_device_timed(d_img.ptr, d_out.ptr, geom, a.iters)
 alg = plan.transfer_bytes + 2 * img.nbytes
-print(json.dumps({"tag": a.tag, "n": a.n, "size": a.size, "patches": len(coords), "kernel_ms_med": round(float(np.median(ker)), 4),
+print(json.dumps({"tag": a.tag, "stagger": a.stagger, "n": a.n, "size": a.size, "patches": len(coords), "kernel_ms_med": round(float(np.median(ker)), 4),
                   "kernel_ms_min": round(float(ker.min()), 4), "total_ms_med": round(float(np.median(tot)), 4),
                   "GBs": round(float(alg / np.median(ker) / 1e6), 1), "frac": round(float(alg / np.median(ker) / 1e6 / 8000), 4)}))

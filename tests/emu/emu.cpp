@@ -67,10 +67,10 @@ static int emu_apply_t(int n_patches, const int32_t* coords, int H, int W, int p
     for (int t = 0; t < T; ++t) x2_last_read<C, 1>(&gids[(size_t)t * C::P], &regs[(size_t)t * 64], lds.data());
     for (int t = 0; t < T; ++t) {
       cf* v = &regs[(size_t)t * 64];
-      cf k0[2 * C::E];
-      load_slot_k<C, 0>(t, k0, g.data());
+      KRing<C> kring;
+      kring_fill<C>(t, kring, g.data());
       stage_last<C, false>(v);
-      pointwise<C>(t, &gids[(size_t)t * C::P], v, k0, g.data(), gs.data(), tw.data());
+      pointwise<C>(t, &gids[(size_t)t * C::P], v, kring, g.data(), gs.data(), tw.data());
       stage_last<C, true>(v);
     }
     for (int t = 0; t < T; ++t) x2_last_write<C, 0>(&gids[(size_t)t * C::P], &regs[(size_t)t * 64], lds.data());
