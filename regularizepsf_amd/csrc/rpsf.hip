@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -45,16 +46,116 @@ static int fail(int code, const std::string& msg) {
 extern "C" const char* rpsf_last_error(void) { return g_err.c_str(); }
 
 // ------------------------------------------------------------------------------------------------
+// K5: out = sum of the colour planes that have a patch over the pixel (fixed order: deterministic)
+// ------------------------------------------------------------------------------------------------
+struct SumParams {
+  const float* planes;
+  size_t plane_stride;
+  float* out;
+  int rows, W, ld_planes, ld_out;
+  int row_begin;       // first window row this launch sums
+  int row0;            // full-image row of window row 0
+  int lat_r0, lat_c0;  // full-image coordinates of lattice tile (0, 0)
+  int half_shift;      // log2(N/2)
+  int nti, ntj;
+  const uint8_t* cover;  // nti x ntj, 4-bit class masks
+};
+
+__device__ __forceinline__ int cover_at(const SumParams& p, int y, int x) {
+  int ty = (y - p.lat_r0) >> p.half_shift, tx = (x - p.lat_c0) >> p.half_shift;
+  if (y < p.lat_r0 || x < p.lat_c0 || ty >= p.nti || tx >= p.ntj) return 0;
+  return p.cover[ty * p.ntj + tx];
+}
+
+// four consecutive pixels (x .. x+3) of window row yl
+__device__ __forceinline__ void sum_planes_group(const SumParams& p, int yl, int x) {
+  int y = yl + p.row0;
+  size_t off = (size_t)yl * p.ld_planes + x;
+  float* o = p.out + (size_t)yl * p.ld_out + x;
+  int c0 = cover_at(p, y, x), c3 = cover_at(p, y, x + 3);
+  const bool vec = x + 3 < p.W && c0 == c3 && ((p.ld_planes | p.ld_out) & 3) == 0 &&
+                   ((reinterpret_cast<uintptr_t>(p.planes) | reinterpret_cast<uintptr_t>(p.out) | (p.plane_stride * 4)) & 15) == 0;
+  if (vec) {  // one tile, aligned: up to four 16-byte loads, one 16-byte store
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (c0 & (1 << k)) {
+        float4 a = *reinterpret_cast<const float4*>(p.planes + k * p.plane_stride + off);
+        acc.x += a.x, acc.y += a.y, acc.z += a.z, acc.w += a.w;
+      }
+    *reinterpret_cast<float4*>(o) = acc;
+  } else {
+    for (int i = 0; i < 4 && x + i < p.W; ++i) o[i] = sum_planes_at(p.planes, p.plane_stride, off + i, cover_at(p, y, x + i));
+  }
+}
+
+__global__ void sum_planes_kernel(SumParams p) {
+  const int groups = (p.W + 3) >> 2;
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)groups * p.rows) return;
+  sum_planes_group(p, (int)(idx / groups) + p.row_begin, (int)(idx % groups) * 4);
+}
+
+// the same work done by `nblocks` co-operating workgroups of a larger launch (grid-stride).  These
+// workgroups are as register-heavy as the patch kernel (one per CU), so each thread keeps eight
+// independent 4-pixel groups in flight to cover the HBM latency.
+__device__ __forceinline__ void sum_planes_worker(const SumParams& p, int block, int nblocks) {
+  const int groups = (p.W + 3) >> 2;
+  const size_t total = (size_t)groups * p.rows;
+  const size_t stride = (size_t)nblocks * blockDim.x;
+  size_t idx = (size_t)block * blockDim.x + threadIdx.x;
+  const bool aligned = ((p.ld_planes | p.ld_out) & 3) == 0 && (p.W & 3) == 0 &&
+                       ((reinterpret_cast<uintptr_t>(p.planes) | reinterpret_cast<uintptr_t>(p.out) | (p.plane_stride * 4)) & 15) == 0;
+  constexpr int SU = 8;
+  if (aligned) {
+    for (; idx + (SU - 1) * stride < total; idx += SU * stride) {
+      float4 v[SU][4];
+      int cov[SU], yl[SU], x[SU];
+      bool uniform = true;
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        size_t i = idx + u * stride;
+        yl[u] = (int)(i / groups) + p.row_begin, x[u] = (int)(i % groups) * 4;
+        cov[u] = cover_at(p, yl[u] + p.row0, x[u]);
+        uniform = uniform && cov[u] == cover_at(p, yl[u] + p.row0, x[u] + 3);
+      }
+      if (!uniform) {  // a group straddles two lattice tiles: generic path
+#pragma unroll
+        for (int u = 0; u < SU; ++u) sum_planes_group(p, yl[u], x[u]);
+        continue;
+      }
+#pragma unroll
+      for (int u = 0; u < SU; ++u)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float4* src = reinterpret_cast<const float4*>(p.planes + k * p.plane_stride + (size_t)yl[u] * p.ld_planes + x[u]);
+          v[u][k] = (cov[u] & (1 << k)) ? *src : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc.x += v[u][k].x, acc.y += v[u][k].y, acc.z += v[u][k].z, acc.w += v[u][k].w;
+        *reinterpret_cast<float4*>(p.out + (size_t)yl[u] * p.ld_out + x[u]) = acc;
+      }
+    }
+  }
+  for (; idx < total; idx += stride) sum_planes_group(p, (int)(idx / groups) + p.row_begin, (int)(idx % groups) * 4);
+}
+
+// ------------------------------------------------------------------------------------------------
 // K1
 // ------------------------------------------------------------------------------------------------
 struct PatchParams {
   ImageView im;
   OutView ov;
   int origin_row, origin_col;
-  const int32_t* coords;
-  const uint8_t* plane_of;  // colour-plane class per patch (plane mode only)
-  const int32_t* order;     // processing order (Z-order of the lattice), see patch_kernel
+  const int4* desc;         // per processing-order slot: {corner row, corner col, patch index, colour plane}
+                            // (one 16-byte load instead of the order -> coords -> plane pointer chase)
   int chunk;                // patches per XCD chunk
+  int seq_base;             // first processing-order slot of this launch (the apply may be split in two launches)
+  int patch_blocks;         // blocks [0, patch_blocks) process patches; blocks beyond it sum colour planes
+  SumParams sum;            // (tail launch: the rows the tail patches do not touch are summed by the idle CUs)
   unsigned long long* stamps;  // diagnostic builds (RPSF_STAMPS): 16 phase timestamps per patch
   int stagger_ticks;        // start-up stagger of the first resident workgroups, in 10 ns ticks (0 = off)
   int stagger_blocks;       // how many leading blocks are staggered (= resident workgroup capacity)
@@ -88,6 +189,35 @@ __device__ __forceinline__ void x2_nop(A, B, D) {}
 __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// K staging through LDS (N = 256 plan).  The X2 exchange buffer is idle from the end of X2 to the start
+// of X2'; K slots 1 and 2 (2 x 64 KiB) are copied into it by LDS-DMA (no data registers), slot 0 and slot 3
+// travel through registers.  That puts ~190 KiB of K in flight per CU instead of 64 KiB; the register
+// file (128 data + 2 x 32 K registers) has no room for more.  Each lane reads back exactly the bytes it
+// asked for, so no cross-wave synchronisation is needed for the staged K itself.
+template <class C>
+struct KStage {
+  static constexpr bool enabled = C::NSLOT == 4 && C::S3 && (2 * C::E * C::T * 8 * 2 <= C::LDS_FLOATS * 4);
+  static constexpr int SLOT_FLOATS = 2 * C::E * C::T * 2;  // floats per staged slot
+};
+template <class C, int S>
+__device__ __forceinline__ void dma_slot_k(int t, float* lds_slot, const cf* __restrict__ g) {
+  StaticFor<0, C::E>::run([&]<int I>() RPSF_AI {
+    const cf* src = g + ((size_t)(S * C::E + I) * C::T + t) * 2;                 // per-lane source
+    float* dst = lds_slot + ((size_t)I * C::T + (t & ~63)) * 4;                   // wave-uniform base; lane*16 B is implied
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    __builtin_amdgcn_global_load_lds((gptr_t)(const void*)src, (lptr_t)(void*)dst, 16, 0, 0);
+  });
+}
+template <class C>
+__device__ __forceinline__ void read_slot_k(int t, cf* k, const float* lds_slot) {
+  StaticFor<0, C::E>::run([&]<int I>() RPSF_AI {
+    const f32x4 q = *reinterpret_cast<const f32x4*>(lds_slot + ((size_t)I * C::T + t) * 4);
+    k[2 * I] = cf{q.x, q.y};
+    k[2 * I + 1] = cf{q.z, q.w};
+  });
+}
+
 #if defined(RPSF_STAMPS)
 #define STAMP(i)                                                                                         \
   do {                                                                                                   \
@@ -101,6 +231,10 @@ template <class C>
 __global__ __launch_bounds__(Launch<C>::WG) void patch_kernel(PatchParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int T = C::T;
+  if ((int)blockIdx.x >= p.patch_blocks) {  // workgroup-uniform
+    sum_planes_worker(p.sum, blockIdx.x - p.patch_blocks, gridDim.x - p.patch_blocks);
+    return;
+  }
   const int team = threadIdx.x / T, t = threadIdx.x % T;
   // Blocks are dealt round-robin over the 8 XCDs (b and b+8 share one).  `order` lists the patches
   // along a Z-order curve of the lattice, cut into 8 contiguous chunks: XCD x works through chunk x,
@@ -108,7 +242,8 @@ __global__ __launch_bounds__(Launch<C>::WG) void patch_kernel(PatchParams p) {
   const int slot = (blockIdx.x >> 3) * Launch<C>::TEAMS + team;
   const int seq = (blockIdx.x & 7) * p.chunk + slot;
   const bool active = slot < p.chunk && seq < p.n_patches;
-  const int patch = p.order[active ? seq : p.n_patches - 1];  // inactive teams stay in step with the barriers
+  const int4 dsc = p.desc[p.seq_base + (active ? seq : p.n_patches - 1)];  // inactive teams stay in step with the barriers
+  const int patch = dsc.z;
   // De-phase the chip: without this every CU gathers, streams K and stores at the same instants, HBM
   // alternates between saturated and idle, and no memory phase overlaps any compute phase.  Delaying
   // the first resident workgroup of each CU by a different amount spreads the phases for the whole
@@ -118,6 +253,16 @@ __global__ __launch_bounds__(Launch<C>::WG) void patch_kernel(PatchParams p) {
     const unsigned long long wait = (unsigned long long)(((blockIdx.x >> 3) * 0x9E3779B1u >> 22) & 1023) * p.stagger_ticks >> 10;
     while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
   }
+  float* lds = smem + Launch<C>::TABLE_FLOATS + team * C::LDS_FLOATS;
+  STAMP(0);
+  const int pr = dsc.x + p.origin_row, pc = dsc.y + p.origin_col;
+  const cf* g = p.g + (size_t)patch * C::G_PER_PATCH;
+  cf v[64];
+#if defined(RPSF_ABL_NOLOAD)
+#pragma unroll
+  for (int j = 0; j < 64; ++j) v[j] = cf{(float)(t + j), (float)(t - j)};
+#endif
+  const bool fast = patch_inside<C>(pr, pc, p.im.H, p.im.W, p.im.row0, p.im.rows) && pairs_aligned(p.im.img, p.im.ld, pc);
   // twiddle and window tables live in LDS: their reads must not queue behind the patch's global loads
   cf* tw = reinterpret_cast<cf*>(smem);
   float* win = smem + 2 * C::N;
@@ -125,25 +270,26 @@ __global__ __launch_bounds__(Launch<C>::WG) void patch_kernel(PatchParams p) {
     tw[i] = p.tw[i];
     win[i] = p.win[i];
   }
-  float* lds = smem + Launch<C>::TABLE_FLOATS + team * C::LDS_FLOATS;
-  STAMP(0);
-
   int gids[C::P];
 #pragma unroll
   for (int i = 0; i < C::P; ++i) gids[i] = p.tab[t * C::P + i];
-
-  const int pr = p.coords[2 * patch] + p.origin_row, pc = p.coords[2 * patch + 1] + p.origin_col;
-  const cf* g = p.g + (size_t)patch * C::G_PER_PATCH;
-  cf v[64];
-#if defined(RPSF_ABL_NOLOAD)
-#pragma unroll
-  for (int j = 0; j < 64; ++j) v[j] = cf{(float)(t + j), (float)(t - j)};
-#else
+#if defined(RPSF_ABL_NOXCHG)
+#define x1_write x1_nop
+#define x1_read x1_nop
+#define x2_mid_write x2_nop
+#define x2_mid_read x2_nop
+#define x2_last_write x2_nop
+#define x2_last_read x2_nop
+#define lds_barrier() ((void)0)
+#define wave_lds_sync() ((void)0)
+#endif
+#if !defined(RPSF_ABL_NOLOAD)
   {
-    const bool fast = patch_inside<C>(pr, pc, p.im.H, p.im.W, p.im.row0, p.im.rows) && pairs_aligned(p.im.img, p.im.ld, pc);
     int* maps = reinterpret_cast<int*>(lds);
     if (!fast) build_pad_maps<C>(t, maps, p.im, pr, pc);
     lds_barrier();
+    // (VMEM returns in order: issuing these loads before the table staging above would make the tables
+    //  wait for all 64 of them and lose the load -> stage-1 overlap; measured 9.0 -> 12.8 us)
     load_patch<C>(t, v, p.im, pr, pc, win, fast, maps);
     lds_barrier();  // the maps share LDS with the exchange buffer
   }
@@ -194,17 +340,40 @@ __global__ __launch_bounds__(Launch<C>::WG) void patch_kernel(PatchParams p) {
   // no barrier: every X2 word is read by exactly one thread, the same one that rewrites it below
 
   STAMP(5);
-  stage_last<C, false>(v);
-  STAMP(6);
-  pointwise<C>(t, gids, v, kring, g, p.gs + (size_t)patch * C::GS_PER_PATCH, tw);
-  STAMP(7);
-  stage_last<C, true>(v);
-  STAMP(8);
-
-#if defined(RPSF_KPREFETCH) && !defined(RPSF_ABL_NOK)
-#pragma unroll
-  for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(kpf[i]));  // keep the prefetch loads alive
+#if defined(RPSF_KSTAGE) && !defined(RPSF_ABL_NOK) && !defined(RPSF_ABL_NOXCHG)  // measured: no gain (extra barriers), kept for reference
+  if constexpr (KStage<C>::enabled) {
+    const cf* gs = p.gs + (size_t)patch * C::GS_PER_PATCH;
+    lds_barrier();  // every wave has read its X2 data: the buffer may be overwritten
+    dma_slot_k<C, 1>(t, lds, g);
+    dma_slot_k<C, 2>(t, lds + KStage<C>::SLOT_FLOATS, g);
+    stage_last<C, false>(v);
+    STAMP(6);
+    pointwise_slot<C, 0>(t, gids, v, kring.k[0], gs, tw);
+    load_slot_k<C, 3>(t, kring.k[0], g);  // slot 3 reuses slot 0's registers
+    // 2E DMA pieces (older) must have landed; the E loads of slot 3 (younger) may still be in flight
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::E) : "memory");
+    {
+      cf k1[2 * C::E];
+      read_slot_k<C>(t, k1, lds);
+      pointwise_slot<C, 1>(t, gids, v, k1, gs, tw);
+      read_slot_k<C>(t, k1, lds + KStage<C>::SLOT_FLOATS);
+      pointwise_slot<C, 2>(t, gids, v, k1, gs, tw);
+    }
+    pointwise_slot<C, 3>(t, gids, v, kring.k[0], gs, tw);
+    STAMP(7);
+    stage_last<C, true>(v);
+    STAMP(8);
+    lds_barrier();  // staged K fully consumed before X2' reuses the buffer
+  } else
 #endif
+  {
+    stage_last<C, false>(v);
+    STAMP(6);
+    pointwise<C>(t, gids, v, kring, g, p.gs + (size_t)patch * C::GS_PER_PATCH, tw);
+    STAMP(7);
+    stage_last<C, true>(v);
+    STAMP(8);
+  }
 
   x2_last_write<C, 0>(gids, v, lds);
   lds_barrier();
@@ -230,7 +399,7 @@ __global__ __launch_bounds__(Launch<C>::WG) void patch_kernel(PatchParams p) {
   stage1<C, true>(t, v, tw);
   STAMP(12);
   if (active) {
-    const int plane = p.ov.plane_stride ? p.plane_of[patch] : 0;
+    const int plane = p.ov.plane_stride ? dsc.w : 0;
 #if defined(RPSF_ABL_NOSTORE)
     {  // keep every value live but store (almost) nothing
       float acc = 0.f;
@@ -423,52 +592,6 @@ __global__ void add_rows_kernel(float* __restrict__ accum, const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// K5: out = sum of the colour planes that have a patch over the pixel (fixed order: deterministic)
-// ------------------------------------------------------------------------------------------------
-struct SumParams {
-  const float* planes;
-  size_t plane_stride;
-  float* out;
-  int rows, W, ld_planes, ld_out;
-  int row0;            // full-image row of window row 0
-  int lat_r0, lat_c0;  // full-image coordinates of lattice tile (0, 0)
-  int half_shift;      // log2(N/2)
-  int nti, ntj;
-  const uint8_t* cover;  // nti x ntj, 4-bit class masks
-};
-
-__device__ __forceinline__ int cover_at(const SumParams& p, int y, int x) {
-  int ty = (y - p.lat_r0) >> p.half_shift, tx = (x - p.lat_c0) >> p.half_shift;
-  if (y < p.lat_r0 || x < p.lat_c0 || ty >= p.nti || tx >= p.ntj) return 0;
-  return p.cover[ty * p.ntj + tx];
-}
-
-__global__ void sum_planes_kernel(SumParams p) {
-  const int groups = (p.W + 3) >> 2;
-  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (size_t)groups * p.rows) return;
-  int yl = (int)(idx / groups), x = (int)(idx % groups) * 4;
-  int y = yl + p.row0;
-  size_t off = (size_t)yl * p.ld_planes + x;
-  float* o = p.out + (size_t)yl * p.ld_out + x;
-  int c0 = cover_at(p, y, x), c3 = cover_at(p, y, x + 3);
-  const bool vec = x + 3 < p.W && c0 == c3 && ((p.ld_planes | p.ld_out) & 3) == 0 &&
-                   ((reinterpret_cast<uintptr_t>(p.planes) | reinterpret_cast<uintptr_t>(p.out) | (p.plane_stride * 4)) & 15) == 0;
-  if (vec) {  // one tile, aligned: four 16-byte loads, one 16-byte store
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (c0 & (1 << k)) {
-        float4 a = *reinterpret_cast<const float4*>(p.planes + k * p.plane_stride + off);
-        acc.x += a.x, acc.y += a.y, acc.z += a.z, acc.w += a.w;
-      }
-    *reinterpret_cast<float4*>(o) = acc;
-  } else {
-    for (int i = 0; i < 4 && x + i < p.W; ++i) o[i] = sum_planes_at(p.planes, p.plane_stride, off + i, cover_at(p, y, x + i));
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // plan
 // ------------------------------------------------------------------------------------------------
 struct rpsf_plan {
@@ -490,11 +613,19 @@ struct rpsf_plan {
   // overlap-add strategy: colour planes on regular half-overlap lattices, float atomics otherwise
   int overlap_mode = 0;  // 0 auto, 1 atomics, 2 planes
   int stagger_us = 0, cu_count = 256;
+  // Tail overlap: the last, partial round of patches (ordered last: the bottom lattice rows) is a second
+  // launch; the plane sum of the rows it does not touch runs meanwhile on a low-priority stream.
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_main = nullptr, ev_sum = nullptr;
+  int n_tail = 0;        // patches in the tail launch (0 = no split)
+  int tail_row = 0;      // smallest corner row among the tail patches
+  int split_mode = 0;    // 0 auto, 1 never
+  int round_capacity = 0;  // patches the chip holds at once (CUs x resident workgroups x patches per workgroup)
   bool lattice = false;
   int lat_r0 = 0, lat_c0 = 0, nti = 0, ntj = 0;
-  uint8_t* d_plane_of = nullptr;
   uint8_t* d_cover = nullptr;
-  int32_t* d_order = nullptr;
+  int4* d_desc = nullptr;
+  std::vector<int32_t> h_order;
   unsigned long long* d_stamps = nullptr;
   float* d_planes = nullptr;
   size_t planes_floats = 0;  // per plane
@@ -522,14 +653,34 @@ static int setup_lattice(rpsf_plan* p) {
     c0 = std::min(c0, p->h_coords[2 * i + 1]), c1 = std::max(c1, p->h_coords[2 * i + 1]);
   }
   {
+    // tail = the last, partial round of patches: the bottom-most lattice rows, so that the rows above
+    // them are final as soon as the main launch is done
+    std::vector<char> in_tail(n, 0);
+    p->n_tail = 0;
+    const int cap = p->round_capacity;
+    const int n_full = cap > 0 ? (n / cap) * cap : 0, tail = n - n_full;
+    if (p->split_mode == 0 && n_full > 0 && tail > 0 && tail * 10 <= cap * 6) {
+      std::vector<int32_t> by_row(n);
+      for (int i = 0; i < n; ++i) by_row[i] = i;
+      std::sort(by_row.begin(), by_row.end(), [&](int a, int b) {
+        if (p->h_coords[2 * a] != p->h_coords[2 * b]) return p->h_coords[2 * a] > p->h_coords[2 * b];
+        return p->h_coords[2 * a + 1] > p->h_coords[2 * b + 1];
+      });
+      p->tail_row = p->h_coords[2 * by_row[0]];
+      for (int k = 0; k < tail; ++k) {
+        in_tail[by_row[k]] = 1;
+        p->tail_row = std::min(p->tail_row, p->h_coords[2 * by_row[k]]);
+      }
+      p->n_tail = tail;
+    }
     std::vector<std::pair<uint64_t, int32_t>> keyed(n);
     for (int i = 0; i < n; ++i)
-      keyed[i] = {morton2((uint32_t)((p->h_coords[2 * i] - r0) / half), (uint32_t)((p->h_coords[2 * i + 1] - c0) / half)), i};
+      keyed[i] = {((uint64_t)in_tail[i] << 62) |
+                      morton2((uint32_t)((p->h_coords[2 * i] - r0) / half), (uint32_t)((p->h_coords[2 * i + 1] - c0) / half)),
+                  i};
     std::sort(keyed.begin(), keyed.end());
-    std::vector<int32_t> order(n);
-    for (int i = 0; i < n; ++i) order[i] = keyed[i].second;
-    HIP_TRY(hipMalloc(&p->d_order, sizeof(int32_t) * n));
-    HIP_TRY(hipMemcpy(p->d_order, order.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    p->h_order.resize(n);
+    for (int i = 0; i < n; ++i) p->h_order[i] = keyed[i].second;
   }
   bool ok = true;
   for (int i = 0; i < n && ok; ++i)
@@ -553,10 +704,17 @@ static int setup_lattice(rpsf_plan* p) {
     }
   }
   p->lattice = ok;
+  {
+    std::vector<int4> desc(n);
+    for (int s2 = 0; s2 < n; ++s2) {
+      int i = p->h_order[s2];
+      desc[s2] = make_int4(p->h_coords[2 * i], p->h_coords[2 * i + 1], i, ok ? cls[i] : 0);
+    }
+    HIP_TRY(hipMalloc(&p->d_desc, sizeof(int4) * n));
+    HIP_TRY(hipMemcpy(p->d_desc, desc.data(), sizeof(int4) * n, hipMemcpyHostToDevice));
+  }
   if (!ok) return RPSF_OK;
   p->lat_r0 = r0, p->lat_c0 = c0, p->nti = nti, p->ntj = ntj;
-  HIP_TRY(hipMalloc(&p->d_plane_of, n));
-  HIP_TRY(hipMemcpy(p->d_plane_of, cls.data(), n, hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc(&p->d_cover, cover.size()));
   HIP_TRY(hipMemcpy(p->d_cover, cover.data(), cover.size(), hipMemcpyHostToDevice));
   return RPSF_OK;
@@ -633,7 +791,14 @@ extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int
   p->device = device, p->N = N, p->n_patches = n_patches;
   auto body = [&]() -> int {
     HIP_TRY(hipSetDevice(device));
-    HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    {
+      int lo = 0, hi = 0;
+      HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));  // lo = least, hi = greatest priority
+      HIP_TRY(hipStreamCreateWithPriority(&p->stream, hipStreamNonBlocking, hi));
+      HIP_TRY(hipStreamCreateWithPriority(&p->stream2, hipStreamNonBlocking, lo));
+      HIP_TRY(hipEventCreateWithFlags(&p->ev_main, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&p->ev_sum, hipEventDisableTiming));
+    }
     for (auto& e : p->ev) HIP_TRY(hipEventCreate(&e));
     {
       hipDeviceProp_t prop;
@@ -645,7 +810,19 @@ extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int
     p->h_coords.assign(coords_rc, coords_rc + 2 * (size_t)n_patches);
     HIP_TRY(hipMalloc(&p->d_stamps, sizeof(unsigned long long) * 16 * (size_t)n_patches));
     HIP_TRY(hipMemset(p->d_stamps, 0, sizeof(unsigned long long) * 16 * (size_t)n_patches));
-    int rl = setup_lattice(p);
+    int rl = dispatch_n(N, [&]<class C>() -> int {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_kernel<C>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)Launch<C>::LDS_BYTES));
+      int per_cu = 0;
+      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, patch_kernel<C>, Launch<C>::WG, Launch<C>::LDS_BYTES));
+      p->round_capacity = p->cu_count * std::max(1, per_cu) * Launch<C>::TEAMS;
+      return RPSF_OK;
+    });
+    if (rl != RPSF_OK) return rl;
+    // Tail/sum fusion is opt-in: measured neutral on MI355X (the plane sum is HBM-bound by itself), see DESIGN.md
+    p->split_mode = 1;
+    if (const char* e = std::getenv("RPSF_SPLIT")) p->split_mode = (e[0] && e[0] != '0') ? 0 : 1;
+    rl = setup_lattice(p);
     if (rl != RPSF_OK) return rl;
     return dispatch_n(N, [&]<class C>() -> int {
       int r2 = upload_tables<C>(device, &p->d_tab, &p->d_tw, &p->d_win);
@@ -684,14 +861,16 @@ extern "C" void rpsf_plan_destroy(rpsf_plan* p) {
   (void)hipFree(p->d_gs);
   (void)hipFree(p->d_img);
   (void)hipFree(p->d_out);
-  (void)hipFree(p->d_plane_of);
   (void)hipFree(p->d_cover);
-  (void)hipFree(p->d_order);
+  (void)hipFree(p->d_desc);
   (void)hipFree(p->d_stamps);
   (void)hipFree(p->d_planes);
   for (auto& e : p->ev)
     if (e) (void)hipEventDestroy(e);
   if (p->stream) (void)hipStreamDestroy(p->stream);
+  if (p->stream2) (void)hipStreamDestroy(p->stream2);
+  if (p->ev_main) (void)hipEventDestroy(p->ev_main);
+  if (p->ev_sum) (void)hipEventDestroy(p->ev_sum);
   delete p;
 }
 
@@ -767,8 +946,58 @@ static int check_geometry(const rpsf_plan* p, const rpsf_geometry* g) {
   return RPSF_OK;
 }
 
+static SumParams make_sum_params(const rpsf_plan* p, float* d_out, const rpsf_geometry& g, int row_begin, int row_end) {
+  SumParams sp;
+  sp.planes = p->d_planes, sp.plane_stride = p->planes_floats, sp.out = d_out;
+  sp.rows = row_end - row_begin, sp.row_begin = row_begin;
+  sp.W = g.width, sp.ld_planes = g.width, sp.ld_out = g.ld_out, sp.row0 = g.out_row0;
+  sp.lat_r0 = p->lat_r0 + g.origin_row, sp.lat_c0 = p->lat_c0 + g.origin_col;
+  sp.half_shift = 0;
+  while ((1 << (sp.half_shift + 1)) < p->N) ++sp.half_shift;
+  sp.nti = p->nti, sp.ntj = p->ntj, sp.cover = p->d_cover;
+  return sp;
+}
+
+// sum_rows > 0: append workgroups that sum colour-plane rows [0, sum_rows) (tail launch only)
+static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const rpsf_geometry& g, bool planes,
+                          int seq_base, int count, hipStream_t st, int sum_rows = 0) {
+  return dispatch_n(p->N, [&]<class C>() -> int {
+    PatchParams pp;
+    pp.im = ImageView{d_img, g.height, g.width, g.ld_image, g.pad_mode, g.pad_value, g.image_row0, g.image_rows};
+    if (planes)
+      pp.ov = OutView{p->d_planes, g.height, g.width, g.width, g.out_row0, g.out_rows, p->planes_floats};
+    else
+      pp.ov = OutView{d_out, g.height, g.width, g.ld_out, g.out_row0, g.out_rows, 0};
+    pp.origin_row = g.origin_row, pp.origin_col = g.origin_col;
+    pp.desc = p->d_desc, pp.n_patches = count, pp.seq_base = seq_base;
+    pp.tab = p->d_tab, pp.tw = p->d_tw, pp.win = p->d_win, pp.g = p->d_g, pp.gs = p->d_gs;
+    pp.stamps = p->d_stamps;
+    constexpr int TEAMS = Launch<C>::TEAMS;
+    pp.chunk = ((count + 7) / 8 + TEAMS - 1) / TEAMS * TEAMS;  // patches per XCD, whole workgroups
+    pp.stagger_ticks = p->stagger_us * 100;
+    pp.stagger_blocks = p->cu_count * std::max(1, 512 / Launch<C>::WG);
+    unsigned grid = (unsigned)(8 * (pp.chunk / TEAMS));
+    pp.patch_blocks = (int)grid;
+    pp.sum = make_sum_params(p, d_out, g, 0, sum_rows);
+    if (sum_rows > 0) grid += (unsigned)std::max(8, p->round_capacity / TEAMS - (int)grid);  // one per CU left idle by the tail
+    patch_kernel<C><<<dim3(grid), dim3(Launch<C>::WG), Launch<C>::LDS_BYTES, st>>>(pp);
+    HIP_TRY(hipGetLastError());
+    return RPSF_OK;
+  });
+}
+
+static int launch_sum(rpsf_plan* p, float* d_out, const rpsf_geometry& g, int row_begin, int row_end, hipStream_t st) {
+  if (row_end <= row_begin) return RPSF_OK;
+  SumParams sp = make_sum_params(p, d_out, g, row_begin, row_end);
+  size_t total = (size_t)((g.width + 3) / 4) * sp.rows;
+  sum_planes_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(sp);
+  HIP_TRY(hipGetLastError());
+  return RPSF_OK;
+}
+
+// One apply.  ev_k0 / ev_k1 (optional) bracket the patch-kernel launches for timing.
 static int launch_apply(rpsf_plan* p, const float* d_img, float* d_out, const rpsf_geometry& g, hipStream_t st,
-                        hipEvent_t mid, hipEvent_t mid2 = nullptr) {
+                        hipEvent_t ev_k0, hipEvent_t ev_k1 = nullptr) {
   const bool planes = p->overlap_mode == 2 || (p->overlap_mode == 0 && p->lattice);
   if (planes && !p->lattice) return fail(RPSF_E_STATE, "colour planes need a regular half-overlap lattice of patch corners");
   if (planes) {
@@ -784,42 +1013,35 @@ static int launch_apply(rpsf_plan* p, const float* d_img, float* d_out, const rp
   } else {
     HIP_TRY(hipMemset2DAsync(d_out, (size_t)g.ld_out * sizeof(float), 0, (size_t)g.width * sizeof(float), g.out_rows, st));
   }
-  if (mid) HIP_TRY(hipEventRecord(mid, st));
-  int rc = dispatch_n(p->N, [&]<class C>() -> int {
-    PatchParams pp;
-    pp.im = ImageView{d_img, g.height, g.width, g.ld_image, g.pad_mode, g.pad_value, g.image_row0, g.image_rows};
-    if (planes)
-      pp.ov = OutView{p->d_planes, g.height, g.width, g.width, g.out_row0, g.out_rows, p->planes_floats};
-    else
-      pp.ov = OutView{d_out, g.height, g.width, g.ld_out, g.out_row0, g.out_rows, 0};
-    pp.origin_row = g.origin_row, pp.origin_col = g.origin_col;
-    pp.coords = p->d_coords, pp.plane_of = p->d_plane_of, pp.n_patches = p->n_patches;
-    pp.tab = p->d_tab, pp.tw = p->d_tw, pp.win = p->d_win, pp.g = p->d_g, pp.gs = p->d_gs;
-    constexpr int TEAMS = Launch<C>::TEAMS;
-    pp.order = p->d_order;
-    pp.stamps = p->d_stamps;
-    pp.stagger_ticks = p->stagger_us * 100;
-    pp.stagger_blocks = p->cu_count * std::max(1, 512 / Launch<C>::WG);
-    pp.chunk = ((p->n_patches + 7) / 8 + TEAMS - 1) / TEAMS * TEAMS;  // patches per XCD, whole workgroups
-    unsigned grid = (unsigned)(8 * (pp.chunk / TEAMS));
-    patch_kernel<C><<<dim3(grid), dim3(Launch<C>::WG), Launch<C>::LDS_BYTES, st>>>(pp);
-    HIP_TRY(hipGetLastError());
-    return RPSF_OK;
-  });
-  if (rc != RPSF_OK) return rc;
-  if (mid2) HIP_TRY(hipEventRecord(mid2, st));
-  if (planes) {
-    SumParams sp;
-    sp.planes = p->d_planes, sp.plane_stride = p->planes_floats, sp.out = d_out;
-    sp.rows = g.out_rows, sp.W = g.width, sp.ld_planes = g.width, sp.ld_out = g.ld_out, sp.row0 = g.out_row0;
-    sp.lat_r0 = p->lat_r0 + g.origin_row, sp.lat_c0 = p->lat_c0 + g.origin_col;
-    sp.half_shift = 0;
-    while ((1 << (sp.half_shift + 1)) < p->N) ++sp.half_shift;
-    sp.nti = p->nti, sp.ntj = p->ntj, sp.cover = p->d_cover;
-    size_t total = (size_t)((g.width + 3) / 4) * g.out_rows;
-    sum_planes_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(sp);
-    HIP_TRY(hipGetLastError());
+  if (ev_k0) HIP_TRY(hipEventRecord(ev_k0, st));
+  const int n = p->n_patches;
+  // window row (relative to out_row0) from which the tail patches contribute
+  int split_row = p->n_tail > 0 ? std::min(std::max(p->tail_row + g.origin_row - g.out_row0, 0), g.out_rows) : g.out_rows;
+  const bool split = planes && p->n_tail > 0 && split_row > 0 && split_row < g.out_rows;
+  int rc;
+  if (!split) {
+    rc = launch_patches(p, d_img, d_out, g, planes, 0, n, st);
+    if (rc != RPSF_OK) return rc;
+    if (ev_k1) HIP_TRY(hipEventRecord(ev_k1, st));
+    if (planes) rc = launch_sum(p, d_out, g, 0, g.out_rows, st);
+    return rc;
   }
+  // main rounds; then ONE launch whose first workgroups are the tail patches (dispatched first, onto empty
+  // CUs) and whose other workgroups sum the colour planes of the rows the tail does not touch; then the
+  // remaining rows.  (Two streams do not work: the sum's small blocks occupy every CU first and the tail
+  // patches, which need a whole CU each, wait for them - measured.)
+  rc = launch_patches(p, d_img, d_out, g, true, 0, n - p->n_tail, st);
+  if (rc != RPSF_OK) return rc;
+  rc = launch_patches(p, d_img, d_out, g, true, n - p->n_tail, p->n_tail, st, split_row);
+  if (rc != RPSF_OK) return rc;
+  if (ev_k1) HIP_TRY(hipEventRecord(ev_k1, st));
+  return launch_sum(p, d_out, g, split_row, g.out_rows, st);
+}
+
+extern "C" int rpsf_plan_set_overlap_mode(rpsf_plan* p, int mode) {
+  if (!p || mode < 0 || mode > 2) return fail(RPSF_E_BADARG, "mode must be 0 (auto), 1 (atomics) or 2 (colour planes)");
+  if (mode == 2 && !p->lattice) return fail(RPSF_E_STATE, "colour planes need a regular half-overlap lattice of patch corners");
+  p->overlap_mode = mode;
   return RPSF_OK;
 }
 
@@ -839,12 +1061,6 @@ extern "C" int rpsf_plan_set_stagger(rpsf_plan* p, int microseconds) {
   return RPSF_OK;
 }
 
-extern "C" int rpsf_plan_set_overlap_mode(rpsf_plan* p, int mode) {
-  if (!p || mode < 0 || mode > 2) return fail(RPSF_E_BADARG, "mode must be 0 (auto), 1 (atomics) or 2 (colour planes)");
-  if (mode == 2 && !p->lattice) return fail(RPSF_E_STATE, "colour planes need a regular half-overlap lattice of patch corners");
-  p->overlap_mode = mode;
-  return RPSF_OK;
-}
 
 extern "C" int rpsf_apply_device(rpsf_plan* p, const void* image_dev, void* out_dev, const rpsf_geometry* geom,
                                  void* stream) {

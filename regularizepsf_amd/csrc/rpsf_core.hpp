@@ -536,10 +536,10 @@ RPSF_HD void pointwise_slot(int t, const int* gids, cf* v, const cf* k, const cf
 // the exchange's barriers; each slot's buffer is refilled with slot S+KDEPTH as soon as it is consumed.
 template <class C>
 struct KRing {
-  #if !defined(RPSF_KDEPTH)
-#define RPSF_KDEPTH 1  // deeper rings spill: 128 data registers + 32 per slot buffer + butterfly temporaries > 256
-#endif
-  static constexpr int DEPTH = C::NSLOT < RPSF_KDEPTH ? C::NSLOT : RPSF_KDEPTH;
+    // ring registers are capped at 32 per thread: 128 data registers + butterfly temporaries leave no more
+  // (a second 32-register slot buffer at N = 256 spilled 216 B per lane)
+  static constexpr int WANT = 8 / C::E < 1 ? 1 : 8 / C::E;
+  static constexpr int DEPTH = C::NSLOT < WANT ? C::NSLOT : WANT;
   cf k[DEPTH][2 * C::E];
 };
 template <class C>
@@ -631,24 +631,45 @@ RPSF_HD void build_pad_maps(int t, int* maps, const ImageView& im, int pr, int p
   }
 }
 
+// Interior patch, step 1: issue the 64 eight-byte loads (no table needed yet, so this can start before
+// the twiddle/window tables have been staged in LDS).
+template <class C>
+RPSF_HD void load_patch_raw(int t, cf* v, const ImageView& im, int pr, int pc) {
+  ThreadPos<C> tp(t);
+  constexpr int NR = 1 << C::A1, NCOL = 1 << C::B1;
+  const float* base = im.img + (size_t)(pr - im.row0) * im.ld + pc;
+  StaticFor<0, NR>::run([&]<int R1>() RPSF_AI {
+    int r = (R1 << (C::A2 + C::AL)) + tp.r_rest;
+    const float* row = base + (size_t)r * im.ld;
+    StaticFor<0, NCOL>::run([&]<int C1>() RPSF_AI {
+      int c = (C1 << C::B2) + tp.c_rest;
+      v[R1 * NCOL + C1] = *reinterpret_cast<const cf*>(row + 2 * c);
+    });
+  });
+}
+// Interior patch, step 2: sine window (transform.py:151-155,163).
+template <class C>
+RPSF_HD void window_patch(int t, cf* v, const float* __restrict__ win) {
+  ThreadPos<C> tp(t);
+  constexpr int NR = 1 << C::A1, NCOL = 1 << C::B1;
+  StaticFor<0, NR>::run([&]<int R1>() RPSF_AI {
+    float wr = win[(R1 << (C::A2 + C::AL)) + tp.r_rest];
+    StaticFor<0, NCOL>::run([&]<int C1>() RPSF_AI {
+      int c = (C1 << C::B2) + tp.c_rest;
+      cf w2 = *reinterpret_cast<const cf*>(win + 2 * c);
+      v[R1 * NCOL + C1] = v[R1 * NCOL + C1] * (w2 * wr);
+    });
+  });
+}
+
 template <class C>
 RPSF_HD void load_patch(int t, cf* v, const ImageView& im, int pr, int pc, const float* __restrict__ win,
                         bool fast, const int* maps) {
   ThreadPos<C> tp(t);
   constexpr int NR = 1 << C::A1, NCOL = 1 << C::B1;
   if (fast) {
-    const float* base = im.img + (size_t)(pr - im.row0) * im.ld + pc;
-    StaticFor<0, NR>::run([&]<int R1>() RPSF_AI {
-      int r = (R1 << (C::A2 + C::AL)) + tp.r_rest;
-      float wr = win[r];
-      const float* row = base + (size_t)r * im.ld;
-      StaticFor<0, NCOL>::run([&]<int C1>() RPSF_AI {
-        int c = (C1 << C::B2) + tp.c_rest;
-        cf px = *reinterpret_cast<const cf*>(row + 2 * c);
-        cf w2 = *reinterpret_cast<const cf*>(win + 2 * c);
-        v[R1 * NCOL + C1] = px * (w2 * wr);
-      });
-    });
+    load_patch_raw<C>(t, v, im, pr, pc);
+    window_patch<C>(t, v, win);
   } else {
     StaticFor<0, NR>::run([&]<int R1>() RPSF_AI {
       int r = (R1 << (C::A2 + C::AL)) + tp.r_rest;

@@ -10,6 +10,7 @@ coords = [tuple(int(v) for v in t) for t in calculate_covering((size, size), n)]
 plan = _native.Plan(n, coords)
 k = np.empty((len(coords), n, n), np.complex64); k.real = rng.standard_normal(k.shape, dtype=np.float32); k.imag = rng.standard_normal(k.shape, dtype=np.float32)
 plan.set_transfer(k)
+plan.set_stagger(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 img = (100 + 5 * rng.standard_normal((size, size), dtype=np.float32)).astype(np.float32)
 d_img = _native.DeviceBuffer(img.nbytes).upload(img); d_out = _native.DeviceBuffer(img.nbytes)
 geom = _native.Geometry.whole(size, size, 1)

@@ -189,3 +189,33 @@ def test_row_bands_on_one_gpu(world):
         bufs[g][: bands[g].recv_rows] += bufs[g - 1][p.send_offset_rows : p.send_offset_rows + p.send_rows]
     got = np.concatenate([buf[: b.own_rows] for buf, b in zip(bufs, bands)])
     check(got, ref)
+
+
+def test_rccl_wrapper_single_rank():
+    """The dlopen'ed RCCL path of the C ABI (rpsf_comm_*) with world size 1: id, init, all-reduce, no-op seam."""
+    from regularizepsf_amd import _native
+
+    uid = _native.Comm.unique_id()
+    assert len(uid) == 128
+    comm = _native.Comm(0, 0, 1, uid)
+    assert comm.allreduce_max(3.25) == 3.25
+    comm.barrier()
+    buf = _native.DeviceBuffer(4096)
+    comm.seam_exchange_add(buf.ptr, 1024, buf.ptr, 0, buf.ptr)  # no neighbour: nothing to send or receive
+    comm.close()
+
+
+def test_forced_atomic_mode_matches_planes():
+    """Both overlap-add strategies (colour planes + sum kernel, float atomics) give the same image."""
+    from regularizepsf_amd import _native
+
+    fx, coords, k = load_apply_case("n64_sym")
+    image = np.ascontiguousarray(fx["image"], np.float32)
+    outs = {}
+    for mode in ("planes", "atomic"):
+        plan = _native.Plan(64, coords)
+        plan.set_transfer(k)
+        plan.set_overlap_mode(mode)
+        outs[mode] = plan.apply(image, _native.PAD_MODES["symmetric"]).astype(np.float64)
+        check(outs[mode], fx["expected"])
+    assert np.abs(outs["planes"] - outs["atomic"]).max() <= 2e-6 * np.abs(fx["expected"]).max()
