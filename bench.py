@@ -7,9 +7,9 @@ One "step" = one full apply (output clear + fused patch kernel) of the headline 
 Gaussian target, alpha=3, eps=0.1) with image, output and packed transfer kernel resident in HBM.
 For N > 1 (launched by torch.distributed.run, one process per GPU) the image grows to (4096*N) x 4096
 and is split into N row bands of the patch lattice; each rank runs its band and the seam rows are
-exchanged with RCCL send/recv (weak scaling: per-GPU work is fixed).  torch is used here only to
-read the launcher's environment (RANK / WORLD_SIZE / MASTER_*) through a TCPStore that carries the
-RCCL unique id; the compute path is ctypes -> librpsf_hip.so.
+exchanged with RCCL send/recv (weak scaling: per-GPU work is fixed).  torch is used here only for the
+launcher's rendezvous: a gloo group broadcasts the 128-byte RCCL unique id; the compute path and the
+seam exchange are ctypes -> librpsf_hip.so (RCCL is loaded by the library itself).
 
 Prints ONE JSON line on rank 0 (see the "Measurement" section of DESIGN.md for every field).
 """
@@ -135,13 +135,12 @@ def main() -> None:
 
     comm = None
     if world > 1:
-        import torch.distributed as dist  # launcher plumbing only: carries the RCCL unique id
+        import torch.distributed as dist  # launcher plumbing only: a gloo group carries the 128-byte RCCL unique id
 
-        store = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ["MASTER_PORT"]), world,
-                              rank == 0)
-        if rank == 0:
-            store.set("rccl_id", _native.Comm.unique_id())
-        comm = _native.Comm(device, rank, world, bytes(store.get("rccl_id")))
+        dist.init_process_group(backend="gloo")  # env:// rendezvous from torch.distributed.run (works with its agent store)
+        box = [_native.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        comm = _native.Comm(device, rank, world, bytes(box[0]))
     shard = ShardedApply(coords, kernel_for, n, height, w, rank, world, device, comm, pad_mode=pad)
     band = shard.band
     band_image = image_rows(band.image_row0, band.image_row0 + band.image_rows)
@@ -175,6 +174,13 @@ def main() -> None:
     alg_bytes = plan.transfer_bytes + band.image_rows * w * 4 + band.out_rows * w * 4  # K + image + output, once each
     achieved = alg_bytes / (kern_avg_ms * 1e-3) / 1e9
 
+    if comm is not None:  # orderly shutdown: nobody tears RCCL down while a peer is still in a collective
+        import torch.distributed as dist
+
+        barrier()
+        comm.close()
+        dist.barrier()
+        dist.destroy_process_group()
     if rank != 0:
         return
     total_pixels = height * w
