@@ -641,19 +641,10 @@ RPSF_HD void load_patch_raw(int t, cf* v, const ImageView& im, int pr, int pc) {
   StaticFor<0, NR>::run([&]<int R1>() RPSF_AI {
     int r = (R1 << (C::A2 + C::AL)) + tp.r_rest;
     const float* row = base + (size_t)r * im.ld;
-#if defined(RPSF_PROBE_LOAD16)  // timing probe only: half as many, 16-byte loads (data placement is wrong)
-    StaticFor<0, NCOL / 2>::run([&]<int H>() RPSF_AI {
-      int c = ((2 * H) << C::B2) + tp.c_rest;
-      f32x4 q = *reinterpret_cast<const f32x4*>(row + ((2 * c) & ~3));
-      v[R1 * NCOL + 2 * H] = cf{q.x, q.y};
-      v[R1 * NCOL + 2 * H + 1] = cf{q.z, q.w};
-    });
-#else
     StaticFor<0, NCOL>::run([&]<int C1>() RPSF_AI {
       int c = (C1 << C::B2) + tp.c_rest;
       v[R1 * NCOL + C1] = *reinterpret_cast<const cf*>(row + 2 * c);
     });
-#endif
   });
 }
 // Interior patch, step 2: sine window (transform.py:151-155,163).
@@ -711,21 +702,11 @@ RPSF_HD void store_patch(int t, const cf* v, const OutView& ov, int plane, int p
       int r = (R1 << (C::A2 + C::AL)) + tp.r_rest;
       float wr = win[r];
       float* row = base + (size_t)r * ov.ld;
-#if defined(RPSF_PROBE_STORE16)  // timing probe only: half as many, 16-byte stores (data placement is wrong)
-      StaticFor<0, NCOL / 2>::run([&]<int H>() RPSF_AI {
-        int c = ((2 * H) << C::B2) + tp.c_rest;
-        cf w2 = *reinterpret_cast<const cf*>(win + 2 * c);
-        cf a = v[R1 * NCOL + 2 * H] * (w2 * wr), b = v[R1 * NCOL + 2 * H + 1] * (w2 * wr);
-        f32x4 q = {a.x, a.y, b.x, b.y};
-        __builtin_nontemporal_store(q, reinterpret_cast<f32x4*>(row + ((2 * c) & ~3)));
-      });
-#else
       StaticFor<0, NCOL>::run([&]<int C1>() RPSF_AI {
         int c = (C1 << C::B2) + tp.c_rest;
         cf w2 = *reinterpret_cast<const cf*>(win + 2 * c);
         store_stream8(row + 2 * c, v[R1 * NCOL + C1] * (w2 * wr));
       });
-#endif
     });
     return;
   }
