@@ -228,7 +228,7 @@ __device__ __forceinline__ void read_slot_k(int t, cf* k, const float* lds_slot)
 #endif
 
 template <class C>
-__global__ __launch_bounds__(Launch<C>::WG) void patch_kernel(PatchParams p) {
+__global__ __launch_bounds__(Launch<C>::WG, 2) void patch_kernel(PatchParams p) {  // 2 waves per SIMD: 256 registers, no AGPR overflow
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int T = C::T;
   if ((int)blockIdx.x >= p.patch_blocks) {  // workgroup-uniform
@@ -270,9 +270,8 @@ __global__ __launch_bounds__(Launch<C>::WG) void patch_kernel(PatchParams p) {
     tw[i] = p.tw[i];
     win[i] = p.win[i];
   }
-  int gids[C::P];
-#pragma unroll
-  for (int i = 0; i < C::P; ++i) gids[i] = p.tab[t * C::P + i];
+  GroupIds<C> gids;
+  gids.load(p.tab, t);
 #if defined(RPSF_ABL_NOXCHG)
 #define x1_write x1_nop
 #define x1_read x1_nop
@@ -505,9 +504,8 @@ __global__ __launch_bounds__(Launch<C>::WG) void psf_fft_kernel(const float* __r
   const bool active = item < count;
   if (!active) item = count - 1;
   float* lds = smem + team * C::LDS_FLOATS;
-  int gids[C::P];
-#pragma unroll
-  for (int i = 0; i < C::P; ++i) gids[i] = tab[t * C::P + i];
+  GroupIds<C> gids;
+  gids.load(tab, t);
   const float* src = values + (size_t)item * N * N;
   cf v[64];
   {

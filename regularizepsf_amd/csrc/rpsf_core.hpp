@@ -432,9 +432,21 @@ RPSF_HD void x2_mid_read(int t, cf* v, const float* lds) {
     if (PART) v[J].y = f; else v[J].x = f;
   });
 }
+// The thread's P group ids in the last layout (slot-major, member minor), two 16-bit ids per register:
+// at N = 128 a thread owns 32 groups and unpacked ids alone would take 32 of the 256 registers.
+template <class C>
+struct GroupIds {
+  uint32_t w[C::P / 2];
+  RPSF_HD int operator[](int i) const { return (int)((w[i >> 1] >> ((i & 1) * 16)) & 0xffffu); }
+  RPSF_HD void load(const uint16_t* __restrict__ tab, int t) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(tab + (size_t)t * C::P);
+    StaticFor<0, C::P / 2>::run([&]<int I>() RPSF_AI { w[I] = src[I]; });
+  }
+};
+
 // last layout: gids[g] for the thread's P groups (slot-major, member minor)
 template <class C, int PART>
-RPSF_HD void x2_last_read(const int* gids, cf* v, const float* lds) {
+RPSF_HD void x2_last_read(const GroupIds<C>& gids, cf* v, const float* lds) {
   StaticFor<0, C::P>::run([&]<int GI>() RPSF_AI {
     StaticFor<0, C::E>::run([&]<int EE>() RPSF_AI {
       float f = lds[EE * C::X2_STRIDE + gids[GI]];
@@ -443,7 +455,7 @@ RPSF_HD void x2_last_read(const int* gids, cf* v, const float* lds) {
   });
 }
 template <class C, int PART>
-RPSF_HD void x2_last_write(const int* gids, const cf* v, float* lds) {
+RPSF_HD void x2_last_write(const GroupIds<C>& gids, const cf* v, float* lds) {
   StaticFor<0, C::P>::run([&]<int GI>() RPSF_AI {
     StaticFor<0, C::E>::run([&]<int EE>() RPSF_AI {
       lds[EE * C::X2_STRIDE + gids[GI]] = PART ? v[GI * C::E + EE].y : v[GI * C::E + EE].x;
@@ -487,7 +499,7 @@ RPSF_HD void load_slot_k(int t, cf* k, const cf* __restrict__ g) {
 }
 
 template <class C, int S>
-RPSF_HD void pointwise_slot(int t, const int* gids, cf* v, const cf* k, const cf* __restrict__ gs,
+RPSF_HD void pointwise_slot(int t, const GroupIds<C>& gids, cf* v, const cf* k, const cf* __restrict__ gs,
                             const cf* __restrict__ tw) {
   constexpr int E = C::E;
   constexpr int ST = C::spec_t(S);
@@ -538,7 +550,7 @@ template <class C>
 struct KRing {
     // ring registers are capped at 32 per thread: 128 data registers + butterfly temporaries leave no more
   // (a second 32-register slot buffer at N = 256 spilled 216 B per lane)
-  static constexpr int WANT = 8 / C::E < 1 ? 1 : 8 / C::E;
+  static constexpr int WANT = 4 / C::E < 1 ? 1 : 4 / C::E;  // <= 16 registers of K in flight for small E
   static constexpr int DEPTH = C::NSLOT < WANT ? C::NSLOT : WANT;
   cf k[DEPTH][2 * C::E];
 };
@@ -547,7 +559,7 @@ RPSF_HD void kring_fill(int t, KRing<C>& r, const cf* __restrict__ g) {
   StaticFor<0, KRing<C>::DEPTH>::run([&]<int S>() RPSF_AI { load_slot_k<C, S>(t, r.k[S], g); });
 }
 template <class C>
-RPSF_HD void pointwise(int t, const int* gids, cf* v, KRing<C>& r, const cf* __restrict__ g,
+RPSF_HD void pointwise(int t, const GroupIds<C>& gids, cf* v, KRing<C>& r, const cf* __restrict__ g,
                        const cf* __restrict__ gs, const cf* __restrict__ tw) {
   constexpr int D = KRing<C>::DEPTH;
   StaticFor<0, C::NSLOT>::run([&]<int S>() RPSF_AI {

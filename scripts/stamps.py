@@ -4,7 +4,7 @@ import pathlib, sys
 import numpy as np
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
 from regularizepsf_amd import _native, calculate_covering
-n, size = 256, 4096
+n, size = (int(sys.argv[2]) if len(sys.argv) > 2 else 256), 4096
 rng = np.random.default_rng(0)
 coords = [tuple(int(v) for v in t) for t in calculate_covering((size, size), n)]
 plan = _native.Plan(n, coords)

@@ -27,9 +27,8 @@ static int emu_apply_t(int n_patches, const int32_t* coords, int H, int W, int p
   std::vector<cf> regs((size_t)T * 64);
   std::vector<float> lds(C::LDS_FLOATS);
   std::vector<cf> g((size_t)C::G_PER_PATCH), gs((size_t)C::GS_PER_PATCH + 1);
-  std::vector<int> gids((size_t)T * C::P);
-  for (int t = 0; t < T; ++t)
-    for (int i = 0; i < C::P; ++i) gids[(size_t)t * C::P + i] = tab[(size_t)t * C::P + i];
+  std::vector<GroupIds<C>> gids(T);
+  for (int t = 0; t < T; ++t) gids[t].load(tab.data(), t);
   ImageView im{img, H, W, W, pad_mode, pad_value, 0, H};
   OutView ov{out, H, W, W, 0, H, 0};
   memset(out, 0, sizeof(float) * (size_t)H * W);
@@ -62,20 +61,20 @@ static int emu_apply_t(int n_patches, const int32_t* coords, int H, int W, int p
       for (int t = 0; t < T; ++t) stage2<C, false>(t, &regs[(size_t)t * 64], tw.data());
     }
     for (int t = 0; t < T; ++t) x2_mid_write<C, 0>(t, &regs[(size_t)t * 64], lds.data());
-    for (int t = 0; t < T; ++t) x2_last_read<C, 0>(&gids[(size_t)t * C::P], &regs[(size_t)t * 64], lds.data());
+    for (int t = 0; t < T; ++t) x2_last_read<C, 0>(gids[t], &regs[(size_t)t * 64], lds.data());
     for (int t = 0; t < T; ++t) x2_mid_write<C, 1>(t, &regs[(size_t)t * 64], lds.data());
-    for (int t = 0; t < T; ++t) x2_last_read<C, 1>(&gids[(size_t)t * C::P], &regs[(size_t)t * 64], lds.data());
+    for (int t = 0; t < T; ++t) x2_last_read<C, 1>(gids[t], &regs[(size_t)t * 64], lds.data());
     for (int t = 0; t < T; ++t) {
       cf* v = &regs[(size_t)t * 64];
       KRing<C> kring;
       kring_fill<C>(t, kring, g.data());
       stage_last<C, false>(v);
-      pointwise<C>(t, &gids[(size_t)t * C::P], v, kring, g.data(), gs.data(), tw.data());
+      pointwise<C>(t, gids[t], v, kring, g.data(), gs.data(), tw.data());
       stage_last<C, true>(v);
     }
-    for (int t = 0; t < T; ++t) x2_last_write<C, 0>(&gids[(size_t)t * C::P], &regs[(size_t)t * 64], lds.data());
+    for (int t = 0; t < T; ++t) x2_last_write<C, 0>(gids[t], &regs[(size_t)t * 64], lds.data());
     for (int t = 0; t < T; ++t) x2_mid_read<C, 0>(t, &regs[(size_t)t * 64], lds.data());
-    for (int t = 0; t < T; ++t) x2_last_write<C, 1>(&gids[(size_t)t * C::P], &regs[(size_t)t * 64], lds.data());
+    for (int t = 0; t < T; ++t) x2_last_write<C, 1>(gids[t], &regs[(size_t)t * 64], lds.data());
     for (int t = 0; t < T; ++t) x2_mid_read<C, 1>(t, &regs[(size_t)t * 64], lds.data());
     if constexpr (C::S3) {
       for (int t = 0; t < T; ++t) stage2<C, true>(t, &regs[(size_t)t * 64], tw.data());
