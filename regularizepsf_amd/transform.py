@@ -112,6 +112,9 @@ class ArrayPSFTransform:
         if image.ndim != 2:
             msg = f"image must be two dimensional, got shape {image.shape}"
             raise ValueError(msg)
+        if len(self) == 0:  # the reference fails in np.stack([]) (transform.py:157-162)
+            msg = "need at least one array to stack"
+            raise ValueError(msg)
         n = self._checked_patch_size()
         plan = self._device_plan()
         height, width = image.shape

@@ -219,3 +219,45 @@ def test_forced_atomic_mode_matches_planes():
         outs[mode] = plan.apply(image, _native.PAD_MODES["symmetric"]).astype(np.float64)
         check(outs[mode], fx["expected"])
     assert np.abs(outs["planes"] - outs["atomic"]).max() <= 2e-6 * np.abs(fx["expected"]).max()
+
+
+@pytest.mark.parametrize("pad_mode", ["symmetric", "reflect", "edge", "wrap", "constant"])
+@pytest.mark.parametrize("shape", [(5, 7), (1, 1), (33, 9)])
+def test_images_smaller_than_a_patch(shape, pad_mode):
+    """np.pad reflects repeatedly when the pad is wider than the image; the in-kernel index maps must agree."""
+    n = 16
+    rng = np.random.default_rng(shape[0] * 100 + shape[1])
+    coords = [tuple(int(v) for v in c) for c in rp.calculate_covering(shape, n)]
+    k = (rng.standard_normal((len(coords), n, n)) + 1j * rng.standard_normal((len(coords), n, n))).astype(np.complex64)
+    image = rng.standard_normal(shape).astype(np.float32) + 3
+    out = rp.ArrayPSFTransform(rp.IndexedCube(coords, k)).apply(image, pad_mode=pad_mode)
+    check(out, orc.apply_transfer(image, coords, k, pad_mode=pad_mode))
+
+
+def test_input_layouts_and_dtypes():
+    fx, coords, k = load_apply_case("n32_sym")
+    t = rp.ArrayPSFTransform(rp.IndexedCube(coords, k))
+    base = fx["image"]
+    ref = fx["expected"]
+    wide = np.zeros((base.shape[0], 2 * base.shape[1]), np.float32)
+    wide[:, ::2] = base
+    check(t.apply(wide[:, ::2]), ref)                 # non-contiguous view
+    check(t.apply(base.astype(np.float64)), ref)      # float64 input
+    check(t.apply(np.asfortranarray(base)), ref)      # Fortran order
+    ints = np.round(base).astype(np.int32)
+    check(t.apply(ints), orc.apply_transfer(ints, coords, k))  # integer input is promoted like the reference does
+    k128 = k.astype(np.complex128)                     # complex128 kernels are accepted (rounded to complex64 on upload)
+    check(rp.ArrayPSFTransform(rp.IndexedCube(coords, k128)).apply(base), ref)
+
+
+def test_editing_the_kernel_invalidates_the_device_copy():
+    fx, coords, k = load_apply_case("n32_sym")
+    cube = rp.IndexedCube(coords, k.copy())
+    t = rp.ArrayPSFTransform(cube)
+    first = t.apply(fx["image"])
+    cube[coords[0]] = np.zeros((32, 32), np.complex64)       # __setitem__ is tracked
+    second = t.apply(fx["image"])
+    k2 = k.copy()
+    k2[0] = 0
+    check(second, orc.apply_transfer(fx["image"], coords, k2))
+    assert np.abs(first - second).max() > 0

@@ -132,3 +132,10 @@ def test_apply_argument_errors_come_before_any_device_work():
         rp.ArrayPSFTransform(rp.IndexedCube([(0, 0)], np.ones((1, 32, 16), np.complex64))).apply(np.zeros((64, 64)))
     with pytest.raises(NotImplementedError):  # no compiled plan for this size
         rp.ArrayPSFTransform(rp.IndexedCube([(0, 0)], np.ones((1, 24, 24), np.complex64))).apply(np.zeros((64, 64)))
+
+
+def test_empty_transform_raises_like_the_reference():
+    t = rp.ArrayPSFTransform(rp.IndexedCube([], np.zeros((0, 16, 16), np.complex64)))
+    assert len(t) == 0
+    with pytest.raises(ValueError):
+        t.apply(np.zeros((8, 8)))
