@@ -76,6 +76,52 @@ def cpu_baseline(image, coords, k, budget_s: float = 20.0):
     }
 
 
+class GlooSeam:
+    """Debug stand-in for regularizepsf_amd._native.Comm: same calls, seam rows travel through the host over gloo."""
+
+    def __init__(self, rank, world, device):
+        self.rank, self.world, self.device = rank, world, device
+
+    def seam_exchange_add(self, send_ptr, send_count, recv_ptr, recv_count, accum_ptr, stream=None):
+        import ctypes
+        import torch
+        import torch.distributed as dist
+        from regularizepsf_amd import _native
+
+        lib = _native.lib()
+        _native.check(lib.rpsf_device_synchronize(self.device))
+        req = None
+        if self.rank + 1 < self.world and send_count:
+            out = np.empty(send_count, np.float32)
+            _native.check(lib.rpsf_memcpy_d2h(self.device, out.ctypes.data_as(ctypes.c_void_p), send_ptr, out.nbytes))
+            req = dist.isend(torch.from_numpy(out), self.rank + 1)
+        if self.rank > 0 and recv_count:
+            got = torch.empty(recv_count, dtype=torch.float32)
+            dist.recv(got, self.rank - 1)
+            acc = np.empty(recv_count, np.float32)
+            _native.check(lib.rpsf_memcpy_d2h(self.device, acc.ctypes.data_as(ctypes.c_void_p), accum_ptr, acc.nbytes))
+            acc += got.numpy()
+            _native.check(lib.rpsf_memcpy_h2d(self.device, accum_ptr, acc.ctypes.data_as(ctypes.c_void_p), acc.nbytes))
+        if req is not None:
+            req.wait()
+
+    def barrier(self, stream=None):
+        import torch.distributed as dist
+
+        dist.barrier()
+
+    def allreduce_max(self, value):
+        import torch
+        import torch.distributed as dist
+
+        t = torch.tensor([value], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0])
+
+    def close(self):
+        pass
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,6 +129,10 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--comm", choices=["rccl", "gloo"], default="rccl",
+                    help="seam transport for N > 1; 'gloo' is a debug stand-in (host copies) used to exercise the "
+                         "multi-rank flow on a box with fewer GPUs than ranks")
+    ap.add_argument("--verify", action="store_true", help="check every rank's owned rows against the CPU oracle")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -97,7 +147,7 @@ def main() -> None:
 
     h1, w, n, seed = CONFIGS[args.config]
     height = h1 * world
-    device = local_rank
+    device = local_rank % max(1, _native.device_count()) if args.comm == "gloo" else local_rank
     pad = "symmetric"
 
     # ---------------- inputs: synthetic, same recipe on every rank, each rank builds only its band ----------
@@ -138,9 +188,12 @@ def main() -> None:
         import torch.distributed as dist  # launcher plumbing only: a gloo group carries the 128-byte RCCL unique id
 
         dist.init_process_group(backend="gloo")  # env:// rendezvous from torch.distributed.run (works with its agent store)
-        box = [_native.Comm.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        comm = _native.Comm(device, rank, world, bytes(box[0]))
+        if args.comm == "rccl":
+            box = [_native.Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            comm = _native.Comm(device, rank, world, bytes(box[0]))
+        else:
+            comm = GlooSeam(rank, world, device)
     shard = ShardedApply(coords, kernel_for, n, height, w, rank, world, device, comm, pad_mode=pad)
     band = shard.band
     band_image = image_rows(band.image_row0, band.image_row0 + band.image_rows)
@@ -174,6 +227,18 @@ def main() -> None:
     alg_bytes = plan.transfer_bytes + band.image_rows * w * 4 + band.out_rows * w * 4  # K + image + output, once each
     achieved = alg_bytes / (kern_avg_ms * 1e-3) / 1e9
 
+    if args.verify:  # every rank checks the rows it owns against the float64 oracle on the same inputs
+        run_step()
+        barrier()
+        own = shard.owned_rows().astype(np.float64)
+        full_image = image_rows(0, height)
+        ref = orc.apply_transfer(full_image, coords, kernel_for(list(range(len(coords)))), workers=-1)
+        ref_own = ref[band.out_row0:band.out_row0 + band.own_rows]
+        err = float(np.abs(own - ref_own).max() / np.abs(ref).max())
+        print(f"[verify] rank {rank}: rows {band.out_row0}..{band.out_row0 + band.own_rows}, max|d|/max|ref| = {err:.3e}",
+              file=sys.stderr, flush=True)
+        if err > 1e-5:
+            raise SystemExit(f"verification failed on rank {rank}")
     if comm is not None:  # orderly shutdown: nobody tears RCCL down while a peer is still in a collective
         import torch.distributed as dist
 
@@ -193,7 +258,7 @@ def main() -> None:
         "dtype": "f32", "data": "synthetic",
         "config": {
             "workload": f"{height}x{w} starfield, {n}x{n} patches, {len(coords)} patches "
-                        f"({'whole image on one GPU' if world == 1 else f'{world} row bands, RCCL seam exchange'}), "
+                        f"({'whole image on one GPU' if world == 1 else f'{world} row bands, {args.comm.upper()} seam exchange'}), "
                         f"coma PSF grid -> Gaussian target, alpha=3 eps=0.1, pad symmetric",
             "image": [height, w], "patch": n, "patches": len(coords), "device": name, "compute_units": cus,
             "resident": "image, output and packed transfer kernel in HBM before the timed region",
