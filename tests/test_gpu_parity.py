@@ -280,9 +280,17 @@ def test_kernel_fft_agrees_with_hipfft():
     z = vals.astype(np.complex64)
     d_in = _native.DeviceBuffer(z.nbytes).upload(z)
     d_out = _native.DeviceBuffer(z.nbytes)
-    plan = ctypes.c_int(0)
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    hipfft.hipfftPlanMany.restype = ci  # hipfftHandle is a pointer: declare every prototype explicitly
+    hipfft.hipfftPlanMany.argtypes = [ctypes.POINTER(vp), ci, ctypes.POINTER(ci), ctypes.POINTER(ci), ci, ci,
+                                      ctypes.POINTER(ci), ci, ci, ci, ci]
+    hipfft.hipfftExecC2C.restype = ci
+    hipfft.hipfftExecC2C.argtypes = [vp, vp, vp, ci]
+    hipfft.hipfftDestroy.restype = ci
+    hipfft.hipfftDestroy.argtypes = [vp]
+    plan = vp()
     HIPFFT_C2C, HIPFFT_FORWARD = 0x29, -1
-    dims = (ctypes.c_int * 2)(n, n)
+    dims = (ci * 2)(n, n)
     rc = hipfft.hipfftPlanMany(ctypes.byref(plan), 2, dims, None, 1, n * n, None, 1, n * n, HIPFFT_C2C, count)
     assert rc == 0
     assert hipfft.hipfftExecC2C(plan, d_in.ptr, d_out.ptr, HIPFFT_FORWARD) == 0
