@@ -118,6 +118,10 @@ int rpsf_build_transfer_device(int device, size_t count, const void* s_dev, cons
  * complex64 out, (count, N, N) host arrays. */
 int rpsf_psf_fft(int device, int patch_size, int count, const float* values_host, float* fft_c64_host);
 
+/* Host-side helper for the saturation branch of apply (transform.py:135-138): sequential, row-major
+ * NaN-ignoring neighbourhood-mean fill of the masked pixels of the float64 padded image (no GPU involved). */
+int rpsf_saturation_fill(double* padded, int rows, int cols, const uint8_t* mask, int neighborhood_width);
+
 /* Device memory helpers for callers that keep frames resident (bench, tests, streaming). */
 int rpsf_dev_alloc(int device, size_t bytes, void** out);
 int rpsf_dev_free(int device, void* ptr);

@@ -67,6 +67,7 @@ _PROTOTYPES = {
     "rpsf_build_transfer_device": (c_int, [c_int, c_size_t, c_void_p, c_void_p, c_int, c_double, c_double, c_void_p,
                                            c_void_p]),
     "rpsf_psf_fft": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rpsf_saturation_fill": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int]),
     "rpsf_dev_alloc": (c_int, [c_int, c_size_t, POINTER(c_void_p)]),
     "rpsf_dev_free": (c_int, [c_int, c_void_p]),
     "rpsf_memcpy_h2d": (c_int, [c_int, c_void_p, c_void_p, c_size_t]),
@@ -257,6 +258,15 @@ def psf_fft(values: np.ndarray, device: int = 0) -> np.ndarray:
     if v.shape[0]:
         check(lib().rpsf_psf_fft(device, v.shape[1], v.shape[0], _ptr(v), _ptr(out)))
     return out
+
+
+def saturation_fill(padded: np.ndarray, mask: np.ndarray, neighborhood_width: int) -> None:
+    """In-place sequential neighbourhood-mean fill of ``padded[mask]`` (float64, C-contiguous), transform.py:135-138."""
+    if padded.dtype != np.float64 or not padded.flags.c_contiguous:
+        msg = "padded must be a C-contiguous float64 array"
+        raise ValueError(msg)
+    m = np.ascontiguousarray(mask, dtype=np.uint8)
+    check(lib().rpsf_saturation_fill(_ptr(padded), padded.shape[0], padded.shape[1], _ptr(m), int(neighborhood_width)))
 
 
 class Comm:

@@ -1215,6 +1215,41 @@ extern "C" int rpsf_psf_fft(int device, int patch_size, int count, const float* 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Host-side saturation fill (regularizepsf/transform.py:135-138).  Sequential by definition: masked pixels
+// are visited in row-major order and each is replaced by the NaN-ignoring mean of the window
+// [i - w/2, i + w/2) x [j - w/2, j + w/2), so later pixels see earlier fills.  Window bounds follow Python
+// slice semantics (a negative start wraps once; an empty window gives NaN), as in the reference.
+// ------------------------------------------------------------------------------------------------
+static void py_slice(long start, long stop, long n, long* lo, long* hi) {
+  if (start < 0) start = std::max(start + n, 0L);
+  if (stop < 0) stop = std::max(stop + n, 0L);
+  *lo = std::min(start, n);
+  *hi = std::min(stop, n);
+}
+
+extern "C" int rpsf_saturation_fill(double* padded, int rows, int cols, const uint8_t* mask, int neighborhood_width) {
+  if (!padded || !mask || rows <= 0 || cols <= 0) return fail(RPSF_E_BADARG, "bad argument");
+  const long h = neighborhood_width / 2;  // floor division, like Python's // for the non-negative widths in use
+  const double nan = std::nan("");
+  for (long i = 0; i < rows; ++i)
+    for (long j = 0; j < cols; ++j) {
+      if (!mask[i * cols + j]) continue;
+      long r0, r1, c0, c1;
+      py_slice(i - h, i + h, rows, &r0, &r1);
+      py_slice(j - h, j + h, cols, &c0, &c1);
+      double sum = 0.0;
+      long cnt = 0;
+      for (long r = r0; r < r1; ++r)
+        for (long c = c0; c < c1; ++c) {
+          double v = padded[r * cols + c];
+          if (v == v) sum += v, ++cnt;
+        }
+      padded[i * cols + j] = cnt ? sum / (double)cnt : nan;
+    }
+  return RPSF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // device memory helpers
 // ------------------------------------------------------------------------------------------------
 extern "C" int rpsf_dev_alloc(int device, size_t bytes, void** out) {

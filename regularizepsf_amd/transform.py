@@ -137,10 +137,14 @@ class ArrayPSFTransform:
 
             mask = binary_dilation(mask, iterations=saturation_dilation)
             padded[mask] = np.nan
-            half = neighborhood_width // 2
-            with np.errstate(all="ignore"):
-                for i, j in zip(*np.where(mask)):  # sequential: later pixels see earlier fills
-                    padded[i, j] = np.nanmean(padded[i - half : i + half, j - half : j + half])
+            if neighborhood_width >= 0:
+                # the reference's per-pixel np.nanmean loop, restated in C (same order, same window rule)
+                _native.saturation_fill(padded, mask, neighborhood_width)
+            else:  # negative widths: keep NumPy's own slice arithmetic
+                half = neighborhood_width // 2
+                with np.errstate(all="ignore"):
+                    for i, j in zip(*np.where(mask)):
+                        padded[i, j] = np.nanmean(padded[i - half : i + half, j - half : j + half])
         corrected = self._apply_prepadded(padded.astype(np.float32), 2 * n)
         corrected = corrected.astype(np.float64)
         corrected[mask] = raw[mask]

@@ -66,3 +66,29 @@ def test_product_never_imports_the_oracle():
     for path in (ROOT / "regularizepsf_amd").rglob("*"):
         if path.suffix in {".py", ".hip", ".hpp"}:
             assert "oracle" not in path.read_text().replace("# oracle", ""), f"{path} mentions the oracle"
+
+
+def test_saturation_fill_matches_the_reference_loop():
+    """rpsf_saturation_fill (host code in the library) vs the per-pixel np.nanmean loop of transform.py:135-138,
+    including windows that hang over the array edge (Python negative-slice rule) and all-NaN windows."""
+    rng = np.random.default_rng(21)
+    for width in (7, 5, 1, 0, 2):
+        padded = rng.standard_normal((40, 37)) * 10
+        mask = rng.random((40, 37)) > 0.8
+        mask[:3, :] |= rng.random((3, 37)) > 0.3      # dense near the top edge
+        mask[:, -2:] = True                            # and on the right edge
+        mask[20:30, 5:15] = True                       # a block big enough to produce empty (all-NaN) windows
+        expect = padded.copy()
+        expect[mask] = np.nan
+        with np.errstate(all="ignore"):
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                for i, j in zip(*np.where(mask)):
+                    expect[i, j] = np.nanmean(expect[i - width // 2 : i + width // 2, j - width // 2 : j + width // 2])
+        got = padded.copy()
+        got[mask] = np.nan
+        _native.saturation_fill(got, mask, width)
+        assert np.array_equal(np.isnan(got), np.isnan(expect)), width
+        ok = ~np.isnan(expect)
+        assert np.allclose(got[ok], expect[ok], rtol=1e-13, atol=0), width
