@@ -189,35 +189,6 @@ __device__ __forceinline__ void x2_nop(A, B, D) {}
 __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// K staging through LDS (N = 256 plan).  The X2 exchange buffer is idle from the end of X2 to the start
-// of X2'; K slots 1 and 2 (2 x 64 KiB) are copied into it by LDS-DMA (no data registers), slot 0 and slot 3
-// travel through registers.  That puts ~190 KiB of K in flight per CU instead of 64 KiB; the register
-// file (128 data + 2 x 32 K registers) has no room for more.  Each lane reads back exactly the bytes it
-// asked for, so no cross-wave synchronisation is needed for the staged K itself.
-template <class C>
-struct KStage {
-  static constexpr bool enabled = C::NSLOT == 4 && C::S3 && (2 * C::E * C::T * 8 * 2 <= C::LDS_FLOATS * 4);
-  static constexpr int SLOT_FLOATS = 2 * C::E * C::T * 2;  // floats per staged slot
-};
-template <class C, int S>
-__device__ __forceinline__ void dma_slot_k(int t, float* lds_slot, const cf* __restrict__ g) {
-  StaticFor<0, C::E>::run([&]<int I>() RPSF_AI {
-    const cf* src = g + ((size_t)(S * C::E + I) * C::T + t) * 2;                 // per-lane source
-    float* dst = lds_slot + ((size_t)I * C::T + (t & ~63)) * 4;                   // wave-uniform base; lane*16 B is implied
-    typedef const __attribute__((address_space(1))) void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
-    __builtin_amdgcn_global_load_lds((gptr_t)(const void*)src, (lptr_t)(void*)dst, 16, 0, 0);
-  });
-}
-template <class C>
-__device__ __forceinline__ void read_slot_k(int t, cf* k, const float* lds_slot) {
-  StaticFor<0, C::E>::run([&]<int I>() RPSF_AI {
-    const f32x4 q = *reinterpret_cast<const f32x4*>(lds_slot + ((size_t)I * C::T + t) * 4);
-    k[2 * I] = cf{q.x, q.y};
-    k[2 * I + 1] = cf{q.z, q.w};
-  });
-}
-
 #if defined(RPSF_STAMPS)
 #define STAMP(i)                                                                                         \
   do {                                                                                                   \
@@ -339,36 +310,10 @@ __global__ __launch_bounds__(Launch<C>::WG, 2) void patch_kernel(PatchParams p) 
   // no barrier: every X2 word is read by exactly one thread, the same one that rewrites it below
 
   STAMP(5);
-#if defined(RPSF_KSTAGE) && !defined(RPSF_ABL_NOK) && !defined(RPSF_ABL_NOXCHG)  // measured: no gain (extra barriers), kept for reference
-  if constexpr (KStage<C>::enabled) {
-    const cf* gs = p.gs + (size_t)patch * C::GS_PER_PATCH;
-    lds_barrier();  // every wave has read its X2 data: the buffer may be overwritten
-    dma_slot_k<C, 1>(t, lds, g);
-    dma_slot_k<C, 2>(t, lds + KStage<C>::SLOT_FLOATS, g);
-    stage_last<C, false>(v);
-    STAMP(6);
-    pointwise_slot<C, 0>(t, gids, v, kring.k[0], gs, tw);
-    load_slot_k<C, 3>(t, kring.k[0], g);  // slot 3 reuses slot 0's registers
-    // 2E DMA pieces (older) must have landed; the E loads of slot 3 (younger) may still be in flight
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::E) : "memory");
-    {
-      cf k1[2 * C::E];
-      read_slot_k<C>(t, k1, lds);
-      pointwise_slot<C, 1>(t, gids, v, k1, gs, tw);
-      read_slot_k<C>(t, k1, lds + KStage<C>::SLOT_FLOATS);
-      pointwise_slot<C, 2>(t, gids, v, k1, gs, tw);
-    }
-    pointwise_slot<C, 3>(t, gids, v, kring.k[0], gs, tw);
-    STAMP(7);
-    stage_last<C, true>(v);
-    STAMP(8);
-    lds_barrier();  // staged K fully consumed before X2' reuses the buffer
-  } else
-#endif
   {
     stage_last<C, false>(v);
     STAMP(6);
-    pointwise<C>(t, gids, v, kring, g, p.gs + (size_t)patch * C::GS_PER_PATCH, tw);
+    pointwise<C>(t, gids, v, kring, g, p.gs + (size_t)patch * C::GS_PER_PATCH, tw, reinterpret_cast<cf*>(lds));
     STAMP(7);
     stage_last<C, true>(v);
     STAMP(8);
@@ -440,12 +385,10 @@ __global__ void pack_kernel(const cf* __restrict__ kfull, int n_patches, const u
   int rho = 2 * i + b;
   const cf* kf = kfull + (size_t)patch * C::N * C::N;
   g[idx] = pack_value<C>(kf, tab, t, rho, 0);
-  int s = rho / (2 * C::E);
-  if (slot_is_special<C>(s, t)) {
-    int r = rho % (2 * C::E);
-    gs[(size_t)patch * C::GS_PER_PATCH + (size_t)C::spec_prefix(s) * 2 * C::E + (size_t)r * C::spec_t(s) + t] =
+  const int w = rho >> 1, s = w / C::E, e = w % C::E;
+  if (slot_is_special<C>(s, t))
+    gs[(size_t)patch * C::GS_PER_PATCH + (size_t)C::spec_prefix(s) * 2 * C::E + ((size_t)e * C::spec_t(s) + t) * 2 + b] =
         pack_value<C>(kf, tab, t, rho, 1);
-  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -514,7 +457,7 @@ __global__ __launch_bounds__(Launch<C>::WG) void psf_fft_kernel(const float* __r
     StaticFor<0, NR>::run([&]<int R1>() RPSF_AI {
       int r = (R1 << (C::A2 + C::AL)) + tp.r_rest;
       StaticFor<0, NCOL>::run([&]<int C1>() RPSF_AI {
-        int c = (C1 << C::B2) + tp.c_rest;
+        int c = (C1 << (C::B2 + C::BL)) + tp.c_rest;
         v[R1 * NCOL + C1] = cf{src[(size_t)r * N + 2 * c], src[(size_t)r * N + 2 * c + 1]};
       });
     });
@@ -550,25 +493,30 @@ __global__ __launch_bounds__(Launch<C>::WG) void psf_fft_kernel(const float* __r
     int qa, ma, qb, mb;
     gid_to_qm<C>(ga, qa, ma);
     gid_to_qm<C>(gb, qb, mb);
-    cf wa = tw[ma], wb = tw[mb];
+    const bool qza = qa == 0, qzb = qb == 0, mza = ma == 0, mzb = mb == 0;
     StaticFor<0, E>::run([&]<int EE>() RPSF_AI {
-      constexpr int R = E - 1 - EE, Z = (E - EE) % E;
-      cf az = za[Z], ar = za[R], bz = zb[Z], br = zb[R];
-      cf pa = sel(self, sel(qa == 0, az, ar), sel(qa == 0, bz, br));
-      cf pb = sel(self, sel(qb == 0, bz, br), sel(qb == 0, az, ar));
+      constexpr int EA = C::EA, EB = C::EB, K3 = EE / EB, L3 = EE % EB;
+      constexpr int RR = (EA - 1 - K3) * EB + (EB - 1 - L3), ZR = ((EA - K3) % EA) * EB + (EB - 1 - L3);
+      constexpr int RZ = (EA - 1 - K3) * EB + (EB - L3) % EB, ZZ = ((EA - K3) % EA) * EB + (EB - L3) % EB;
+      auto pick = [&](const cf* src, bool qz, bool mz) RPSF_AI {
+        cf rr = src[RR], zr = src[ZR], rz = src[RZ], zz = src[ZZ];
+        return sel(mz, sel(qz, zz, rz), sel(qz, zr, rr));
+      };
+      cf pa = sel(self, pick(za, qza, mza), pick(zb, qza, mza));
+      cf pb = sel(self, pick(zb, qzb, mzb), pick(za, qzb, mzb));
       {
+        const int kr = qa + C::Q * K3, kc = ma + C::M * L3;
         cf zc = cconj(pa);
-        cf e2 = (za[EE] + zc) * 0.5f, wo = cmul(wa, mul_mi(za[EE] - zc)) * 0.5f;
-        int kr = qa + C::Q * EE;
-        dst[(size_t)kr * N + ma] = e2 + wo;
-        dst[(size_t)kr * N + ma + NC] = e2 - wo;
+        cf e2 = (za[EE] + zc) * 0.5f, wo = cmul(tw[kc], mul_mi(za[EE] - zc)) * 0.5f;
+        dst[(size_t)kr * N + kc] = e2 + wo;
+        dst[(size_t)kr * N + kc + NC] = e2 - wo;
       }
       {
+        const int kr = qb + C::Q * K3, kc = mb + C::M * L3;
         cf zc = cconj(pb);
-        cf e2 = (zb[EE] + zc) * 0.5f, wo = cmul(wb, mul_mi(zb[EE] - zc)) * 0.5f;
-        int kr = qb + C::Q * EE;
-        dst[(size_t)kr * N + mb] = e2 + wo;
-        dst[(size_t)kr * N + mb + NC] = e2 - wo;
+        cf e2 = (zb[EE] + zc) * 0.5f, wo = cmul(tw[kc], mul_mi(zb[EE] - zc)) * 0.5f;
+        dst[(size_t)kr * N + kc] = e2 + wo;
+        dst[(size_t)kr * N + kc + NC] = e2 - wo;
       }
     });
   });

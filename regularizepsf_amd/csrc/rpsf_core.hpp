@@ -21,12 +21,14 @@
 //   * the result is windowed again and overlap-added into the output image (transform.py:165-169).
 //
 // Index algebra.  Row index r has LR = LOGN bits split in digits (A1 | A2 | AL), most significant
-// first; packed-column index c has LC = LOGN-1 bits split in (B1 | B2).  Decimation in frequency:
-//   r = r1*2^(A2+AL) + r2*2^AL + r3      ->  kr = k1 + k2*2^A1 + k3*2^(A1+A2)
-//   c = c1*2^B2 + c2                     ->  kc = l1 + l2*2^B1
-// stage 1 owns (r1,c1) in registers, stage 2 (r2,c2), the last stage r3 (and no column digit, so
-// that -p maps element e of a group to element E-1-e of the partner group, for every group with
-// q != 0).  A1+B1 = 6 and A2+B2 = 6 (three-stage plans, N >= 128) or 0 (two-stage plans, N <= 64).
+// first; packed-column index c has LC = LOGN-1 bits split in (B1 | B2 | BL).  Decimation in frequency:
+//   r = r1*2^(A2+AL) + r2*2^AL + r3        ->  kr = k1 + k2*2^A1 + k3*2^(A1+A2) = q + Q*k3
+//   c = c1*2^(B2+BL) + c2*2^BL + c3        ->  kc = l1 + l2*2^B1 + l3*2^(B1+B2) = m + M*l3
+// stage 1 owns (r1,c1) in registers, stage 2 (r2,c2), the last stage (r3,c3): element e = k3*2^BL + l3 of
+// group (q,m).  -p maps element e of a group to element E-1-e of the partner group (-q,-m) whenever
+// q != 0 and m != 0 (both digits are complemented).  A1+B1 = 6 and A2+B2 = 6 (three-stage plans,
+// N >= 128, BL = 0) or 0 (two-stage plans, N <= 64, which put column bits in the last stage so that
+// consecutive lanes own consecutive columns).
 #pragma once
 #include <stdint.h>
 
@@ -175,18 +177,21 @@ RPSF_HD void fft_axis(cf* v) {
 // ------------------------------------------------------------------------------------------
 // Plan geometry
 // ------------------------------------------------------------------------------------------
-template <int LOGN_, int A1_, int A2_, int AL_, int B1_, int B2_>
+template <int LOGN_, int A1_, int A2_, int AL_, int B1_, int B2_, int BL_ = 0>
 struct Cfg {
   static constexpr int LOGN = LOGN_, N = 1 << LOGN_, NC = N / 2, LR = LOGN_, LC = LOGN_ - 1;
-  static constexpr int A1 = A1_, A2 = A2_, AL = AL_, B1 = B1_, B2 = B2_;
+  static constexpr int A1 = A1_, A2 = A2_, AL = AL_, B1 = B1_, B2 = B2_, BL = BL_;
   static constexpr bool S3 = (A2_ + B2_) != 0;  // three stages
-  static_assert(A1_ + A2_ + AL_ == LOGN_ && B1_ + B2_ == LOGN_ - 1, "digits must cover the index");
-  static_assert(A1_ + B1_ == 6 && (A2_ + B2_ == 6 || A2_ + B2_ == 0) && AL_ >= 1, "64 values per thread per stage");
-  static constexpr int E = 1 << AL_;          // bins per group (last-stage DFT length)
+  static_assert(A1_ + A2_ + AL_ == LOGN_ && B1_ + B2_ + BL_ == LOGN_ - 1, "digits must cover the index");
+  static_assert(A1_ + B1_ == 6 && (A2_ + B2_ == 6 || A2_ + B2_ == 0) && AL_ + BL_ >= 1 && B1_ + B2_ >= 1,
+                "64 values per thread per stage");
+  static constexpr int EA = 1 << AL_, EB = 1 << BL_;
+  static constexpr int E = EA * EB;           // bins per group (last-stage 2-D DFT size), e = k3*EB + l3
   static constexpr int P = 64 / E;            // groups per thread in the last layout
   static constexpr int NSLOT = P / 2;         // pair slots per thread
+  static constexpr int KCH = E >= 8 ? 8 : 4;   // pair words of K per streaming chunk (2 cf = 4 registers each)
   static constexpr int T = N * NC / 64;       // threads per patch
-  static constexpr int LQ = A1_ + A2_, Q = 1 << LQ, M = NC, G = Q * M;  // group (q,m): kr = q + Q*e, kc = m
+  static constexpr int LQ = A1_ + A2_, Q = 1 << LQ, M = 1 << (B1_ + B2_), G = Q * M;  // kr = q + Q*k3, kc = m + M*l3
   static constexpr int NSPEC = (Q + M) / 2;   // slots whose groups have q == 0, m == 0 or are self-paired
   static constexpr int WAVE = T < 64 ? T : 64;  // threads that share the special/general decision
   // threads t' < spec_t(s) of slot s use the "special" K format (natural K_h plus the Nyquist-side array)
@@ -208,7 +213,9 @@ struct Cfg {
   static constexpr int X1_FLOATS = S3 ? (T / 64) * 64 * 65 : 0;
   static constexpr int X2_STRIDE = S3 ? G : G + 1;
   static constexpr int X2_FLOATS = E * X2_STRIDE;
-  static constexpr int LDS_FLOATS = X1_FLOATS > X2_FLOATS ? X1_FLOATS : X2_FLOATS;
+  static constexpr int PARK_FLOATS = S3 ? 0 : 2 * E * T * 2;  // parked special slot (two-stage plans), cf = 2 floats
+  static constexpr int LDS_FLOATS0 = X1_FLOATS > X2_FLOATS ? X1_FLOATS : X2_FLOATS;
+  static constexpr int LDS_FLOATS = LDS_FLOATS0 > PARK_FLOATS ? LDS_FLOATS0 : PARK_FLOATS;
   static constexpr float SCALE = 1.0f / (2.0f * (float)N * (float)N);  // 1/4 (pair algebra) * 1/(N*N/2) (inverse DFT)
 };
 
@@ -311,18 +318,21 @@ RPSF_HD int pad_index(int i, int n, int mode) {  // returns -1 for "constant val
 // ------------------------------------------------------------------------------------------
 template <class C>
 struct ThreadPos {
-  int r_rest, c_rest;  // stage-1 layout: r = r1*2^(A2+AL) + r_rest, c = c1*2^B2 + c_rest
-  int r3;              // last row digit (same thread bits in the stage-1 and stage-2 layouts)
+  int r_rest, c_rest;  // stage-1 layout: r = r1*2^(A2+AL) + r_rest, c = c1*2^(B2+BL) + c_rest
+  int r3, c3;          // last digits (same thread bits in the stage-1 and stage-2 layouts)
   RPSF_HD explicit ThreadPos(int t) {
+    // thread index = e * (T / E) + (stage digit bits), e = r3 * 2^BL + c3
+    const int e = C::S3 ? (t >> 6) : t;
+    r3 = e >> C::BL;
+    c3 = e & ((1 << C::BL) - 1);
     if constexpr (C::S3) {
-      r3 = t >> 6;
       int r2 = (t >> C::B2) & ((1 << C::A2) - 1);
-      c_rest = t & ((1 << C::B2) - 1);
+      int c2 = t & ((1 << C::B2) - 1);
       r_rest = (r2 << C::AL) + r3;
+      c_rest = (c2 << C::BL) + c3;
     } else {
-      r3 = t;
-      r_rest = t;
-      c_rest = 0;
+      r_rest = r3;
+      c_rest = c3;
     }
   }
 };
@@ -341,14 +351,14 @@ RPSF_HD void stage1(int t, cf* v, const cf* __restrict__ tw) {
       StaticFor<0, NCOL>::run([&]<int C1>() RPSF_AI { v[K1 * NCOL + C1] = cmul(v[K1 * NCOL + C1], w); });
     });
     fft_axis<C::B1, 1, NR, NCOL, false>(v);
-    if constexpr (C::B2 > 0) {
+    if constexpr (C::B2 + C::BL > 0) {
       StaticFor<1, NCOL>::run([&]<int L1>() RPSF_AI {
         cf w = tw[(2 * L1 * tp.c_rest) & (C::N - 1)];
         StaticFor<0, NR>::run([&]<int K1>() RPSF_AI { v[K1 * NCOL + L1] = cmul(v[K1 * NCOL + L1], w); });
       });
     }
   } else {
-    if constexpr (C::B2 > 0) {
+    if constexpr (C::B2 + C::BL > 0) {
       StaticFor<1, NCOL>::run([&]<int L1>() RPSF_AI {
         cf w = tw[(2 * L1 * tp.c_rest) & (C::N - 1)];
         StaticFor<0, NR>::run([&]<int K1>() RPSF_AI { v[K1 * NCOL + L1] = cmulc(v[K1 * NCOL + L1], w); });
@@ -368,6 +378,16 @@ RPSF_HD void stage2(int t, cf* v, const cf* __restrict__ tw) {
   if constexpr (C::S3) {
     constexpr int NR = 1 << C::A2, NCOL = 1 << C::B2;
     ThreadPos<C> tp(t);
+    auto col_twiddle = [&]() RPSF_AI {  // W_{2^(B2+BL)}^(l2 c3), only when the last stage owns column bits
+      if constexpr (C::BL > 0) {
+        StaticFor<1, NCOL>::run([&]<int L2>() RPSF_AI {
+          cf w = tw[((2 * L2 * tp.c3) << C::B1) & (C::N - 1)];
+          StaticFor<0, NR>::run([&]<int K2>() RPSF_AI {
+            v[K2 * NCOL + L2] = INV ? cmulc(v[K2 * NCOL + L2], w) : cmul(v[K2 * NCOL + L2], w);
+          });
+        });
+      }
+    };
     if constexpr (!INV) {
       fft_axis<C::A2, NCOL, NCOL, 1, false>(v);
       StaticFor<1, NR>::run([&]<int K2>() RPSF_AI {
@@ -375,7 +395,9 @@ RPSF_HD void stage2(int t, cf* v, const cf* __restrict__ tw) {
         StaticFor<0, NCOL>::run([&]<int C2>() RPSF_AI { v[K2 * NCOL + C2] = cmul(v[K2 * NCOL + C2], w); });
       });
       fft_axis<C::B2, 1, NR, NCOL, false>(v);
+      col_twiddle();
     } else {
+      col_twiddle();
       fft_axis<C::B2, 1, NR, NCOL, true>(v);
       StaticFor<1, NR>::run([&]<int K2>() RPSF_AI {
         cf w = tw[((K2 * tp.r3) << C::A1) & (C::N - 1)];
@@ -386,10 +408,13 @@ RPSF_HD void stage2(int t, cf* v, const cf* __restrict__ tw) {
   }
 }
 
-// Last stage: DFT over r3 inside every group (register index rho = group*E + e).
+// Last stage: 2-D DFT over (r3, c3) inside every group (register index rho = group*E + k3*EB + l3).
 template <class C, bool INV>
 RPSF_HD void stage_last(cf* v) {
-  fft_axis<C::AL, 1, C::P, C::E, INV>(v);
+  StaticFor<0, C::P>::run([&]<int GI>() RPSF_AI {
+    fft_axis<C::AL, C::EB, C::EB, 1, INV, GI * C::E>(v);   // along r3 for every l3
+    fft_axis<C::BL, 1, C::EA, C::EB, INV, GI * C::E>(v);   // along c3 for every k3
+  });
 }
 
 // ------------------------------------------------------------------------------------------
@@ -483,88 +508,137 @@ RPSF_HD PairOut pair_op(cf za, cf zb, cf ka, cf kb, cf w) {
   return r;
 }
 
-// K values of slot S (2E complex values, E 16-byte loads).  Issued one slot ahead of their use so the
-// HBM latency of the next slot hides behind the arithmetic of the current one.
-template <class C, int S>
-RPSF_HD void load_slot_k(int t, cf* k, const cf* __restrict__ g) {
-  constexpr int E = C::E;
-  StaticFor<0, E>::run([&]<int I>() RPSF_AI {
+// ------------------------------------------------------------------------------------------
+// Packed K layout (device memory, per patch) and its streaming through registers
+//   g : 32 "pair words" of 16 bytes per thread, word w of thread t at cf index (w*T + t)*2.
+//       w = S*E + e addresses bins e of slot S.  General slot: (K'_h(p), K'_h(p + (0,N/2))) for p = bin e of
+//       member A - exactly the two factors of pair_op(A_e, B_{E-1-e}).  Special-format slot:
+//       (K'_h(A_e), K'_h(B_e)), and the Nyquist-side factors (K'_h(A_e + (0,N/2)), K'_h(B_e + (0,N/2))) sit in
+//   gs: cf index prefix(S)*2E + (e*spec_t(S) + t)*2, for t < spec_t(S).
+// K is consumed in chunks of C::KCH pair words (8, or 4 for the plans with tiny groups whose other
+// temporaries are larger): 16-byte streaming loads, 1 KiB per wave instruction.
+// ------------------------------------------------------------------------------------------
+template <class C, int CI>
+RPSF_HD void load_k_chunk(int t, cf* k, const cf* __restrict__ g) {
+  StaticFor<0, C::KCH>::run([&]<int I>() RPSF_AI {
 #if defined(RPSF_ABL_NOK)
     k[2 * I] = cf{1.0f + (float)I, 0.5f};
     k[2 * I + 1] = cf{0.25f, (float)t};
 #else
-    load_stream16(g + ((size_t)(S * E + I) * C::T + t) * 2, k[2 * I], k[2 * I + 1]);  // one 16-byte load per lane
+    load_stream16(g + ((size_t)(CI * C::KCH + I) * C::T + t) * 2, k[2 * I], k[2 * I + 1]);
 #endif
   });
 }
-
-template <class C, int S>
-RPSF_HD void pointwise_slot(int t, const GroupIds<C>& gids, cf* v, const cf* k, const cf* __restrict__ gs,
-                            const cf* __restrict__ tw) {
-  constexpr int E = C::E;
-  constexpr int ST = C::spec_t(S);
-  cf* za = v + (2 * S) * E;
-  cf* zb = za + E;
-  bool special = false;
-  if constexpr (ST > 0) special = (t & ~(C::WAVE - 1)) < ST;  // uniform over a 64-thread team
-  if (!special) {
-    int qa, ma;
-    gid_to_qm<C>(gids[2 * S], qa, ma);
-    cf w = tw[ma];
-    StaticFor<0, E>::run([&]<int EE>() RPSF_AI {
-      PairOut r = pair_op(za[EE], zb[E - 1 - EE], k[EE], k[E + (E - 1 - EE)], w);
-      za[EE] = r.a;
-      zb[E - 1 - EE] = r.b;
-    });
-  } else if constexpr (ST > 0) {
-    int ga = gids[2 * S], gb = gids[2 * S + 1];
-    bool self = partner_gid<C>(ga) == ga;
-    int qa, ma, qb, mb;
-    gid_to_qm<C>(ga, qa, ma);
-    gid_to_qm<C>(gb, qb, mb);
-    bool qza = qa == 0, qzb = qb == 0;
-    cf wa = tw[ma], wb = tw[mb];
-    const cf* gsp = gs + (size_t)C::spec_prefix(S) * 2 * E + t;
-    cf ks[2 * E];  // all Nyquist-side values first: one latency, not 2E of them
-    StaticFor<0, 2 * E>::run([&]<int I>() RPSF_AI { ks[I] = gsp[(size_t)I * ST]; });
-    cf na[E], nb[E];
-    StaticFor<0, E>::run([&]<int EE>() RPSF_AI {
-      constexpr int R = E - 1 - EE, Z = (E - EE) % E;
-      cf az = za[Z], ar = za[R], bz = zb[Z], br = zb[R];
-      cf pa = sel(self, sel(qza, az, ar), sel(qza, bz, br));
-      cf pb = sel(self, sel(qzb, bz, br), sel(qzb, az, ar));
-      na[EE] = pair_op(za[EE], pa, k[EE], ks[EE], wa).a;
-      nb[EE] = pair_op(zb[EE], pb, k[E + EE], ks[E + EE], wb).a;
-    });
-    StaticFor<0, E>::run([&]<int EE>() RPSF_AI { za[EE] = na[EE]; zb[EE] = nb[EE]; });
-  }
-}
-
-// K layout in device memory, per patch:
-//   g  [i][t][2]            i < 32          -> registers rho = 2i, 2i+1 of thread t      (cf units)
-//   gs [prefix(s)*2E + r*spec_t(s) + t]     r < 2E, slot s, t < spec_t(s)
-// K is streamed through a ring of KDEPTH slot buffers in registers.  The caller fills the ring
-// (slots 0..KDEPTH-1) BEFORE the exchange into the last layout, so those loads are in flight during
-// the exchange's barriers; each slot's buffer is refilled with slot S+KDEPTH as soon as it is consumed.
 template <class C>
 struct KRing {
-    // ring registers are capped at 32 per thread: 128 data registers + butterfly temporaries leave no more
-  // (a second 32-register slot buffer at N = 256 spilled 216 B per lane)
-  static constexpr int WANT = 4 / C::E < 1 ? 1 : 4 / C::E;  // <= 16 registers of K in flight for small E
-  static constexpr int DEPTH = C::NSLOT < WANT ? C::NSLOT : WANT;
-  cf k[DEPTH][2 * C::E];
+  cf k[2 * C::KCH];  // one chunk in flight: 128 data registers + butterfly temporaries leave no room for two
 };
 template <class C>
 RPSF_HD void kring_fill(int t, KRing<C>& r, const cf* __restrict__ g) {
-  StaticFor<0, KRing<C>::DEPTH>::run([&]<int S>() RPSF_AI { load_slot_k<C, S>(t, r.k[S], g); });
+  load_k_chunk<C, 0>(t, r.k, g);
 }
+
+// Special slot, three-stage plans (E <= 8): whole slot at once, partners picked with selects.
+// k = the slot's E pair words (Ka(A_e), Ka(B_e)).
+template <class C, int S>
+RPSF_HD void special_slot_regs(int t, const GroupIds<C>& gids, cf* v, const cf* k, const cf* __restrict__ gs,
+                               const cf* __restrict__ tw) {
+  constexpr int E = C::E, EA = C::EA, EB = C::EB, ST = C::spec_t(S);
+  cf* za = v + (2 * S) * E;
+  cf* zb = za + E;
+  const int ga = gids[2 * S], gb = gids[2 * S + 1];
+  const bool self = partner_gid<C>(ga) == ga;
+  int qa, ma, qb, mb;
+  gid_to_qm<C>(ga, qa, ma);
+  gid_to_qm<C>(gb, qb, mb);
+  const bool qza = qa == 0, qzb = qb == 0, mza = ma == 0, mzb = mb == 0;
+  const cf* gsp = gs + (size_t)C::spec_prefix(S) * 2 * E + (size_t)t * 2;
+  cf ks[2 * E];  // all Nyquist-side values first: one latency, not E of them
+  StaticFor<0, E>::run([&]<int I>() RPSF_AI {
+    ks[2 * I] = gsp[(size_t)I * ST * 2];
+    ks[2 * I + 1] = gsp[(size_t)I * ST * 2 + 1];
+  });
+  cf na[E], nb[E];
+  StaticFor<0, E>::run([&]<int EE>() RPSF_AI {
+    // partner bin: each digit is reversed (E-1-e form) unless the group's q (resp. m) is zero, where it is negated
+    constexpr int K3 = EE / EB, L3 = EE % EB;
+    constexpr int RR = (EA - 1 - K3) * EB + (EB - 1 - L3), ZR = ((EA - K3) % EA) * EB + (EB - 1 - L3);
+    constexpr int RZ = (EA - 1 - K3) * EB + (EB - L3) % EB, ZZ = ((EA - K3) % EA) * EB + (EB - L3) % EB;
+    auto pick = [&](const cf* src, bool qz, bool mz) RPSF_AI {
+      cf rr = src[RR], zr = src[ZR], rz = src[RZ], zz = src[ZZ];
+      return sel(mz, sel(qz, zz, rz), sel(qz, zr, rr));
+    };
+    cf pa = sel(self, pick(za, qza, mza), pick(zb, qza, mza));
+    cf pb = sel(self, pick(zb, qzb, mzb), pick(za, qzb, mzb));
+    na[EE] = pair_op(za[EE], pa, k[2 * EE], ks[2 * EE], tw[ma + C::M * L3]).a;
+    nb[EE] = pair_op(zb[EE], pb, k[2 * EE + 1], ks[2 * EE + 1], tw[mb + C::M * L3]).a;
+  });
+  StaticFor<0, E>::run([&]<int EE>() RPSF_AI { za[EE] = na[EE]; zb[EE] = nb[EE]; });
+}
+
+// Special slot, two-stage plans (single-wave workgroups, E up to 32): the slot is parked in thread-private
+// LDS columns (scratch[(h*E + e)*T + t]) and every bin fetches its partner by computed address, so no
+// register temporaries and no 4-way selects are needed.
+template <class C, int S>
+RPSF_HD void special_slot_park(int t, const cf* v, cf* scratch) {
+  constexpr int E = C::E;
+  StaticFor<0, 2 * E>::run([&]<int I>() RPSF_AI { scratch[(size_t)I * C::T + t] = v[(2 * S) * E + I]; });
+}
+template <class C, int S, int EE>
+RPSF_HD void special_pair_parked(int t, const GroupIds<C>& gids, cf* v, cf ka_a, cf ka_b, const cf* __restrict__ gs,
+                                 const cf* __restrict__ tw, const cf* scratch) {
+  constexpr int E = C::E, EA = C::EA, EB = C::EB, ST = C::spec_t(S), K3 = EE / EB, L3 = EE % EB;
+  cf* za = v + (2 * S) * E;
+  cf* zb = za + E;
+  const int ga = gids[2 * S], gb = gids[2 * S + 1];
+  const bool self = partner_gid<C>(ga) == ga;
+  int qa, ma, qb, mb;
+  gid_to_qm<C>(ga, qa, ma);
+  gid_to_qm<C>(gb, qb, mb);
+  auto partner = [&](int q, int m, int own_member) RPSF_AI {  // bin of -p: digit negated if the low part is zero, else reversed
+    const int k3 = q == 0 ? (EA - K3) % EA : EA - 1 - K3;
+    const int l3 = m == 0 ? (EB - L3) % EB : EB - 1 - L3;
+    const int member = self ? own_member : 1 - own_member;
+    return scratch[(size_t)(member * E + k3 * EB + l3) * C::T + t];
+  };
+  const cf* gsp = gs + (size_t)C::spec_prefix(S) * 2 * E + ((size_t)EE * ST + t) * 2;
+  const cf ks_a = gsp[0], ks_b = gsp[1];
+  const cf pa = partner(qa, ma, 0), pb = partner(qb, mb, 1);
+  za[EE] = pair_op(za[EE], pa, ka_a, ks_a, tw[ma + C::M * L3]).a;
+  zb[EE] = pair_op(zb[EE], pb, ka_b, ks_b, tw[mb + C::M * L3]).a;
+}
+
+// The whole frequency step of one thread: 32 pair words in 4 chunks.  r holds chunk 0 (loaded by the caller
+// before the exchange into the last layout); each later chunk is requested as soon as its buffer is free.
+// scratch: thread-private LDS columns for the parked special path (two-stage plans), else unused.
 template <class C>
 RPSF_HD void pointwise(int t, const GroupIds<C>& gids, cf* v, KRing<C>& r, const cf* __restrict__ g,
-                       const cf* __restrict__ gs, const cf* __restrict__ tw) {
-  constexpr int D = KRing<C>::DEPTH;
-  StaticFor<0, C::NSLOT>::run([&]<int S>() RPSF_AI {
-    pointwise_slot<C, S>(t, gids, v, r.k[S % D], gs, tw);
-    if constexpr (S + D < C::NSLOT) load_slot_k<C, S + D>(t, r.k[S % D], g);
+                       const cf* __restrict__ gs, const cf* __restrict__ tw, cf* scratch) {
+  constexpr int E = C::E, EB = C::EB;
+  StaticFor<0, 32 / C::KCH>::run([&]<int CI>() RPSF_AI {
+    StaticFor<0, C::KCH>::run([&]<int I>() RPSF_AI {
+      constexpr int W = CI * C::KCH + I, S = W / E, EE = W % E, ST = C::spec_t(S);
+      cf* za = v + (2 * S) * E;
+      cf* zb = za + E;
+      bool special = false;
+      if constexpr (ST > 0) special = (t & ~(C::WAVE - 1)) < ST;  // uniform over a 64-thread team
+      if (!special) {
+        int qa, ma;
+        gid_to_qm<C>(gids[2 * S], qa, ma);
+        PairOut o = pair_op(za[EE], zb[E - 1 - EE], r.k[2 * I], r.k[2 * I + 1], tw[ma + C::M * (EE % EB)]);
+        za[EE] = o.a;
+        zb[E - 1 - EE] = o.b;
+      } else if constexpr (ST > 0) {
+        if constexpr (C::S3) {
+          static_assert(!C::S3 || C::KCH % C::E == 0, "a slot must not straddle chunks in the register-select path");
+          if constexpr (EE == 0) special_slot_regs<C, S>(t, gids, v, r.k + 2 * I, gs, tw);
+        } else {
+          if constexpr (EE == 0) special_slot_park<C, S>(t, v, scratch);
+          special_pair_parked<C, S, EE>(t, gids, v, r.k[2 * I], r.k[2 * I + 1], gs, tw, scratch);
+        }
+      }
+    });
+    if constexpr (CI + 1 < 32 / C::KCH) load_k_chunk<C, CI + 1>(t, r.k, g);
   });
 }
 
@@ -582,16 +656,15 @@ RPSF_HD bool slot_is_special(int s, int t) {
 }
 template <class C>
 RPSF_HD cf pack_value(const cf* __restrict__ kfull, const uint16_t* __restrict__ tab, int t, int rho, int which) {
-  int s = rho / (2 * C::E), h = (rho / C::E) & 1, e = rho % C::E;
-  int gid = tab[(t * C::NSLOT + s) * 2 + h];
+  // rho = 2*w + b, pair word w = S*E + e;  which = 0: g, 1: gs (special-format slots only)
+  const int w = rho >> 1, b = rho & 1, s = w / C::E, e = w % C::E;
+  const bool special = slot_is_special<C>(s, t);
+  const int member = special ? b : 0;  // general words describe bin e of member A only
   int q, m;
-  gid_to_qm<C>(gid, q, m);
-  int kr = q + C::Q * e, kc = m;
-  if (which == 1) return kh_at<C>(kfull, kr, kc + C::NC);
-  if (slot_is_special<C>(s, t) || h == 0) return kh_at<C>(kfull, kr, kc);
-  // general slot, member B: store K'_h(p_A + (0, N/2)) of the partner bin p_A = -p
-  int kra = (C::N - kr) & (C::N - 1), kca = (C::NC - kc) & (C::NC - 1);
-  return kh_at<C>(kfull, kra, kca + C::NC);
+  gid_to_qm<C>(tab[(t * C::NSLOT + s) * 2 + member], q, m);
+  const int kr = q + C::Q * (e / C::EB), kc = m + C::M * (e % C::EB);
+  const bool nyquist_side = special ? which == 1 : b == 1;
+  return kh_at<C>(kfull, kr, nyquist_side ? kc + C::NC : kc);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -654,7 +727,7 @@ RPSF_HD void load_patch_raw(int t, cf* v, const ImageView& im, int pr, int pc) {
     int r = (R1 << (C::A2 + C::AL)) + tp.r_rest;
     const float* row = base + (size_t)r * im.ld;
     StaticFor<0, NCOL>::run([&]<int C1>() RPSF_AI {
-      int c = (C1 << C::B2) + tp.c_rest;
+      int c = (C1 << (C::B2 + C::BL)) + tp.c_rest;
       v[R1 * NCOL + C1] = *reinterpret_cast<const cf*>(row + 2 * c);
     });
   });
@@ -667,7 +740,7 @@ RPSF_HD void window_patch(int t, cf* v, const float* __restrict__ win) {
   StaticFor<0, NR>::run([&]<int R1>() RPSF_AI {
     float wr = win[(R1 << (C::A2 + C::AL)) + tp.r_rest];
     StaticFor<0, NCOL>::run([&]<int C1>() RPSF_AI {
-      int c = (C1 << C::B2) + tp.c_rest;
+      int c = (C1 << (C::B2 + C::BL)) + tp.c_rest;
       cf w2 = *reinterpret_cast<const cf*>(win + 2 * c);
       v[R1 * NCOL + C1] = v[R1 * NCOL + C1] * (w2 * wr);
     });
@@ -689,7 +762,7 @@ RPSF_HD void load_patch(int t, cf* v, const ImageView& im, int pr, int pc, const
       int yl = maps[r];
       const float* row = im.img + (size_t)(yl < 0 ? 0 : yl) * im.ld;
       StaticFor<0, NCOL>::run([&]<int C1>() RPSF_AI {
-        int c = (C1 << C::B2) + tp.c_rest;
+        int c = (C1 << (C::B2 + C::BL)) + tp.c_rest;
         int xa = maps[C::N + 2 * c], xb = maps[C::N + 2 * c + 1];
         float p0 = row[xa < 0 ? 0 : xa], p1 = row[xb < 0 ? 0 : xb];  // always in bounds; select afterwards
         p0 = (yl < 0 || xa < 0) ? im.pad_value : p0;
@@ -715,7 +788,7 @@ RPSF_HD void store_patch(int t, const cf* v, const OutView& ov, int plane, int p
       float wr = win[r];
       float* row = base + (size_t)r * ov.ld;
       StaticFor<0, NCOL>::run([&]<int C1>() RPSF_AI {
-        int c = (C1 << C::B2) + tp.c_rest;
+        int c = (C1 << (C::B2 + C::BL)) + tp.c_rest;
         cf w2 = *reinterpret_cast<const cf*>(win + 2 * c);
         store_stream8(row + 2 * c, v[R1 * NCOL + C1] * (w2 * wr));
       });
@@ -729,7 +802,7 @@ RPSF_HD void store_patch(int t, const cf* v, const OutView& ov, int plane, int p
     if (y >= 0 && y < ov.H && yl >= 0 && yl < ov.rows) {
       float* row = dst + (size_t)yl * ov.ld;
       StaticFor<0, NCOL>::run([&]<int C1>() RPSF_AI {
-        int c = (C1 << C::B2) + tp.c_rest;
+        int c = (C1 << (C::B2 + C::BL)) + tp.c_rest;
         int x0 = pc + 2 * c;
         cf val = v[R1 * NCOL + C1];
         float a0 = val.x * (wr * win[2 * c]), a1 = val.y * (wr * win[2 * c + 1]);
@@ -760,8 +833,10 @@ RPSF_HD float sum_planes_at(const float* planes, size_t plane_stride, size_t off
 // digits chosen so that the 64 lanes of a wave cover 2 rows x 32 packed columns (2 x 256 B contiguous)
 using Cfg256 = Cfg<8, 4, 1, 3, 2, 5>;
 using Cfg128 = Cfg<7, 5, 1, 1, 1, 5>;
-using Cfg64 = Cfg<6, 1, 0, 5, 5, 0>;
-using Cfg32 = Cfg<5, 2, 0, 3, 4, 0>;
-using Cfg16 = Cfg<4, 3, 0, 1, 3, 0>;
+// two-stage plans: all row bits but one (or none) in stage 1, column bits in the last stage, so that the
+// threads of a patch own consecutive packed columns (the earlier row-only last stage made a wave touch 32-64 rows)
+using Cfg64 = Cfg<6, 5, 0, 1, 1, 0, 4>;  // 32 threads: 2 rows x 16 packed columns (128 B)
+using Cfg32 = Cfg<5, 5, 0, 0, 1, 0, 3>;  // 8 threads: 8 packed columns (64 B) of one row
+using Cfg16 = Cfg<4, 4, 0, 0, 2, 0, 1>;  // 2 threads
 
 }  // namespace rpsf

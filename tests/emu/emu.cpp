@@ -39,12 +39,10 @@ static int emu_apply_t(int n_patches, const int32_t* coords, int H, int W, int p
     for (int t = 0; t < T; ++t)
       for (int rho = 0; rho < 64; ++rho) {
         g[((size_t)(rho / 2) * T + t) * 2 + (rho & 1)] = pack_value<C>(kf, tab.data(), t, rho, 0);
-        int s = rho / (2 * C::E);
-        if (slot_is_special<C>(s, t)) {
-          int r = rho % (2 * C::E);
-          gs[(size_t)C::spec_prefix(s) * 2 * C::E + (size_t)r * C::spec_t(s) + t] =
+        const int w = rho >> 1, b = rho & 1, s = w / C::E, e = w % C::E;
+        if (slot_is_special<C>(s, t))
+          gs[(size_t)C::spec_prefix(s) * 2 * C::E + ((size_t)e * C::spec_t(s) + t) * 2 + b] =
               pack_value<C>(kf, tab.data(), t, rho, 1);
-        }
       }
     int pr = coords[2 * p], pc = coords[2 * p + 1];
     const bool fast = patch_inside<C>(pr, pc, H, W, 0, H) && pairs_aligned(img, W, pc);
@@ -69,7 +67,7 @@ static int emu_apply_t(int n_patches, const int32_t* coords, int H, int W, int p
       KRing<C> kring;
       kring_fill<C>(t, kring, g.data());
       stage_last<C, false>(v);
-      pointwise<C>(t, gids[t], v, kring, g.data(), gs.data(), tw.data());
+      pointwise<C>(t, gids[t], v, kring, g.data(), gs.data(), tw.data(), reinterpret_cast<cf*>(lds.data()));
       stage_last<C, true>(v);
     }
     for (int t = 0; t < T; ++t) x2_last_write<C, 0>(gids[t], &regs[(size_t)t * 64], lds.data());
