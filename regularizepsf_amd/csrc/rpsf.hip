@@ -67,80 +67,94 @@ __device__ __forceinline__ int cover_at(const SumParams& p, int y, int x) {
   return p.cover[ty * p.ntj + tx];
 }
 
+__device__ __forceinline__ bool sum_vector_ok(const SumParams& p) {
+  return ((p.ld_planes | p.ld_out) & 3) == 0 &&
+         ((reinterpret_cast<uintptr_t>(p.planes) | reinterpret_cast<uintptr_t>(p.out) | (p.plane_stride * 4)) & 15) == 0;
+}
+// Branch-free 16-byte read of plane k: a plane without a patch over the tile is never read (its content is
+// stale) - the load is redirected to one always-valid line and its result discarded.  Keeping the loads
+// unconditional matters: a load under a branch is waited for at the join, which serialises the four planes.
+__device__ __forceinline__ float4 load_plane4(const SumParams& p, int k, size_t off, int cov) {
+  const bool on = (cov >> k) & 1;
+  const float* src = on ? p.planes + k * p.plane_stride + off : p.planes;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  f4 a = __builtin_nontemporal_load(reinterpret_cast<const f4*>(src));
+  return make_float4(on ? a.x : 0.f, on ? a.y : 0.f, on ? a.z : 0.f, on ? a.w : 0.f);
+}
+__device__ __forceinline__ void store_out4(float* o, float4 v) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  f4 w = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(w, reinterpret_cast<f4*>(o));
+}
+
 // four consecutive pixels (x .. x+3) of window row yl
-__device__ __forceinline__ void sum_planes_group(const SumParams& p, int yl, int x) {
+__device__ __forceinline__ void sum_planes_group(const SumParams& p, int yl, int x, bool vector_ok) {
   int y = yl + p.row0;
   size_t off = (size_t)yl * p.ld_planes + x;
   float* o = p.out + (size_t)yl * p.ld_out + x;
   int c0 = cover_at(p, y, x), c3 = cover_at(p, y, x + 3);
-  const bool vec = x + 3 < p.W && c0 == c3 && ((p.ld_planes | p.ld_out) & 3) == 0 &&
-                   ((reinterpret_cast<uintptr_t>(p.planes) | reinterpret_cast<uintptr_t>(p.out) | (p.plane_stride * 4)) & 15) == 0;
-  if (vec) {  // one tile, aligned: up to four 16-byte loads, one 16-byte store
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (c0 & (1 << k)) {
-        float4 a = *reinterpret_cast<const float4*>(p.planes + k * p.plane_stride + off);
-        acc.x += a.x, acc.y += a.y, acc.z += a.z, acc.w += a.w;
-      }
-    *reinterpret_cast<float4*>(o) = acc;
+  if (vector_ok && x + 3 < p.W && c0 == c3) {  // one tile, aligned: four 16-byte loads, one 16-byte store
+    float4 a0 = load_plane4(p, 0, off, c0), a1 = load_plane4(p, 1, off, c0), a2 = load_plane4(p, 2, off, c0),
+           a3 = load_plane4(p, 3, off, c0);
+    store_out4(o, make_float4(((a0.x + a1.x) + a2.x) + a3.x, ((a0.y + a1.y) + a2.y) + a3.y,
+                              ((a0.z + a1.z) + a2.z) + a3.z, ((a0.w + a1.w) + a2.w) + a3.w));
   } else {
     for (int i = 0; i < 4 && x + i < p.W; ++i) o[i] = sum_planes_at(p.planes, p.plane_stride, off + i, cover_at(p, y, x + i));
   }
 }
 
 __global__ void sum_planes_kernel(SumParams p) {
-  const int groups = (p.W + 3) >> 2;
+  const unsigned groups = (unsigned)(p.W + 3) >> 2;
   size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)groups * p.rows) return;
-  sum_planes_group(p, (int)(idx / groups) + p.row_begin, (int)(idx % groups) * 4);
+  const bool small = (size_t)groups * p.rows < ((size_t)1 << 32);
+  const int yl = small ? (int)((unsigned)idx / groups) : (int)(idx / groups);
+  const int xg = small ? (int)((unsigned)idx % groups) : (int)(idx % groups);
+  sum_planes_group(p, yl + p.row_begin, xg * 4, sum_vector_ok(p));
 }
 
 // the same work done by `nblocks` co-operating workgroups of a larger launch (grid-stride).  These
 // workgroups are as register-heavy as the patch kernel (one per CU), so each thread keeps eight
-// independent 4-pixel groups in flight to cover the HBM latency.
+// independent 4-pixel groups (32 loads) in flight to cover the HBM latency.
 __device__ __forceinline__ void sum_planes_worker(const SumParams& p, int block, int nblocks) {
-  const int groups = (p.W + 3) >> 2;
+  const unsigned groups = (unsigned)(p.W + 3) >> 2;
   const size_t total = (size_t)groups * p.rows;
   const size_t stride = (size_t)nblocks * blockDim.x;
   size_t idx = (size_t)block * blockDim.x + threadIdx.x;
-  const bool aligned = ((p.ld_planes | p.ld_out) & 3) == 0 && (p.W & 3) == 0 &&
-                       ((reinterpret_cast<uintptr_t>(p.planes) | reinterpret_cast<uintptr_t>(p.out) | (p.plane_stride * 4)) & 15) == 0;
+  const bool vector_ok = sum_vector_ok(p) && (p.W & 3) == 0;
+  const bool small = total < ((size_t)1 << 32);
   constexpr int SU = 8;
-  if (aligned) {
+  if (vector_ok) {
     for (; idx + (SU - 1) * stride < total; idx += SU * stride) {
-      float4 v[SU][4];
       int cov[SU], yl[SU], x[SU];
       bool uniform = true;
 #pragma unroll
       for (int u = 0; u < SU; ++u) {
         size_t i = idx + u * stride;
-        yl[u] = (int)(i / groups) + p.row_begin, x[u] = (int)(i % groups) * 4;
+        yl[u] = (small ? (int)((unsigned)i / groups) : (int)(i / groups)) + p.row_begin;
+        x[u] = (small ? (int)((unsigned)i % groups) : (int)(i % groups)) * 4;
         cov[u] = cover_at(p, yl[u] + p.row0, x[u]);
         uniform = uniform && cov[u] == cover_at(p, yl[u] + p.row0, x[u] + 3);
       }
       if (!uniform) {  // a group straddles two lattice tiles: generic path
 #pragma unroll
-        for (int u = 0; u < SU; ++u) sum_planes_group(p, yl[u], x[u]);
+        for (int u = 0; u < SU; ++u) sum_planes_group(p, yl[u], x[u], true);
         continue;
       }
+      float4 v[SU][4];
 #pragma unroll
       for (int u = 0; u < SU; ++u)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float4* src = reinterpret_cast<const float4*>(p.planes + k * p.plane_stride + (size_t)yl[u] * p.ld_planes + x[u]);
-          v[u][k] = (cov[u] & (1 << k)) ? *src : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int k = 0; k < 4; ++k) v[u][k] = load_plane4(p, k, (size_t)yl[u] * p.ld_planes + x[u], cov[u]);
 #pragma unroll
-      for (int u = 0; u < SU; ++u) {
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) acc.x += v[u][k].x, acc.y += v[u][k].y, acc.z += v[u][k].z, acc.w += v[u][k].w;
-        *reinterpret_cast<float4*>(p.out + (size_t)yl[u] * p.ld_out + x[u]) = acc;
-      }
+      for (int u = 0; u < SU; ++u)
+        store_out4(p.out + (size_t)yl[u] * p.ld_out + x[u],
+                   make_float4(((v[u][0].x + v[u][1].x) + v[u][2].x) + v[u][3].x, ((v[u][0].y + v[u][1].y) + v[u][2].y) + v[u][3].y,
+                               ((v[u][0].z + v[u][1].z) + v[u][2].z) + v[u][3].z, ((v[u][0].w + v[u][1].w) + v[u][2].w) + v[u][3].w));
     }
   }
-  for (; idx < total; idx += stride) sum_planes_group(p, (int)(idx / groups) + p.row_begin, (int)(idx % groups) * 4);
+  for (; idx < total; idx += stride)
+    sum_planes_group(p, (int)(idx / groups) + p.row_begin, (int)(idx % groups) * 4, vector_ok);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -202,6 +216,12 @@ template <class C>
 __global__ __launch_bounds__(Launch<C>::WG, 2) void patch_kernel(PatchParams p) {  // 2 waves per SIMD: 256 registers, no AGPR overflow
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int T = C::T;
+#if defined(RPSF_DBG_TAIL_NOPATCH)
+  if (p.sum.rows > 0 && (int)blockIdx.x < p.patch_blocks) return;
+#endif
+#if defined(RPSF_DBG_TAIL_NOSUM)
+  if ((int)blockIdx.x >= p.patch_blocks) return;
+#endif
   if ((int)blockIdx.x >= p.patch_blocks) {  // workgroup-uniform
     sum_planes_worker(p.sum, blockIdx.x - p.patch_blocks, gridDim.x - p.patch_blocks);
     return;
@@ -311,11 +331,9 @@ __global__ __launch_bounds__(Launch<C>::WG, 2) void patch_kernel(PatchParams p) 
 
   STAMP(5);
   {
-    stage_last<C, false>(v);
     STAMP(6);
-    pointwise<C>(t, gids, v, kring, g, p.gs + (size_t)patch * C::GS_PER_PATCH, tw, reinterpret_cast<cf*>(lds));
     STAMP(7);
-    stage_last<C, true>(v);
+    freq_step<C>(t, gids, v, kring, g, p.gs + (size_t)patch * C::GS_PER_PATCH, tw, reinterpret_cast<cf*>(lds));
     STAMP(8);
   }
 

@@ -190,6 +190,11 @@ struct Cfg {
   static constexpr int P = 64 / E;            // groups per thread in the last layout
   static constexpr int NSLOT = P / 2;         // pair slots per thread
   static constexpr int KCH = E >= 8 ? 8 : 4;   // pair words of K per streaming chunk (2 cf = 4 registers each)
+#if defined(RPSF_NOFUSE)
+  static constexpr bool FUSE_LAST = false;
+#else
+  static constexpr bool FUSE_LAST = KCH % E == 0;  // chunks hold whole slots: last stage runs slot by slot around the multiplication
+#endif
   static constexpr int T = N * NC / 64;       // threads per patch
   static constexpr int LQ = A1_ + A2_, Q = 1 << LQ, M = 1 << (B1_ + B2_), G = Q * M;  // kr = q + Q*k3, kc = m + M*l3
   static constexpr int NSPEC = (Q + M) / 2;   // slots whose groups have q == 0, m == 0 or are self-paired
@@ -409,12 +414,14 @@ RPSF_HD void stage2(int t, cf* v, const cf* __restrict__ tw) {
 }
 
 // Last stage: 2-D DFT over (r3, c3) inside every group (register index rho = group*E + k3*EB + l3).
+template <class C, bool INV, int GI>
+RPSF_HD void stage_last_group(cf* v) {
+  fft_axis<C::AL, C::EB, C::EB, 1, INV, GI * C::E>(v);   // along r3 for every l3
+  fft_axis<C::BL, 1, C::EA, C::EB, INV, GI * C::E>(v);   // along c3 for every k3
+}
 template <class C, bool INV>
 RPSF_HD void stage_last(cf* v) {
-  StaticFor<0, C::P>::run([&]<int GI>() RPSF_AI {
-    fft_axis<C::AL, C::EB, C::EB, 1, INV, GI * C::E>(v);   // along r3 for every l3
-    fft_axis<C::BL, 1, C::EA, C::EB, INV, GI * C::E>(v);   // along c3 for every k3
-  });
+  StaticFor<0, C::P>::run([&]<int GI>() RPSF_AI { stage_last_group<C, INV, GI>(v); });
 }
 
 // ------------------------------------------------------------------------------------------
@@ -611,11 +618,17 @@ RPSF_HD void special_pair_parked(int t, const GroupIds<C>& gids, cf* v, cf ka_a,
 // The whole frequency step of one thread: 32 pair words in 4 chunks.  r holds chunk 0 (loaded by the caller
 // before the exchange into the last layout); each later chunk is requested as soon as its buffer is free.
 // scratch: thread-private LDS columns for the parked special path (two-stage plans), else unused.
-template <class C>
+// FUSE: the last stage is a DFT inside each group, so when chunks hold whole slots it runs slot by slot
+// around the multiplication (forward DFT of the chunk's groups, multiply, request the next chunk, inverse
+// DFT of the same groups): the K round trip of chunk i+1 hides behind the butterflies of chunks i and i+1.
+template <class C, bool FUSE>
 RPSF_HD void pointwise(int t, const GroupIds<C>& gids, cf* v, KRing<C>& r, const cf* __restrict__ g,
                        const cf* __restrict__ gs, const cf* __restrict__ tw, cf* scratch) {
   constexpr int E = C::E, EB = C::EB;
+  constexpr int GPC = FUSE ? 2 * C::KCH / E : 0;  // groups per chunk
+  static_assert(!FUSE || C::KCH % E == 0, "fused last stage needs whole slots per chunk");
   StaticFor<0, 32 / C::KCH>::run([&]<int CI>() RPSF_AI {
+    StaticFor<0, GPC>::run([&]<int J>() RPSF_AI { stage_last_group<C, false, CI * GPC + J>(v); });
     StaticFor<0, C::KCH>::run([&]<int I>() RPSF_AI {
       constexpr int W = CI * C::KCH + I, S = W / E, EE = W % E, ST = C::spec_t(S);
       cf* za = v + (2 * S) * E;
@@ -639,7 +652,20 @@ RPSF_HD void pointwise(int t, const GroupIds<C>& gids, cf* v, KRing<C>& r, const
       }
     });
     if constexpr (CI + 1 < 32 / C::KCH) load_k_chunk<C, CI + 1>(t, r.k, g);
+    StaticFor<0, GPC>::run([&]<int J>() RPSF_AI { stage_last_group<C, true, CI * GPC + J>(v); });
   });
+}
+// Last stage forward, multiplication by K, last stage inverse.
+template <class C>
+RPSF_HD void freq_step(int t, const GroupIds<C>& gids, cf* v, KRing<C>& r, const cf* __restrict__ g,
+                       const cf* __restrict__ gs, const cf* __restrict__ tw, cf* scratch) {
+  if constexpr (C::FUSE_LAST) {
+    pointwise<C, true>(t, gids, v, r, g, gs, tw, scratch);
+  } else {
+    stage_last<C, false>(v);
+    pointwise<C, false>(t, gids, v, r, g, gs, tw, scratch);
+    stage_last<C, true>(v);
+  }
 }
 
 // Value of the packed K arrays at (thread t, register rho).  kfull = one patch of the caller's
