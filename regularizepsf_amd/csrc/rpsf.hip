@@ -216,12 +216,6 @@ template <class C>
 __global__ __launch_bounds__(Launch<C>::WG, 2) void patch_kernel(PatchParams p) {  // 2 waves per SIMD: 256 registers, no AGPR overflow
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int T = C::T;
-#if defined(RPSF_DBG_TAIL_NOPATCH)
-  if (p.sum.rows > 0 && (int)blockIdx.x < p.patch_blocks) return;
-#endif
-#if defined(RPSF_DBG_TAIL_NOSUM)
-  if ((int)blockIdx.x >= p.patch_blocks) return;
-#endif
   if ((int)blockIdx.x >= p.patch_blocks) {  // workgroup-uniform
     sum_planes_worker(p.sum, blockIdx.x - p.patch_blocks, gridDim.x - p.patch_blocks);
     return;
