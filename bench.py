@@ -33,6 +33,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X spec peak, /opt/skills/guides/MI355X_MICROARCH.m
 CONFIGS = {  # name -> (height, width, patch, starfield seed)
     2: (2048, 2048, 128, 2),
     3: (4096, 4096, 256, 3),
+    5: (2048, 2048, 128, 100),  # batch of frames sharing config 2's transfer kernel (BASELINE.json configs[4])
 }
 
 
@@ -122,6 +123,98 @@ class GlooSeam:
         pass
 
 
+def run_batch(args, rank, world, device, comm):
+    """Config 5: every rank corrects its own `--frames` frames of 2048^2 with the shared 128-px transfer kernel
+    (replicas: no data-path collective; weak scaling - 8 frames per GPU is BASELINE's 64 frames on 8 GPUs)."""
+    from oracle import regpsf_oracle as orc
+    from regularizepsf_amd import _native
+
+    h, w, n, seed = CONFIGS[5]
+    frames = args.frames
+    coords = [tuple(int(v) for v in t) for t in orc.calculate_covering((h, w), n)]
+    src = np.stack([orc.coma_psf(n, r, c, h, w) for r, c in coords])
+    tgt = orc.psf_fft(orc.gaussian_psf(n, 1.8))[None]
+    s_fft = orc.psf_fft(src, workers=-1)
+    k = orc.construct_transfer(s_fft, np.broadcast_to(tgt, s_fft.shape), 3.0, 0.1).astype(np.complex64)
+    if not np.isfinite(k).all():
+        raise ValueError("synthetic transfer kernel is not finite")
+    images = np.stack([orc.starfield(h, w, seed + rank * frames + i) for i in range(frames)])
+    plan = _native.Plan(n, coords, device)
+    plan.set_transfer(k)
+    d_in = _native.DeviceBuffer(images.nbytes, device).upload(images)
+    d_out = _native.DeviceBuffer(images.nbytes, device)
+    geom = _native.Geometry.whole(h, w, _native.PAD_MODES["symmetric"])
+    stride = h * w
+
+    def run_step():
+        plan.apply_batch_device(d_in.ptr, d_out.ptr, frames, stride, stride, geom)
+
+    def barrier():
+        plan.synchronize()
+        if comm is not None:
+            comm.barrier()
+            plan.synchronize()
+
+    for _ in range(args.warmup):
+        run_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if comm is not None:
+        elapsed = comm.allreduce_max(elapsed)
+    ms_per_step = 1e3 * elapsed / args.steps
+    iters = max(10, min(args.steps, 100))
+    total_ms, kernel_ms = plan.apply_batch_device_timed(d_in.ptr, d_out.ptr, frames, stride, stride, geom, iters)
+    kern_avg_ms = float(np.mean(kernel_ms))
+    alg_bytes = plan.transfer_bytes + frames * 2 * h * w * 4  # K once per batch + every frame read and written once
+    achieved = alg_bytes / (kern_avg_ms * 1e-3) / 1e9
+    if args.verify:
+        out = d_out.download((frames, h, w)).astype(np.float64)
+        for f in (0, frames - 1):
+            ref = orc.apply_transfer(images[f], coords, k, workers=-1)
+            err = float(np.abs(out[f] - ref).max() / np.abs(ref).max())
+            print(f"[verify] rank {rank} frame {f}: max|d|/max|ref| = {err:.3e}", file=sys.stderr, flush=True)
+            if err > 1e-5:
+                raise SystemExit(f"verification failed on rank {rank}")
+    if comm is not None:
+        import torch.distributed as dist
+
+        barrier()
+        comm.close()
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank != 0:
+        return
+    value = world * frames * h * w / (ms_per_step * 1e-3) / 1e6
+    cus, name = _native.device_info(device)
+    line = {
+        "metric": "corrected Mpixels/sec + fraction of HBM roofline, batch of 2048^2 frames / 128-patch, shared transfer array",
+        "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": f"{frames} frames per GPU of {h}x{w} starfields, {n}x{n} patches ({len(coords)} per frame), one "
+                        f"transfer kernel shared by the batch (coma PSF grid -> Gaussian target, alpha=3 eps=0.1), "
+                        f"{'one GPU' if world == 1 else f'{world} replicas, no data-path collective'}",
+            "image": [h, w], "patch": n, "patches": len(coords), "frames_per_gpu": frames, "device": name,
+            "compute_units": cus, "resident": "frames, outputs and packed transfer kernel in HBM before the timed region",
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "patch_kernel",
+            "kernel_avg_ms": round(kern_avg_ms, 4), "kernel_launches": iters, "algorithmic_bytes": int(alg_bytes),
+            "bytes_model": "packed folded K read once per batch + every frame read once + every output written once",
+            "apply_avg_ms_events": round(float(np.mean(total_ms)), 4),
+        },
+    }
+    if not args.no_cpu and world == 1:
+        line["cpu_baseline"] = cpu_baseline(images[0], coords, k)
+    print(json.dumps(line), flush=True)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -133,6 +226,7 @@ def main() -> None:
                     help="seam transport for N > 1; 'gloo' is a debug stand-in (host copies) used to exercise the "
                          "multi-rank flow on a box with fewer GPUs than ranks")
     ap.add_argument("--verify", action="store_true", help="check every rank's owned rows against the CPU oracle")
+    ap.add_argument("--frames", type=int, default=8, help="config 5: frames per GPU in one batch")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -194,6 +288,8 @@ def main() -> None:
             comm = _native.Comm(device, rank, world, bytes(box[0]))
         else:
             comm = GlooSeam(rank, world, device)
+    if args.config == 5:
+        return run_batch(args, rank, world, device, comm)
     shard = ShardedApply(coords, kernel_for, n, height, w, rank, world, device, comm, pad_mode=pad)
     band = shard.band
     band_image = image_rows(band.image_row0, band.image_row0 + band.image_rows)

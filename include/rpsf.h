@@ -101,6 +101,23 @@ int rpsf_apply_device(rpsf_plan* plan, const void* image_dev, void* out_dev, con
  * kernel alone.  Either array may be NULL. */
 int rpsf_apply_device_timed(rpsf_plan* plan, const void* image_dev, void* out_dev, const rpsf_geometry* geom,
                             int iters, float* total_ms, float* kernel_ms);
+/* A batch of n_frames frames of identical geometry corrected with the plan's (shared) transfer kernel -
+ * what a caller of the reference does with a Python loop over ArrayPSFTransform.apply
+ * (transform.py:85-177) on a stack of exposures.  The frames of one patch are scheduled next to each other so
+ * the packed transfer kernel is read from HBM once per batch, not once per frame.
+ * Host variant: images_host / outs_host are (n_frames, height, width) float32, C-contiguous; copies in and
+ * out overlap the computation. */
+int rpsf_apply_batch(rpsf_plan* plan, const float* images_host, int n_frames, int height, int width, int pad_mode,
+                     float pad_value, float* outs_host);
+/* Device variant: frame f is at images_dev + f * image_stride and outs_dev + f * out_stride (strides in
+ * floats); asynchronous on `stream` (NULL: the plan's own).  The plan keeps 16 bytes of scratch per output
+ * pixel per frame in flight (large batches are cut into groups internally). */
+int rpsf_apply_batch_device(rpsf_plan* plan, const void* images_dev, void* outs_dev, int n_frames, size_t image_stride,
+                            size_t out_stride, const rpsf_geometry* geom, void* stream);
+/* Timed variant, like rpsf_apply_device_timed: total_ms[i] covers the whole batch, kernel_ms[i] its patch kernel. */
+int rpsf_apply_batch_device_timed(rpsf_plan* plan, const void* images_dev, void* outs_dev, int n_frames,
+                                  size_t image_stride, size_t out_stride, const rpsf_geometry* geom, int iters,
+                                  float* total_ms, float* kernel_ms);
 /* The plan's own stream (hipStream_t), for callers that enqueue follow-up work such as the seam exchange. */
 void* rpsf_plan_stream(rpsf_plan* plan);
 

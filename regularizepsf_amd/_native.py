@@ -62,6 +62,11 @@ _PROTOTYPES = {
     "rpsf_apply": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "rpsf_apply_device": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(Geometry), c_void_p]),
     "rpsf_apply_device_timed": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(Geometry), c_int, c_void_p, c_void_p]),
+    "rpsf_apply_batch": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "rpsf_apply_batch_device": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_size_t, POINTER(Geometry),
+                                        c_void_p]),
+    "rpsf_apply_batch_device_timed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_size_t,
+                                              POINTER(Geometry), c_int, c_void_p, c_void_p]),
     "rpsf_plan_stream": (c_void_p, [c_void_p]),
     "rpsf_build_transfer": (c_int, [c_int, c_size_t, c_void_p, c_void_p, c_int, c_double, c_double, c_void_p]),
     "rpsf_build_transfer_device": (c_int, [c_int, c_size_t, c_void_p, c_void_p, c_int, c_double, c_double, c_void_p,
@@ -219,6 +224,31 @@ class Plan:
         kern = np.zeros(iters, np.float32)
         check(lib().rpsf_apply_device_timed(self._handle, image_ptr, out_ptr, ctypes.byref(geometry), iters,
                                             _ptr(total), _ptr(kern)))
+        return total, kern
+
+    def apply_batch(self, images: np.ndarray, pad_mode: int, pad_value: float = 0.0) -> np.ndarray:
+        """(frames, H, W) host stack in, float32 stack out; the frames share the installed transfer kernel."""
+        imgs = np.ascontiguousarray(images, dtype=np.float32)
+        if imgs.ndim != 3:
+            msg = "images must have shape (frames, H, W)"
+            raise ValueError(msg)
+        out = np.empty_like(imgs)
+        if imgs.shape[0]:
+            check(lib().rpsf_apply_batch(self._handle, _ptr(imgs), imgs.shape[0], imgs.shape[1], imgs.shape[2], pad_mode,
+                                         pad_value, _ptr(out)))
+        return out
+
+    def apply_batch_device(self, images_ptr: c_void_p, outs_ptr: c_void_p, n_frames: int, image_stride: int,
+                           out_stride: int, geometry: Geometry, stream: c_void_p | None = None) -> None:
+        check(lib().rpsf_apply_batch_device(self._handle, images_ptr, outs_ptr, n_frames, image_stride, out_stride,
+                                            ctypes.byref(geometry), stream))
+
+    def apply_batch_device_timed(self, images_ptr: c_void_p, outs_ptr: c_void_p, n_frames: int, image_stride: int,
+                                 out_stride: int, geometry: Geometry, iters: int):
+        total = np.zeros(iters, np.float32)
+        kern = np.zeros(iters, np.float32)
+        check(lib().rpsf_apply_batch_device_timed(self._handle, images_ptr, outs_ptr, n_frames, image_stride, out_stride,
+                                                  ctypes.byref(geometry), iters, _ptr(total), _ptr(kern)))
         return total, kern
 
     def synchronize(self) -> None:

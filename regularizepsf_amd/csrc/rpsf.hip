@@ -59,6 +59,7 @@ struct SumParams {
   int half_shift;      // log2(N/2)
   int nti, ntj;
   const uint8_t* cover;  // nti x ntj, 4-bit class masks
+  size_t planes_frame_floats, out_frame_floats;  // batch: frame f (= blockIdx.y) at planes + f*..., out + f*...
 };
 
 __device__ __forceinline__ int cover_at(const SumParams& p, int y, int x) {
@@ -104,6 +105,8 @@ __device__ __forceinline__ void sum_planes_group(const SumParams& p, int yl, int
 }
 
 __global__ void sum_planes_kernel(SumParams p) {
+  p.planes += (size_t)blockIdx.y * p.planes_frame_floats;
+  p.out += (size_t)blockIdx.y * p.out_frame_floats;
   const unsigned groups = (unsigned)(p.W + 3) >> 2;
   size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)groups * p.rows) return;
@@ -174,6 +177,9 @@ struct PatchParams {
   int stagger_ticks;        // start-up stagger of the first resident workgroups, in 10 ns ticks (0 = off)
   int stagger_blocks;       // how many leading blocks are staggered (= resident workgroup capacity)
   int n_patches;
+  int n_frames;             // batch: every patch slot is processed for n_frames frames that share the transfer kernel
+  size_t im_frame_floats;   // frame f reads im.img + f * im_frame_floats ...
+  size_t ov_frame_floats;   // ... and writes ov.out + f * ov_frame_floats
   const uint16_t* tab;
   const cf* tw;
   const float* win;
@@ -224,7 +230,18 @@ __global__ __launch_bounds__(Launch<C>::WG, 2) void patch_kernel(PatchParams p) 
   // Blocks are dealt round-robin over the 8 XCDs (b and b+8 share one).  `order` lists the patches
   // along a Z-order curve of the lattice, cut into 8 contiguous chunks: XCD x works through chunk x,
   // so the four patches that overlap a pixel usually read it through the same L2.  Speed only.
-  const int slot = (blockIdx.x >> 3) * Launch<C>::TEAMS + team;
+  // Batch: the n_frames workgroups of one patch slot are consecutive on their XCD, so the slot's packed
+  // K comes from HBM once and from that XCD's L2 for the other frames.
+  int frame = 0, xrow = blockIdx.x >> 3;
+  if (p.n_frames > 1) {
+    frame = xrow % p.n_frames;
+    xrow /= p.n_frames;
+  }
+  ImageView im = p.im;
+  OutView ov = p.ov;
+  im.img += (size_t)frame * p.im_frame_floats;
+  ov.out += (size_t)frame * p.ov_frame_floats;
+  const int slot = xrow * Launch<C>::TEAMS + team;
   const int seq = (blockIdx.x & 7) * p.chunk + slot;
   const bool active = slot < p.chunk && seq < p.n_patches;
   const int4 dsc = p.desc[p.seq_base + (active ? seq : p.n_patches - 1)];  // inactive teams stay in step with the barriers
@@ -247,7 +264,7 @@ __global__ __launch_bounds__(Launch<C>::WG, 2) void patch_kernel(PatchParams p) 
 #pragma unroll
   for (int j = 0; j < 64; ++j) v[j] = cf{(float)(t + j), (float)(t - j)};
 #endif
-  const bool fast = patch_inside<C>(pr, pc, p.im.H, p.im.W, p.im.row0, p.im.rows) && pairs_aligned(p.im.img, p.im.ld, pc);
+  const bool fast = patch_inside<C>(pr, pc, im.H, im.W, im.row0, im.rows) && pairs_aligned(im.img, im.ld, pc);
   // twiddle and window tables live in LDS: their reads must not queue behind the patch's global loads
   cf* tw = reinterpret_cast<cf*>(smem);
   float* win = smem + 2 * C::N;
@@ -270,11 +287,11 @@ __global__ __launch_bounds__(Launch<C>::WG, 2) void patch_kernel(PatchParams p) 
 #if !defined(RPSF_ABL_NOLOAD)
   {
     int* maps = reinterpret_cast<int*>(lds);
-    if (!fast) build_pad_maps<C>(t, maps, p.im, pr, pc);
+    if (!fast) build_pad_maps<C>(t, maps, im, pr, pc);
     lds_barrier();
     // (VMEM returns in order: issuing these loads before the table staging above would make the tables
     //  wait for all 64 of them and lose the load -> stage-1 overlap; measured 9.0 -> 12.8 us)
-    load_patch<C>(t, v, p.im, pr, pc, win, fast, maps);
+    load_patch<C>(t, v, im, pr, pc, win, fast, maps);
     lds_barrier();  // the maps share LDS with the exchange buffer
   }
 #endif
@@ -355,18 +372,18 @@ __global__ __launch_bounds__(Launch<C>::WG, 2) void patch_kernel(PatchParams p) 
   stage1<C, true>(t, v, tw);
   STAMP(12);
   if (active) {
-    const int plane = p.ov.plane_stride ? dsc.w : 0;
+    const int plane = ov.plane_stride ? dsc.w : 0;
 #if defined(RPSF_ABL_NOSTORE)
     {  // keep every value live but store (almost) nothing
       float acc = 0.f;
 #pragma unroll
       for (int j = 0; j < 64; ++j) acc += v[j].x * v[j].y;
-      if (acc == 123456.789f) p.ov.out[threadIdx.x] = acc;
+      if (acc == 123456.789f) ov.out[threadIdx.x] = acc;
     }
 #elif defined(RPSF_ABL_NOATOMIC)
-    store_patch<C>(t, v, p.ov, plane, pr, pc, win, [](float* a, float val) { *a = val; });
+    store_patch<C>(t, v, ov, plane, pr, pc, win, [](float* a, float val) { *a = val; });
 #else
-    store_patch<C>(t, v, p.ov, plane, pr, pc, win, [](float* a, float val) { unsafeAtomicAdd(a, val); });
+    store_patch<C>(t, v, ov, plane, pr, pc, win, [](float* a, float val) { unsafeAtomicAdd(a, val); });
 #endif
   }
 #if defined(RPSF_ABL_NOXCHG)
@@ -585,8 +602,15 @@ struct rpsf_plan {
   int4* d_desc = nullptr;
   std::vector<int32_t> h_order;
   unsigned long long* d_stamps = nullptr;
+  // batch entry point with host pointers: double-buffered device staging and two copy streams
+  float* d_batch_in = nullptr;
+  float* d_batch_out = nullptr;
+  size_t batch_bytes = 0;
+  hipStream_t copy_in = nullptr, copy_out = nullptr;
+  hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
   float* d_planes = nullptr;
   size_t planes_floats = 0;  // per plane
+  size_t planes_frames = 0;  // frames the allocation holds (4 planes each)
 };
 
 static uint64_t morton2(uint32_t a, uint32_t b) {
@@ -823,8 +847,15 @@ extern "C" void rpsf_plan_destroy(rpsf_plan* p) {
   (void)hipFree(p->d_desc);
   (void)hipFree(p->d_stamps);
   (void)hipFree(p->d_planes);
+  (void)hipFree(p->d_batch_in);
+  (void)hipFree(p->d_batch_out);
   for (auto& e : p->ev)
     if (e) (void)hipEventDestroy(e);
+  for (auto* arr : {p->ev_in, p->ev_done, p->ev_out})
+    for (int i = 0; i < 2; ++i)
+      if (arr[i]) (void)hipEventDestroy(arr[i]);
+  if (p->copy_in) (void)hipStreamDestroy(p->copy_in);
+  if (p->copy_out) (void)hipStreamDestroy(p->copy_out);
   if (p->stream) (void)hipStreamDestroy(p->stream);
   if (p->stream2) (void)hipStreamDestroy(p->stream2);
   if (p->ev_main) (void)hipEventDestroy(p->ev_main);
@@ -913,12 +944,19 @@ static SumParams make_sum_params(const rpsf_plan* p, float* d_out, const rpsf_ge
   sp.half_shift = 0;
   while ((1 << (sp.half_shift + 1)) < p->N) ++sp.half_shift;
   sp.nti = p->nti, sp.ntj = p->ntj, sp.cover = p->d_cover;
+  sp.planes_frame_floats = 4 * p->planes_floats, sp.out_frame_floats = 0;
   return sp;
 }
 
+// A batch of frames that share the plan's transfer kernel: frame f at image + f*im_stride, out + f*out_stride (floats)
+struct Batch {
+  int frames = 1;
+  size_t im_stride = 0, out_stride = 0;
+};
+
 // sum_rows > 0: append workgroups that sum colour-plane rows [0, sum_rows) (tail launch only)
 static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const rpsf_geometry& g, bool planes,
-                          int seq_base, int count, hipStream_t st, int sum_rows = 0) {
+                          int seq_base, int count, hipStream_t st, int sum_rows = 0, Batch b = Batch()) {
   return dispatch_n(p->N, [&]<class C>() -> int {
     PatchParams pp;
     pp.im = ImageView{d_img, g.height, g.width, g.ld_image, g.pad_mode, g.pad_value, g.image_row0, g.image_rows};
@@ -934,7 +972,11 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
     pp.chunk = ((count + 7) / 8 + TEAMS - 1) / TEAMS * TEAMS;  // patches per XCD, whole workgroups
     pp.stagger_ticks = p->stagger_us * 100;
     pp.stagger_blocks = p->cu_count * std::max(1, 512 / Launch<C>::WG);
-    unsigned grid = (unsigned)(8 * (pp.chunk / TEAMS));
+    pp.n_frames = b.frames, pp.im_frame_floats = b.im_stride;
+    pp.ov_frame_floats = planes ? 4 * p->planes_floats : b.out_stride;
+    const size_t blocks = (size_t)8 * (pp.chunk / TEAMS) * b.frames;
+    if (blocks > 0x7fffffffu) return fail(RPSF_E_BADARG, "batch too large for one launch");
+    unsigned grid = (unsigned)blocks;
     pp.patch_blocks = (int)grid;
     pp.sum = make_sum_params(p, d_out, g, 0, sum_rows);
     if (sum_rows > 0) grid += (unsigned)std::max(8, p->round_capacity / TEAMS - (int)grid);  // one per CU left idle by the tail
@@ -944,44 +986,55 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
   });
 }
 
-static int launch_sum(rpsf_plan* p, float* d_out, const rpsf_geometry& g, int row_begin, int row_end, hipStream_t st) {
+static int launch_sum(rpsf_plan* p, float* d_out, const rpsf_geometry& g, int row_begin, int row_end, hipStream_t st,
+                      Batch b = Batch()) {
   if (row_end <= row_begin) return RPSF_OK;
   SumParams sp = make_sum_params(p, d_out, g, row_begin, row_end);
+  sp.out_frame_floats = b.out_stride;
   size_t total = (size_t)((g.width + 3) / 4) * sp.rows;
-  sum_planes_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(sp);
+  for (int f0 = 0; f0 < b.frames; f0 += 65535) {  // grid.y limit
+    SumParams q = sp;
+    q.planes += (size_t)f0 * q.planes_frame_floats, q.out += (size_t)f0 * q.out_frame_floats;
+      sum_planes_kernel<<<dim3((unsigned)((total + 255) / 256), (unsigned)std::min(65535, b.frames - f0)), dim3(256), 0, st>>>(q);
+  }
   HIP_TRY(hipGetLastError());
   return RPSF_OK;
 }
 
 // One apply.  ev_k0 / ev_k1 (optional) bracket the patch-kernel launches for timing.
+static bool use_planes(const rpsf_plan* p) { return p->overlap_mode == 2 || (p->overlap_mode == 0 && p->lattice); }
+static size_t plane_floats_needed(const rpsf_geometry& g) { return ((size_t)g.out_rows * g.width + 3) & ~(size_t)3; }
+
 static int launch_apply(rpsf_plan* p, const float* d_img, float* d_out, const rpsf_geometry& g, hipStream_t st,
-                        hipEvent_t ev_k0, hipEvent_t ev_k1 = nullptr) {
-  const bool planes = p->overlap_mode == 2 || (p->overlap_mode == 0 && p->lattice);
+                        hipEvent_t ev_k0, hipEvent_t ev_k1 = nullptr, Batch b = Batch()) {
+  const bool planes = use_planes(p);
   if (planes && !p->lattice) return fail(RPSF_E_STATE, "colour planes need a regular half-overlap lattice of patch corners");
   if (planes) {
-    size_t need = (size_t)g.out_rows * g.width;
-    need = (need + 3) & ~(size_t)3;
-    if (need > p->planes_floats) {
+    const size_t need = plane_floats_needed(g);
+    if (need > p->planes_floats || (size_t)b.frames > p->planes_frames) {  // four planes per frame in flight
+      const size_t per = std::max(need, p->planes_floats), frames = std::max((size_t)b.frames, p->planes_frames);
       HIP_TRY(hipStreamSynchronize(st));
       (void)hipFree(p->d_planes);
-      p->d_planes = nullptr, p->planes_floats = 0;
-      HIP_TRY(hipMalloc(&p->d_planes, 4 * need * sizeof(float)));
-      p->planes_floats = need;
+      p->d_planes = nullptr, p->planes_floats = 0, p->planes_frames = 0;
+      HIP_TRY(hipMalloc(&p->d_planes, 4 * per * frames * sizeof(float)));
+      p->planes_floats = per, p->planes_frames = frames;
     }
   } else {
-    HIP_TRY(hipMemset2DAsync(d_out, (size_t)g.ld_out * sizeof(float), 0, (size_t)g.width * sizeof(float), g.out_rows, st));
+    for (int f = 0; f < b.frames; ++f)
+      HIP_TRY(hipMemset2DAsync(d_out + (size_t)f * b.out_stride, (size_t)g.ld_out * sizeof(float), 0,
+                               (size_t)g.width * sizeof(float), g.out_rows, st));
   }
   if (ev_k0) HIP_TRY(hipEventRecord(ev_k0, st));
   const int n = p->n_patches;
   // window row (relative to out_row0) from which the tail patches contribute
   int split_row = p->n_tail > 0 ? std::min(std::max(p->tail_row + g.origin_row - g.out_row0, 0), g.out_rows) : g.out_rows;
-  const bool split = planes && p->n_tail > 0 && split_row > 0 && split_row < g.out_rows;
+  const bool split = planes && b.frames == 1 && p->n_tail > 0 && split_row > 0 && split_row < g.out_rows;
   int rc;
   if (!split) {
-    rc = launch_patches(p, d_img, d_out, g, planes, 0, n, st);
+    rc = launch_patches(p, d_img, d_out, g, planes, 0, n, st, 0, b);
     if (rc != RPSF_OK) return rc;
     if (ev_k1) HIP_TRY(hipEventRecord(ev_k1, st));
-    if (planes) rc = launch_sum(p, d_out, g, 0, g.out_rows, st);
+    if (planes) rc = launch_sum(p, d_out, g, 0, g.out_rows, st, b);
     return rc;
   }
   // main rounds; then ONE launch whose first workgroups are the tail patches (dispatched first, onto empty
@@ -1055,6 +1108,146 @@ extern "C" int rpsf_apply(rpsf_plan* p, const float* image_host, int height, int
   HIP_TRY(hipMemcpyAsync(out_host, p->d_out, bytes, hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
   return RPSF_OK;
+}
+
+// Frames per launch group: the colour planes take 16 bytes per output pixel per frame in flight; keep
+// them under a quarter of the device memory.
+static int batch_group_frames(const rpsf_plan* p, const rpsf_geometry& g, int n_frames) {
+  if (!use_planes(p)) return n_frames;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) total_b = (size_t)64 << 30;
+  const size_t per_frame = 16 * plane_floats_needed(g);
+  return (int)std::max<size_t>(1, std::min<size_t>((size_t)n_frames, (total_b / 4) / per_frame));
+}
+
+static int check_batch(rpsf_plan* p, const void* a, const void* b, int n_frames, size_t im_stride, size_t out_stride,
+                       const rpsf_geometry* geom) {
+  if (!p || !a || !b) return fail(RPSF_E_BADARG, "null argument");
+  if (n_frames <= 0) return fail(RPSF_E_BADARG, "n_frames must be positive");
+  if (!p->have_k) return fail(RPSF_E_STATE, "no transfer kernel installed (call rpsf_plan_set_transfer first)");
+  int rc = check_geometry(p, geom);
+  if (rc != RPSF_OK) return rc;
+  if (n_frames > 1 && (im_stride < (size_t)(geom->image_rows - 1) * geom->ld_image + geom->width ||
+                       out_stride < (size_t)(geom->out_rows - 1) * geom->ld_out + geom->width))
+    return fail(RPSF_E_BADARG, "frame stride smaller than one frame");
+  return RPSF_OK;
+}
+
+static int launch_batch(rpsf_plan* p, const float* d_imgs, float* d_outs, int n_frames, size_t im_stride, size_t out_stride,
+                        const rpsf_geometry& g, hipStream_t st, hipEvent_t ev_k0 = nullptr, hipEvent_t ev_k1 = nullptr) {
+  const int group = batch_group_frames(p, g, n_frames);
+  for (int f0 = 0; f0 < n_frames; f0 += group) {
+    Batch b;
+    b.frames = std::min(group, n_frames - f0), b.im_stride = im_stride, b.out_stride = out_stride;
+    const bool first = f0 == 0, last = f0 + group >= n_frames;
+    // (with several groups the kernel-time bracket covers everything between the first group's patch launch
+    //  and the last group's, plane sums of the earlier groups included)
+    int rc = launch_apply(p, d_imgs + (size_t)f0 * im_stride, d_outs + (size_t)f0 * out_stride, g, st,
+                          first ? ev_k0 : nullptr, last ? ev_k1 : nullptr, b);
+    if (rc != RPSF_OK) return rc;
+  }
+  return RPSF_OK;
+}
+
+extern "C" int rpsf_apply_batch_device(rpsf_plan* p, const void* images_dev, void* outs_dev, int n_frames,
+                                       size_t image_stride, size_t out_stride, const rpsf_geometry* geom, void* stream) {
+  int rc = check_batch(p, images_dev, outs_dev, n_frames, image_stride, out_stride, geom);
+  if (rc != RPSF_OK) return rc;
+  HIP_TRY(hipSetDevice(p->device));
+  hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : p->stream;
+  return launch_batch(p, reinterpret_cast<const float*>(images_dev), reinterpret_cast<float*>(outs_dev), n_frames,
+                      image_stride, out_stride, *geom, st);
+}
+
+extern "C" int rpsf_apply_batch_device_timed(rpsf_plan* p, const void* images_dev, void* outs_dev, int n_frames,
+                                             size_t image_stride, size_t out_stride, const rpsf_geometry* geom, int iters,
+                                             float* total_ms, float* kernel_ms) {
+  if (iters <= 0) return fail(RPSF_E_BADARG, "bad argument");
+  int rc = check_batch(p, images_dev, outs_dev, n_frames, image_stride, out_stride, geom);
+  if (rc != RPSF_OK) return rc;
+  HIP_TRY(hipSetDevice(p->device));
+  for (int i = 0; i < iters; ++i) {
+    HIP_TRY(hipEventRecord(p->ev[0], p->stream));
+    rc = launch_batch(p, reinterpret_cast<const float*>(images_dev), reinterpret_cast<float*>(outs_dev), n_frames,
+                      image_stride, out_stride, *geom, p->stream, p->ev[1], p->ev[2]);
+    if (rc != RPSF_OK) return rc;
+    HIP_TRY(hipEventRecord(p->ev[3], p->stream));
+    HIP_TRY(hipEventSynchronize(p->ev[3]));
+    float ms = 0.f;
+    if (total_ms) {
+      HIP_TRY(hipEventElapsedTime(&ms, p->ev[0], p->ev[3]));
+      total_ms[i] = ms;
+    }
+    if (kernel_ms) {
+      HIP_TRY(hipEventElapsedTime(&ms, p->ev[1], p->ev[2]));
+      kernel_ms[i] = ms;
+    }
+  }
+  return RPSF_OK;
+}
+
+// Host frames in, host frames out.  The frames are cut into groups; group i+1 is copied in and group
+// i-1 copied out (two copy streams, pinned through hipHostRegister when the platform allows it) while
+// group i is corrected on the plan's stream.
+extern "C" int rpsf_apply_batch(rpsf_plan* p, const float* images_host, int n_frames, int height, int width, int pad_mode,
+                                float pad_value, float* outs_host) {
+  rpsf_geometry g{height, width, pad_mode, pad_value, 0, 0, 0, height, width, 0, height, width};
+  const size_t frame_floats = (size_t)height * width;
+  int rc = check_batch(p, images_host, outs_host, n_frames, frame_floats, frame_floats, &g);
+  if (rc != RPSF_OK) return rc;
+  HIP_TRY(hipSetDevice(p->device));
+  const size_t frame_bytes = frame_floats * sizeof(float);
+  // group size: at most 8 frames or ~256 MB of pixels per group, at least 1
+  const int group = (int)std::max<size_t>(1, std::min<size_t>({(size_t)n_frames, (size_t)8, ((size_t)256 << 20) / frame_bytes}));
+  const size_t need = 2 * (size_t)group * frame_bytes;  // double-buffered
+  if (need > p->batch_bytes) {
+    (void)hipFree(p->d_batch_in);
+    (void)hipFree(p->d_batch_out);
+    p->d_batch_in = p->d_batch_out = nullptr, p->batch_bytes = 0;
+    HIP_TRY(hipMalloc(&p->d_batch_in, need));
+    HIP_TRY(hipMalloc(&p->d_batch_out, need));
+    p->batch_bytes = need;
+  }
+  if (!p->copy_in) {
+    HIP_TRY(hipStreamCreateWithFlags(&p->copy_in, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&p->copy_out, hipStreamNonBlocking));
+    for (auto& e : p->ev_in) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& e : p->ev_done) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& e : p->ev_out) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  const bool want_pin = !std::getenv("RPSF_NO_PIN");
+  const bool pin_in = want_pin && hipHostRegister(const_cast<float*>(images_host), (size_t)n_frames * frame_bytes, hipHostRegisterDefault) == hipSuccess;
+  const bool pin_out = want_pin && hipHostRegister(outs_host, (size_t)n_frames * frame_bytes, hipHostRegisterDefault) == hipSuccess;
+  (void)hipGetLastError();
+  int result = RPSF_OK;
+  auto body = [&]() -> int {
+    const int n_groups = (n_frames + group - 1) / group;
+    for (int i = 0; i < n_groups; ++i) {
+      const int slot = i & 1, f0 = i * group, nf = std::min(group, n_frames - f0);
+      float* din = p->d_batch_in + (size_t)slot * group * frame_floats;
+      float* dout = p->d_batch_out + (size_t)slot * group * frame_floats;
+      if (i >= 2) HIP_TRY(hipStreamWaitEvent(p->copy_in, p->ev_done[slot], 0));   // input slot free again
+      HIP_TRY(hipMemcpyAsync(din, images_host + (size_t)f0 * frame_floats, (size_t)nf * frame_bytes, hipMemcpyHostToDevice, p->copy_in));
+      HIP_TRY(hipEventRecord(p->ev_in[slot], p->copy_in));
+      HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_in[slot], 0));
+      if (i >= 2) HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_out[slot], 0));     // output slot drained
+      int r = launch_batch(p, din, dout, nf, frame_floats, frame_floats, g, p->stream);
+      if (r != RPSF_OK) return r;
+      HIP_TRY(hipEventRecord(p->ev_done[slot], p->stream));
+      HIP_TRY(hipStreamWaitEvent(p->copy_out, p->ev_done[slot], 0));
+      HIP_TRY(hipMemcpyAsync(outs_host + (size_t)f0 * frame_floats, dout, (size_t)nf * frame_bytes, hipMemcpyDeviceToHost, p->copy_out));
+      HIP_TRY(hipEventRecord(p->ev_out[slot], p->copy_out));
+    }
+    HIP_TRY(hipStreamSynchronize(p->copy_out));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(hipStreamSynchronize(p->copy_in));
+    return RPSF_OK;
+  };
+  result = body();
+  if (result != RPSF_OK) (void)hipDeviceSynchronize();  // nothing may still touch the caller's buffers
+  if (pin_in) (void)hipHostUnregister(const_cast<float*>(images_host));
+  if (pin_out) (void)hipHostUnregister(outs_host);
+  return result;
 }
 
 extern "C" int rpsf_apply_device_timed(rpsf_plan* p, const void* image_dev, void* out_dev, const rpsf_geometry* geom,

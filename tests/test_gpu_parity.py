@@ -298,3 +298,82 @@ def test_kernel_fft_agrees_with_hipfft():
     theirs = d_out.download((count, n, n), np.complex64)
     hipfft.hipfftDestroy(plan)
     assert np.abs(ours - theirs).max() <= 2e-6 * np.abs(theirs).max()
+
+
+# ------------------------------------------------------------------ batches of frames sharing one transfer kernel
+def _random_case(n, shape, seed, frames):
+    rng = np.random.default_rng(seed)
+    coords = [tuple(int(v) for v in c) for c in rp.calculate_covering(shape, n)]
+    k = (rng.standard_normal((len(coords), n, n)) + 1j * rng.standard_normal((len(coords), n, n))).astype(np.complex64)
+    images = (rng.standard_normal((frames, *shape)) * 10 + 100).astype(np.float32)
+    return coords, k, images
+
+
+@pytest.mark.parametrize(("n", "shape", "frames"), [(16, (70, 90), 5), (32, (128, 100), 3), (64, (200, 256), 4),
+                                                     (128, (300, 420), 3), (256, (512, 512), 2)])
+def test_batch_equals_frame_by_frame(n, shape, frames):
+    """apply_batch is the Python loop over apply, bit for bit (same kernels, same plane-sum order), and the
+    first frame is pinned against the CPU oracle."""
+    coords, k, images = _random_case(n, shape, 7 * n + frames, frames)
+    transform = rp.ArrayPSFTransform(rp.IndexedCube(coords, k))
+    batch = transform.apply_batch(images, pad_mode="reflect")
+    assert batch.shape == images.shape and batch.dtype == np.float64
+    for f in range(frames):
+        assert np.array_equal(batch[f], transform.apply(images[f], pad_mode="reflect")), f
+    check(batch[0], orc.apply_transfer(images[0], coords, k, pad_mode="reflect"))
+    assert transform.apply_batch(images, dtype=np.float32).dtype == np.float32
+
+
+def test_batch_config5_shape_against_oracle():
+    """Config 5 of BASELINE.json scaled down: starfield frames, 128-px patches, coma K shared by the batch."""
+    n, size, frames = 128, 512, 6
+    coords = [tuple(int(v) for v in c) for c in rp.calculate_covering((size, size), n)]
+    src, tgt = make_psfs("coma", coords, n, size, size)
+    k = orc.construct_transfer(orc.psf_fft(src), orc.psf_fft(tgt), 3.0, 0.1).astype(np.complex64)
+    images = np.stack([orc.starfield(size, size, 100 + i) for i in range(frames)])
+    out = rp.ArrayPSFTransform(rp.IndexedCube(coords, k)).apply_batch(images)
+    for f in range(frames):
+        check(out[f], orc.apply_transfer(images[f], coords, k))
+
+
+def test_batch_device_strides_modes_and_errors():
+    from regularizepsf_amd import _native
+
+    n, shape, frames = 32, (96, 80), 4
+    coords, k, images = _random_case(n, shape, 3, frames)
+    h, w = shape
+    pad = _native.PAD_MODES["symmetric"]
+    ref = None
+    for mode in ("planes", "atomic"):
+        plan = _native.Plan(n, coords)
+        plan.set_transfer(k)
+        plan.set_overlap_mode(mode)
+        # device variant with padded frame strides (frames are not back to back)
+        stride = h * w + 64
+        host = np.zeros((frames, stride), np.float32)
+        host[:, : h * w] = images.reshape(frames, -1)
+        d_in = _native.DeviceBuffer(host.nbytes).upload(host)
+        d_out = _native.DeviceBuffer(host.nbytes)
+        plan.apply_batch_device(d_in.ptr, d_out.ptr, frames, stride, stride, _native.Geometry.whole(h, w, pad))
+        plan.synchronize()
+        got = d_out.download((frames, stride))[:, : h * w].reshape(frames, h, w)
+        single = np.stack([plan.apply(images[f], pad) for f in range(frames)])
+        if mode == "planes":
+            assert np.array_equal(got, single)
+            ref = got
+        else:  # float atomics: order of the four contributions differs run to run
+            assert np.abs(got - ref).max() <= 2e-6 * np.abs(ref).max()
+        assert np.array_equal(plan.apply_batch(images, pad), single) or mode == "atomic"
+        with pytest.raises(_native.NativeError):
+            plan.apply_batch_device(d_in.ptr, d_out.ptr, frames, h * w - 1, stride, _native.Geometry.whole(h, w, pad))
+        with pytest.raises(_native.NativeError):
+            plan.apply_batch_device(d_in.ptr, d_out.ptr, 0, stride, stride, _native.Geometry.whole(h, w, pad))
+        d_in.free()
+        d_out.free()
+    transform = rp.ArrayPSFTransform(rp.IndexedCube(coords, k))
+    with pytest.raises(ValueError):
+        transform.apply_batch(images[0])
+    # unsupported-in-kernel pad mode and the saturation branch fall back to the per-frame path
+    out = transform.apply_batch(images[:2], pad_mode="mean", saturation_threshold=125.0)
+    for f in range(2):
+        assert np.array_equal(out[f], transform.apply(images[f], pad_mode="mean", saturation_threshold=125.0))
