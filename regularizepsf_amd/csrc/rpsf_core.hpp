@@ -215,7 +215,8 @@ struct Cfg {
   static constexpr int GS_PER_PATCH = NSPEC_THREADSLOTS * 2 * E;  // complex values
   static constexpr int G_PER_PATCH = N * NC;                      // complex values
   // LDS floats for one exchange pass
-  static constexpr int X1_FLOATS = S3 ? (T / 64) * 64 * 65 : 0;
+  static constexpr int X1_ROW = 68;  // floats per X1 row: 16-byte aligned rows (wide reads), 4*lane + c mod 64 covers every bank once
+  static constexpr int X1_FLOATS = S3 ? (T / 64) * 64 * X1_ROW : 0;
   static constexpr int X2_STRIDE = S3 ? G : G + 1;
   static constexpr int X2_FLOATS = E * X2_STRIDE;
   static constexpr int PARK_FLOATS = S3 ? 0 : 2 * E * T * 2;  // parked special slot (two-stage plans), cf = 2 floats
@@ -430,17 +431,20 @@ RPSF_HD void stage_last(cf* v) {
 // X2: stage-2 layout (or stage-1 layout for two-stage plans) <-> last layout, element-major:
 //     address = e * X2_STRIDE + gid'.
 // ------------------------------------------------------------------------------------------
+struct alignas(16) quad { float a, b, c, d; };
 template <class C, int PART>
 RPSF_HD void x1_write(int t, const cf* v, float* lds) {
-  int base = (t >> 6) * (64 * 65) + (t & 63);
-  StaticFor<0, 64>::run([&]<int J>() RPSF_AI { lds[base + J * 65] = PART ? v[J].y : v[J].x; });
+  int base = (t >> 6) * (64 * C::X1_ROW) + (t & 63);
+  StaticFor<0, 64>::run([&]<int J>() RPSF_AI { lds[base + J * C::X1_ROW] = PART ? v[J].y : v[J].x; });
 }
+// a thread reads its whole row: sixteen 16-byte reads (measured 2.7x the rate of 64 dword reads)
 template <class C, int PART>
 RPSF_HD void x1_read(int t, cf* v, const float* lds) {
-  int base = (t >> 6) * (64 * 65) + (t & 63) * 65;
-  StaticFor<0, 64>::run([&]<int J>() RPSF_AI {
-    float f = lds[base + J];
-    if (PART) v[J].y = f; else v[J].x = f;
+  const quad* row = reinterpret_cast<const quad*>(lds + (t >> 6) * (64 * C::X1_ROW) + (t & 63) * C::X1_ROW);
+  StaticFor<0, 16>::run([&]<int J>() RPSF_AI {
+    const quad f = row[J];
+    if (PART) v[4 * J].y = f.a, v[4 * J + 1].y = f.b, v[4 * J + 2].y = f.c, v[4 * J + 3].y = f.d;
+    else v[4 * J].x = f.a, v[4 * J + 1].x = f.b, v[4 * J + 2].x = f.c, v[4 * J + 3].x = f.d;
   });
 }
 
