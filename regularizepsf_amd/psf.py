@@ -2,6 +2,8 @@
 
 from __future__ import annotations
 
+import pathlib
+
 import numpy as np
 import scipy.fft
 
@@ -77,3 +79,37 @@ class ArrayPSF:
         return self._values_cube == other._values_cube and self._fft_cube == other._fft_cube
 
     __hash__ = None
+
+    # ------------------------------------------------------------------ persistence (psf.py:262-332)
+    def save(self, path: pathlib.Path) -> None:
+        """Save to ``.h5``: datasets ``coordinates``, ``values``, ``fft_evaluations`` as the reference writes them
+        (``psf.py:276-280``; like upstream, an existing file is replaced)."""
+        path = pathlib.Path(path)
+        if path.suffix == ".h5":
+            from regularizepsf_amd import _h5min
+
+            _h5min.write_datasets(path, {"coordinates": np.array(self.coordinates, dtype=np.int64).reshape(-1, 2),
+                                         "values": self.values, "fft_evaluations": self.fft_evaluations}, overwrite=True)
+        elif path.suffix == ".fits":
+            msg = "FITS persistence is not implemented in this package (lossy CompImageHDU semantics live in astropy; see DESIGN.md)"
+            raise NotImplementedError(msg)
+        else:
+            msg = f"Unsupported file type {path.suffix}. Change to .h5 or .fits."
+            raise NotImplementedError(msg)
+
+    @classmethod
+    def load(cls, path: pathlib.Path) -> "ArrayPSF":
+        """Load a PSF model saved by this package or by the reference (``psf.py:307-313``); the stored spectra
+        are used as they are, not recomputed."""
+        path = pathlib.Path(path)
+        if path.suffix == ".h5":
+            from regularizepsf_amd import _h5min
+
+            data = _h5min.read_datasets(path, ["coordinates", "values", "fft_evaluations"])
+            coordinates = [tuple(int(v) for v in c) for c in data["coordinates"]]
+            return cls(IndexedCube(coordinates, data["values"]), IndexedCube(coordinates, data["fft_evaluations"]))
+        if path.suffix == ".fits":
+            msg = "FITS persistence is not implemented in this package (lossy CompImageHDU semantics live in astropy; see DESIGN.md)"
+            raise NotImplementedError(msg)
+        msg = f"Unsupported file type {path.suffix}. Change to .h5 or .fits."
+        raise NotImplementedError(msg)

@@ -203,16 +203,17 @@ class ArrayPSFTransform:
 
     # ------------------------------------------------------------------ persistence (transform.py:220-282)
     def save(self, path: pathlib.Path, overwrite: bool = False) -> None:
-        """Save to ``.h5`` (datasets ``coordinates`` and ``transfer_kernel``, as the reference writes them)."""
+        """Save to ``.h5``: datasets ``coordinates`` (n, 2) int64 and ``transfer_kernel`` (n, N, N) complex, exactly
+        what the reference writes (``transform.py:236-240``), so either package loads the other's files.
+        ``overwrite=False`` raises ``FileExistsError`` for an existing file (h5py mode ``"w-"`` upstream)."""
         path = pathlib.Path(path)
         if path.suffix == ".h5":
-            import h5py  # optional dependency, absent from the build image
+            from regularizepsf_amd import _h5min
 
-            with h5py.File(path, "w" if overwrite else "w-") as f:
-                f.create_dataset("coordinates", data=self.coordinates)
-                f.create_dataset("transfer_kernel", data=self._transfer_kernel.values)
+            _h5min.write_datasets(path, {"coordinates": np.array(self.coordinates, dtype=np.int64).reshape(-1, 2),
+                                         "transfer_kernel": self._transfer_kernel.values}, overwrite=overwrite)
         elif path.suffix == ".fits":
-            msg = "FITS persistence is not implemented in this package yet (see DESIGN.md, out of scope)"
+            msg = "FITS persistence is not implemented in this package (lossy CompImageHDU semantics live in astropy; see DESIGN.md)"
             raise NotImplementedError(msg)
         else:
             msg = f"Unsupported file type {path.suffix}. Change to .h5 or .fits."
@@ -220,16 +221,16 @@ class ArrayPSFTransform:
 
     @classmethod
     def load(cls, path: pathlib.Path, device: int = 0) -> "ArrayPSFTransform":
+        """Load a transform saved by this package or by the reference (``transform.py:266-270``)."""
         path = pathlib.Path(path)
         if path.suffix == ".h5":
-            import h5py
+            from regularizepsf_amd import _h5min
 
-            with h5py.File(path, "r") as f:
-                coordinates = [tuple(c) for c in f["coordinates"][:]]
-                kernel = f["transfer_kernel"][:]
-            return cls(IndexedCube(coordinates, kernel), device=device)
+            data = _h5min.read_datasets(path, ["coordinates", "transfer_kernel"])
+            coordinates = [tuple(int(v) for v in c) for c in data["coordinates"]]
+            return cls(IndexedCube(coordinates, data["transfer_kernel"]), device=device)
         if path.suffix == ".fits":
-            msg = "FITS persistence is not implemented in this package yet (see DESIGN.md, out of scope)"
+            msg = "FITS persistence is not implemented in this package (lossy CompImageHDU semantics live in astropy; see DESIGN.md)"
             raise NotImplementedError(msg)
         msg = f"Unsupported file type {path.suffix}. Change to .h5 or .fits."
         raise NotImplementedError(msg)
