@@ -29,6 +29,7 @@ ROOT = pathlib.Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec peak, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
+MEASURED_COPY_GBS = 6290.0  # the same guide's measured device-copy ceiling (SURVEY.md 8d asks for both)
 
 CONFIGS = {  # name -> (height, width, patch, starfield seed)
     2: (2048, 2048, 128, 2),
@@ -70,10 +71,19 @@ def cpu_baseline(image, coords, k, budget_s: float = 20.0):
     # pixels corrected = rows fully covered by the sampled lattice rows
     done_rows = h if n_rows == len(rows) else rows[n_rows - 1] + n // 2
     mpix = done_rows * image.shape[1] / 1e6
+    # the reference's default (workers=None: single-threaded FFTs) on the two-lattice-row probe sample
+    sel1, h1 = band(rows[1])
+    t0 = time.perf_counter()
+    orc.apply_transfer(image[:h1], [coords[i] for i in sel1], k[sel1], workers=None)
+    single = time.perf_counter() - t0
+    single_rows = h1 if len(rows) == 2 else rows[1] + n // 2
     return {
         "value": round(mpix / best, 3), "unit": "Mpixels/s", "cores": cores, "kind": "port",
         "sample": f"top {done_rows} of {image.shape[0]} image rows ({len(sel)} of {len(coords)} patches), "
                   f"float64 NumPy/SciPy oracle, scipy.fft workers={cores}, best of 2, {best:.2f} s",
+        "single_thread_value": round(single_rows * image.shape[1] / 1e6 / single, 3),
+        "single_thread_sample": f"workers=None (the reference's default) on the top {single_rows} rows "
+                                f"({len(sel1)} patches), one run, {single:.2f} s",
     }
 
 
@@ -362,6 +372,7 @@ def main() -> None:
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac_of_measured_copy_ceiling": round(achieved / MEASURED_COPY_GBS, 4),
             "kernel": "patch_kernel", "kernel_avg_ms": round(kern_avg_ms, 4), "kernel_launches": iters,
             "algorithmic_bytes": int(alg_bytes),
             "bytes_model": "packed folded K read once + image read once + output written once (rank 0's band)",
