@@ -295,13 +295,6 @@ __global__ __launch_bounds__(Launch<C>::WG, 2) void patch_kernel(PatchParams p) 
     lds_barrier();  // the maps share LDS with the exchange buffer
   }
 #endif
-#if defined(RPSF_KPREFETCH) && !defined(RPSF_ABL_NOK)
-  // Touch every 128-byte line of this patch's packed K now (4 per thread): HBM delivers it to L2 /
-  // Infinity Cache while the forward DFT runs, so the real loads below do not each pay an HBM round trip.
-  float kpf[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) kpf[i] = reinterpret_cast<const float*>(g)[(size_t)(i * T + t) * 32];
-#endif
 #if defined(RPSF_ABL_NOXCHG)
 #define x1_write x1_nop
 #define x1_read x1_nop
@@ -588,10 +581,8 @@ struct rpsf_plan {
   // overlap-add strategy: colour planes on regular half-overlap lattices, float atomics otherwise
   int overlap_mode = 0;  // 0 auto, 1 atomics, 2 planes
   int stagger_us = 0, cu_count = 256;
-  // Tail overlap: the last, partial round of patches (ordered last: the bottom lattice rows) is a second
-  // launch; the plane sum of the rows it does not touch runs meanwhile on a low-priority stream.
-  hipStream_t stream2 = nullptr;
-  hipEvent_t ev_main = nullptr, ev_sum = nullptr;
+  // Tail overlap (opt-in, RPSF_SPLIT=1): the last, partial round of patches (ordered last: the bottom lattice
+  // rows) is a second launch whose spare workgroups sum the colour planes of the rows it does not touch.
   int n_tail = 0;        // patches in the tail launch (0 = no split)
   int tail_row = 0;      // smallest corner row among the tail patches
   int split_mode = 0;    // 0 auto, 1 never
@@ -773,14 +764,7 @@ extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int
   p->device = device, p->N = N, p->n_patches = n_patches;
   auto body = [&]() -> int {
     HIP_TRY(hipSetDevice(device));
-    {
-      int lo = 0, hi = 0;
-      HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));  // lo = least, hi = greatest priority
-      HIP_TRY(hipStreamCreateWithPriority(&p->stream, hipStreamNonBlocking, hi));
-      HIP_TRY(hipStreamCreateWithPriority(&p->stream2, hipStreamNonBlocking, lo));
-      HIP_TRY(hipEventCreateWithFlags(&p->ev_main, hipEventDisableTiming));
-      HIP_TRY(hipEventCreateWithFlags(&p->ev_sum, hipEventDisableTiming));
-    }
+    HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     for (auto& e : p->ev) HIP_TRY(hipEventCreate(&e));
     {
       hipDeviceProp_t prop;
@@ -857,9 +841,6 @@ extern "C" void rpsf_plan_destroy(rpsf_plan* p) {
   if (p->copy_in) (void)hipStreamDestroy(p->copy_in);
   if (p->copy_out) (void)hipStreamDestroy(p->copy_out);
   if (p->stream) (void)hipStreamDestroy(p->stream);
-  if (p->stream2) (void)hipStreamDestroy(p->stream2);
-  if (p->ev_main) (void)hipEventDestroy(p->ev_main);
-  if (p->ev_sum) (void)hipEventDestroy(p->ev_sum);
   delete p;
 }
 
