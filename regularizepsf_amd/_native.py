@@ -278,6 +278,14 @@ def build_transfer(source_fft: np.ndarray, target_fft: np.ndarray, alpha: float,
     return k
 
 
+def build_transfer_device(s_ptr: c_void_p, t_ptr: c_void_p, k_ptr: c_void_p, count: int, is_f64: bool, alpha: float,
+                          epsilon: float, device: int = 0) -> None:
+    """K2 on device-resident spectra (count complex values each); returns once K is complete."""
+    check(lib().rpsf_build_transfer_device(device, count, s_ptr, t_ptr, int(is_f64), float(alpha), float(epsilon), k_ptr,
+                                           None))
+    check(lib().rpsf_device_synchronize(device))
+
+
 def psf_fft(values: np.ndarray, device: int = 0) -> np.ndarray:
     """K3 on the GPU: (n, N, N) real -> complex64 un-shifted 2-D spectra (psf.py:216-219)."""
     v = np.ascontiguousarray(values, dtype=np.float32)

@@ -61,8 +61,34 @@ class ArrayPSFTransform:
         if np.any(np.array(source.coordinates) != np.array(target.coordinates)):
             msg = "Source PSF coordinates do not match target PSF coordinates."
             raise InvalidCoordinateError(msg)
-        kernel = _native.build_transfer(source.fft_evaluations, target.fft_evaluations, alpha, epsilon, device=device)
-        return cls(IndexedCube(source.coordinates, kernel), device=device)
+        s_fft, t_fft = source.fft_evaluations, target.fft_evaluations
+        resident = (np.result_type(s_fft.dtype, t_fft.dtype) == np.complex64 and s_fft.ndim == 3 and len(source) > 0
+                    and s_fft.shape == t_fft.shape and s_fft.shape[1] == s_fft.shape[2]
+                    and s_fft.shape[1] in _native.SUPPORTED_PATCH_SIZES
+                    and all(isinstance(v, numbers.Integral) for c in source.coordinates for v in c))
+        if not resident:
+            kernel = _native.build_transfer(s_fft, t_fft, alpha, epsilon, device=device)
+            return cls(IndexedCube(source.coordinates, kernel), device=device)
+        # complex64 spectra and a patch size the kernels support: K is built on the device, packed for K1 from
+        # there (no second trip over PCIe at the first apply) and copied back once for the IndexedCube.
+        s_fft = np.ascontiguousarray(s_fft, dtype=np.complex64)
+        t_fft = np.ascontiguousarray(t_fft, dtype=np.complex64)
+        bufs = [_native.DeviceBuffer(s_fft.nbytes, device) for _ in range(3)]
+        try:
+            bufs[0].upload(s_fft)
+            bufs[1].upload(t_fft)
+            _native.build_transfer_device(bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, s_fft.size, False, alpha, epsilon, device)
+            plan = _native.Plan(s_fft.shape[1], source.coordinates, device=device)
+            plan.set_transfer_device(bufs[2].ptr)
+            plan.synchronize()
+            kernel = bufs[2].download(s_fft.shape, np.complex64)
+        finally:
+            for b in bufs:
+                b.free()
+        cube = IndexedCube(source.coordinates, kernel)
+        out = cls(cube, device=device)
+        out._plan, out._plan_stamp = plan, (id(cube.values), cube._edits, len(cube))
+        return out
 
     # ------------------------------------------------------------------ device plan
     def invalidate(self) -> None:

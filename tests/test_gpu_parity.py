@@ -377,3 +377,29 @@ def test_batch_device_strides_modes_and_errors():
     out = transform.apply_batch(images[:2], pad_mode="mean", saturation_threshold=125.0)
     for f in range(2):
         assert np.array_equal(out[f], transform.apply(images[f], pad_mode="mean", saturation_threshold=125.0))
+
+
+def test_construct_keeps_the_kernel_on_the_device():
+    """complex64 spectra + supported patch size: K2 -> pack run on the device; same K and same correction as the
+    host-pointer route, and the first apply does not upload K again."""
+    from regularizepsf_amd import _native
+
+    n, shape = 32, (96, 128)
+    coords = [tuple(int(v) for v in c) for c in rp.calculate_covering(shape, n)]
+    src, tgt = make_psfs("coma", coords, n, *shape)
+    s = rp.ArrayPSF(rp.IndexedCube(coords, src.astype(np.float32)))
+    t = rp.ArrayPSF(rp.IndexedCube(coords, tgt.astype(np.float32)))
+    tr = rp.ArrayPSFTransform.construct(s, t, 3.0, 0.1)
+    k = tr._transfer_kernel.values
+    assert k.dtype == np.complex64 and tr._plan is not None
+    assert np.array_equal(k, _native.build_transfer(s.fft_evaluations, t.fft_evaluations, 3.0, 0.1), equal_nan=True)
+    ref = orc.construct_transfer(s.fft_evaluations, t.fft_evaluations, 3.0, 0.1)
+    assert np.abs(k - ref).max() <= 1e-5 * np.abs(ref).max()
+    plan_before = tr._plan
+    image = orc.starfield(*shape, 5)
+    out = tr.apply(image)
+    assert tr._plan is plan_before  # no re-upload
+    assert np.array_equal(out, rp.ArrayPSFTransform(rp.IndexedCube(coords, k.copy())).apply(image))
+    check(out, orc.apply_transfer(image, coords, k))
+    tr._transfer_kernel[coords[0]] = np.zeros((n, n), np.complex64)  # editing K still invalidates the device copy
+    assert not np.array_equal(tr.apply(image), out)
