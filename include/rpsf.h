@@ -93,6 +93,12 @@ typedef struct rpsf_geometry {
  * done by the Python layer): float32 image (height, width) in, float32 corrected image out. */
 int rpsf_apply(rpsf_plan* plan, const float* image_host, int height, int width, int pad_mode, float pad_value,
                float* out_host);
+/* The same call for the dtypes ArrayPSFTransform.apply really sees: the image as float32 or float64
+ * (image_is_f64; apply casts with astype, transform.py:117) and the result as float32 or float64
+ * (out_is_f64; the reference returns float64, transform.py:174-177).  Conversions run on a few host threads,
+ * chunk by chunk through pinned staging, overlapped with the PCIe copies. */
+int rpsf_apply_host(rpsf_plan* plan, const void* image_host, int image_is_f64, int height, int width, int pad_mode,
+                    float pad_value, void* out_host, int out_is_f64);
 /* Same with image and output already resident on the plan's device; asynchronous on `stream`
  * (a hipStream_t, or NULL for the plan's own stream).  The output rows are cleared first. */
 int rpsf_apply_device(rpsf_plan* plan, const void* image_dev, void* out_dev, const rpsf_geometry* geom, void* stream);

@@ -60,6 +60,7 @@ _PROTOTYPES = {
     "rpsf_plan_set_stagger": (c_int, [c_void_p, c_int]),
     "rpsf_plan_debug_stamps": (c_int, [c_void_p, c_void_p, c_size_t]),
     "rpsf_apply": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+    "rpsf_apply_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int]),
     "rpsf_apply_device": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(Geometry), c_void_p]),
     "rpsf_apply_device_timed": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(Geometry), c_int, c_void_p, c_void_p]),
     "rpsf_apply_batch": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
@@ -214,6 +215,22 @@ class Plan:
         img = np.ascontiguousarray(image, dtype=np.float32)
         out = np.empty_like(img)
         check(lib().rpsf_apply(self._handle, _ptr(img), img.shape[0], img.shape[1], pad_mode, pad_value, _ptr(out)))
+        return out
+
+    def apply_host(self, image: np.ndarray, pad_mode: int, pad_value: float = 0.0, out_dtype=np.float64) -> np.ndarray:
+        """Host array in (float32/float64 taken as they are, anything else through float32), host array out
+        (float64 like the reference, or float32); dtype conversions happen inside the library."""
+        img = np.asarray(image)
+        if img.dtype not in (np.float32, np.float64) or img.dtype.byteorder == ">":
+            img = img.astype(np.float32)
+        img = np.ascontiguousarray(img)
+        out_dtype = np.dtype(out_dtype)
+        if out_dtype not in (np.float32, np.float64):
+            msg = "out_dtype must be float32 or float64"
+            raise ValueError(msg)
+        out = np.empty(img.shape, out_dtype)
+        check(lib().rpsf_apply_host(self._handle, _ptr(img), int(img.dtype == np.float64), img.shape[0], img.shape[1],
+                                    pad_mode, pad_value, _ptr(out), int(out_dtype == np.float64)))
         return out
 
     def apply_device(self, image_ptr: c_void_p, out_ptr: c_void_p, geometry: Geometry, stream: c_void_p | None = None) -> None:

@@ -15,11 +15,13 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <barrier>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rpsf.h"
@@ -599,6 +601,11 @@ struct rpsf_plan {
   size_t batch_bytes = 0;
   hipStream_t copy_in = nullptr, copy_out = nullptr;
   hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+  // rpsf_apply_host: whole-frame pinned staging (float32) for the input and the output, chunk events
+  float* h_pin_in = nullptr;
+  float* h_pin_out = nullptr;
+  size_t pin_bytes = 0;
+  hipEvent_t ev_chunk[16] = {};
   float* d_planes = nullptr;
   size_t planes_floats = 0;  // per plane
   size_t planes_frames = 0;  // frames the allocation holds (4 planes each)
@@ -833,6 +840,10 @@ extern "C" void rpsf_plan_destroy(rpsf_plan* p) {
   (void)hipFree(p->d_planes);
   (void)hipFree(p->d_batch_in);
   (void)hipFree(p->d_batch_out);
+  (void)hipHostFree(p->h_pin_in);
+  (void)hipHostFree(p->h_pin_out);
+  for (auto& e : p->ev_chunk)
+    if (e) (void)hipEventDestroy(e);
   for (auto& e : p->ev)
     if (e) (void)hipEventDestroy(e);
   for (auto* arr : {p->ev_in, p->ev_done, p->ev_out})
@@ -1229,6 +1240,108 @@ extern "C" int rpsf_apply_batch(rpsf_plan* p, const float* images_host, int n_fr
   if (pin_in) (void)hipHostUnregister(const_cast<float*>(images_host));
   if (pin_out) (void)hipHostUnregister(outs_host);
   return result;
+}
+
+// Host frame in (float32 or float64), host frame out (float32 or float64) - what ArrayPSFTransform.apply
+// hands over and gets back (transform.py:117 astype, :174-177 float64 result).  The dtype conversions run on
+// a few host threads in chunks, through pinned staging, overlapped with the PCIe copies; fresh output pages are
+// first touched by all threads instead of one.
+extern "C" int rpsf_apply_host(rpsf_plan* p, const void* image_host, int image_is_f64, int height, int width,
+                               int pad_mode, float pad_value, void* out_host, int out_is_f64) {
+  if (!p || !image_host || !out_host) return fail(RPSF_E_BADARG, "null argument");
+  if (!p->have_k) return fail(RPSF_E_STATE, "no transfer kernel installed (call rpsf_plan_set_transfer first)");
+  rpsf_geometry g{height, width, pad_mode, pad_value, 0, 0, 0, height, width, 0, height, width};
+  int rc = check_geometry(p, &g);
+  if (rc != RPSF_OK) return rc;
+  HIP_TRY(hipSetDevice(p->device));
+  const size_t count = (size_t)height * width, bytes = count * sizeof(float);
+  if (bytes > p->stage_bytes) {
+    (void)hipFree(p->d_img);
+    (void)hipFree(p->d_out);
+    p->d_img = p->d_out = nullptr;
+    p->stage_bytes = 0;
+    HIP_TRY(hipMalloc(&p->d_img, bytes));
+    HIP_TRY(hipMalloc(&p->d_out, bytes));
+    p->stage_bytes = bytes;
+  }
+  if (bytes > p->pin_bytes) {
+    (void)hipHostFree(p->h_pin_in);
+    (void)hipHostFree(p->h_pin_out);
+    p->h_pin_in = p->h_pin_out = nullptr;
+    p->pin_bytes = 0;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->h_pin_in), bytes, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->h_pin_out), bytes, hipHostMallocDefault));
+    p->pin_bytes = bytes;
+  }
+  constexpr int MAXC = 16;
+  for (auto& e : p->ev_chunk)
+    if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  const int n_chunks = (int)std::min<size_t>(MAXC, std::max<size_t>(1, bytes >> 22));  // >= 4 MiB per chunk
+  const int n_threads = (int)std::min<size_t>({(size_t)16, (size_t)std::max(1u, std::thread::hardware_concurrency()),
+                                               std::max<size_t>(1, bytes >> 20)});
+  const size_t per_chunk = (count + n_chunks - 1) / n_chunks;
+  auto chunk_range = [&](int c, size_t& lo, size_t& hi) { lo = std::min(count, c * per_chunk), hi = std::min(count, lo + per_chunk); };
+  auto my_range = [&](size_t lo, size_t hi, int tid, size_t& a, size_t& b) {
+    const size_t span = (hi - lo + n_threads - 1) / n_threads;
+    a = std::min(hi, lo + tid * span), b = std::min(hi, a + span);
+  };
+  hipError_t err = hipSuccess;  // written by thread 0 only
+  std::barrier sync(n_threads);
+  auto worker = [&](int tid) {
+    // ---- in: convert / copy into pinned staging chunk by chunk; thread 0 starts each chunk's H2D
+    for (int c = 0; c < n_chunks; ++c) {
+      size_t lo, hi, a, b;
+      chunk_range(c, lo, hi);
+      my_range(lo, hi, tid, a, b);
+      if (image_is_f64) {
+        const double* src = static_cast<const double*>(image_host);
+        for (size_t i = a; i < b; ++i) p->h_pin_in[i] = (float)src[i];
+      } else if (b > a) {
+        std::memcpy(p->h_pin_in + a, static_cast<const float*>(image_host) + a, (b - a) * sizeof(float));
+      }
+      sync.arrive_and_wait();
+      if (tid == 0 && err == hipSuccess && hi > lo)
+        err = hipMemcpyAsync(p->d_img + lo, p->h_pin_in + lo, (hi - lo) * sizeof(float), hipMemcpyHostToDevice, p->stream);
+    }
+    // ---- compute + chunked D2H, all enqueued by thread 0
+    if (tid == 0 && err == hipSuccess) {
+      if (launch_apply(p, p->d_img, p->d_out, g, p->stream, nullptr) != RPSF_OK) err = hipErrorUnknown;
+      for (int c = 0; c < n_chunks && err == hipSuccess; ++c) {
+        size_t lo, hi;
+        chunk_range(c, lo, hi);
+        if (hi > lo)
+          err = hipMemcpyAsync(p->h_pin_out + lo, p->d_out + lo, (hi - lo) * sizeof(float), hipMemcpyDeviceToHost, p->stream);
+        if (err == hipSuccess) err = hipEventRecord(p->ev_chunk[c], p->stream);
+      }
+    }
+    // ---- out: as each chunk lands, convert / copy it into the caller's array
+    for (int c = 0; c < n_chunks; ++c) {
+      if (tid == 0 && err == hipSuccess) err = hipEventSynchronize(p->ev_chunk[c]);
+      sync.arrive_and_wait();  // publishes err and the chunk
+      if (err != hipSuccess) continue;
+      size_t lo, hi, a, b;
+      chunk_range(c, lo, hi);
+      my_range(lo, hi, tid, a, b);
+      if (out_is_f64) {
+        double* dst = static_cast<double*>(out_host);
+        for (size_t i = a; i < b; ++i) dst[i] = (double)p->h_pin_out[i];
+      } else if (b > a) {
+        std::memcpy(static_cast<float*>(out_host) + a, p->h_pin_out + a, (b - a) * sizeof(float));
+      }
+    }
+  };
+  {
+    std::vector<std::thread> pool;
+    for (int t = 1; t < n_threads; ++t) pool.emplace_back(worker, t);
+    worker(0);
+    for (auto& t : pool) t.join();
+  }
+  if (err != hipSuccess) {
+    (void)hipStreamSynchronize(p->stream);
+    if (err == hipErrorUnknown && !g_err.empty()) return RPSF_E_HIP;  // launch_apply already set the message
+    return fail(RPSF_E_HIP, std::string("rpsf_apply_host: ") + hipGetErrorString(err));
+  }
+  return RPSF_OK;
 }
 
 extern "C" int rpsf_apply_device_timed(rpsf_plan* p, const void* image_dev, void* out_dev, const rpsf_geometry* geom,

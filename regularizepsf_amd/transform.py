@@ -150,8 +150,7 @@ class ArrayPSFTransform:
                 raise ValueError(msg)
 
         if saturation_threshold == math.inf and pad_mode in _native.PAD_MODES:  # nothing can exceed +inf
-            out = plan.apply(image.astype(np.float32, copy=False), _native.PAD_MODES[pad_mode])
-            return out.astype(np.float64)
+            return plan.apply_host(image, _native.PAD_MODES[pad_mode])  # float64 out; conversions inside the library
 
         # Host-side padding: np.pad modes the kernel does not evaluate, and the saturation branch,
         # which works on the padded image (transform.py:119-138,171-172).

@@ -403,3 +403,25 @@ def test_construct_keeps_the_kernel_on_the_device():
     check(out, orc.apply_transfer(image, coords, k))
     tr._transfer_kernel[coords[0]] = np.zeros((n, n), np.complex64)  # editing K still invalidates the device copy
     assert not np.array_equal(tr.apply(image), out)
+
+
+def test_apply_host_converts_dtypes_inside_the_library():
+    """float32 / float64 / integer images in, float64 (reference) or float32 out: same numbers as the float32 entry
+    point, for a frame large enough to be cut into several chunks and threads and for a tiny one."""
+    from regularizepsf_amd import _native
+
+    pad = _native.PAD_MODES["symmetric"]
+    for n, shape in ((64, (1100, 1300)), (16, (9, 7))):
+        coords, k, images = _random_case(n, shape, 11 + n, 1)
+        plan = _native.Plan(n, coords)
+        plan.set_transfer(k)
+        ref = plan.apply(images[0], pad)
+        for dt in (np.float32, np.float64, np.int16, ">f4"):
+            img = images[0].astype(dt)
+            expect = ref if dt != np.int16 else plan.apply(img.astype(np.float32), pad)
+            out64 = plan.apply_host(img, pad)
+            assert out64.dtype == np.float64 and np.array_equal(out64, expect.astype(np.float64)), (n, dt)
+            out32 = plan.apply_host(img, pad, out_dtype=np.float32)
+            assert out32.dtype == np.float32 and np.array_equal(out32, expect), (n, dt)
+        strided = np.asfortranarray(images[0].astype(np.float64))
+        assert np.array_equal(plan.apply_host(strided, pad), ref.astype(np.float64))
