@@ -425,3 +425,31 @@ def test_apply_host_converts_dtypes_inside_the_library():
             assert out32.dtype == np.float32 and np.array_equal(out32, expect), (n, dt)
         strided = np.asfortranarray(images[0].astype(np.float64))
         assert np.array_equal(plan.apply_host(strided, pad), ref.astype(np.float64))
+
+
+def test_distinct_plans_from_distinct_threads():
+    """include/rpsf.h: a plan is not re-entrant, but distinct plans may be driven from distinct threads
+    (ctypes releases the GIL during the calls, so these really overlap)."""
+    import threading
+
+    cases = []
+    for i, (n, shape) in enumerate([(32, (200, 180)), (64, (256, 320)), (128, (384, 256))]):
+        coords, k, images = _random_case(n, shape, 40 + i, 1)
+        t = rp.ArrayPSFTransform(rp.IndexedCube(coords, k))
+        cases.append((t, images[0], t.apply(images[0])))
+    errors = []
+
+    def work(t, image, expect):
+        try:
+            for _ in range(8):
+                if not np.array_equal(t.apply(image), expect):
+                    errors.append("mismatch")
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=c) for c in cases]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
