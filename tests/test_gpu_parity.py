@@ -453,3 +453,26 @@ def test_distinct_plans_from_distinct_threads():
     for th in threads:
         th.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_randomized_shapes_pads_and_corner_lists(seed):
+    """Seeded sweep over patch size, image shape (not a multiple of anything), pad mode and corner list
+    (full lattice, thinned lattice, lattice shifted off the half-patch grid) against the CPU oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([16, 32, 64, 128]))
+    h, w = (int(v) for v in rng.integers(n // 2 + 1, 3 * n + 17, size=2))
+    pad_mode = str(rng.choice(["symmetric", "reflect", "edge", "wrap", "constant"]))
+    coords = [tuple(int(v) for v in c) for c in rp.calculate_covering((h, w), n)]
+    variant = seed % 3
+    if variant == 1:  # thinned: still on the lattice, holes in the coverage
+        keep = rng.random(len(coords)) < 0.7
+        keep[0] = True
+        coords = [c for c, k_ in zip(coords, keep) if k_]
+    elif variant == 2:  # off-lattice corners: overlap-add goes through float atomics
+        dr, dc = (int(v) for v in rng.integers(-n // 4, n // 4 + 1, size=2))
+        coords = [(r + dr + int(rng.integers(0, 3)), c + dc) for r, c in coords]
+    k = (rng.standard_normal((len(coords), n, n)) + 1j * rng.standard_normal((len(coords), n, n))).astype(np.complex64)
+    image = (rng.standard_normal((h, w)) * 20 + 50).astype(np.float32)
+    out = rp.ArrayPSFTransform(rp.IndexedCube(coords, k)).apply(image, pad_mode=pad_mode)
+    check(out, orc.apply_transfer(image, coords, k, pad_mode=pad_mode))
