@@ -100,26 +100,6 @@ constexpr float cos64(int k) {
 }
 constexpr float sin64(int k) { return cos64(k - 16); }
 
-// d * W_n^i (forward, W = exp(-2 pi i / n)) or d * conj(W_n^i) (inverse); n = 2^LOG <= 64, i compile time.
-template <int I, int LOG, bool INV>
-RPSF_HD cf tw_const(cf d) {
-  constexpr int n = 1 << LOG;
-  constexpr int k = (I & (n - 1)) * (64 / n);  // index on the 64-point circle
-  if constexpr (k == 0) {
-    return d;
-  } else if constexpr (k == 16) {
-    return INV ? mul_pi(d) : mul_mi(d);
-  } else if constexpr (k == 32) {
-    return -d;
-  } else if constexpr (k == 48) {
-    return INV ? mul_mi(d) : mul_pi(d);
-  } else {
-    constexpr float c = cos64(k);
-    constexpr float s = INV ? sin64(k) : -sin64(k);  // W = c + i s
-    return cf{d.x * c - d.y * s, d.x * s + d.y * c};
-  }
-}
-
 template <int I, int CNT>
 struct StaticFor {
   template <class F>
@@ -134,24 +114,40 @@ struct StaticFor<CNT, CNT> {
   static RPSF_HD void run(F&&) {}
 };
 
-// In-register DFT of 2^LOG points, natural order in and out, radix-2 decimation in frequency with
-// compile-time twiddles.  All indices are compile-time, so x[] lives in registers.
+// In-register DFT of 2^LOG points, natural order in and out, radix-2 decimation in time with compile-time
+// twiddles.  All indices are compile-time, so x[] lives in registers.  A butterfly with a non-trivial twiddle
+// W = c + i s is six fused multiply-adds (X = E + W O accumulated straight onto E, Y = 2E - X) instead of
+// the eight operations of "multiply, then add and subtract".
+template <int I, int LOG, bool INV>
+RPSF_HD void butterfly_dit(cf e, cf o, cf& x, cf& y) {
+  constexpr int n = 1 << LOG;
+  constexpr int k = (I & (n - 1)) * (64 / n);  // index on the 64-point circle
+  if constexpr (k == 0) {
+    x = e + o, y = e - o;
+  } else if constexpr (k == 16) {
+    cf t = INV ? mul_pi(o) : mul_mi(o);
+    x = e + t, y = e - t;
+  } else {
+    constexpr float c = cos64(k);
+    constexpr float s = INV ? sin64(k) : -sin64(k);  // W = c + i s
+    x.x = __builtin_fmaf(-s, o.y, __builtin_fmaf(c, o.x, e.x));
+    x.y = __builtin_fmaf(c, o.y, __builtin_fmaf(s, o.x, e.y));
+    y.x = __builtin_fmaf(2.0f, e.x, -x.x);
+    y.y = __builtin_fmaf(2.0f, e.y, -x.y);
+  }
+}
 template <int LOG, bool INV>
 struct FftSmall {
   static RPSF_HD void run(cf* x) {
     constexpr int h = 1 << (LOG - 1);
-    cf lo[h], hi[h];
+    cf ev[h], od[h];
     StaticFor<0, h>::run([&]<int I>() RPSF_AI {
-      cf a = x[I], b = x[I + h];
-      lo[I] = a + b;
-      hi[I] = tw_const<I, LOG, INV>(a - b);
+      ev[I] = x[2 * I];
+      od[I] = x[2 * I + 1];
     });
-    FftSmall<LOG - 1, INV>::run(lo);
-    FftSmall<LOG - 1, INV>::run(hi);
-    StaticFor<0, h>::run([&]<int I>() RPSF_AI {
-      x[2 * I] = lo[I];
-      x[2 * I + 1] = hi[I];
-    });
+    FftSmall<LOG - 1, INV>::run(ev);
+    FftSmall<LOG - 1, INV>::run(od);
+    StaticFor<0, h>::run([&]<int I>() RPSF_AI { butterfly_dit<I, LOG, INV>(ev[I], od[I], x[I], x[I + h]); });
   }
 };
 template <bool INV>
