@@ -339,7 +339,7 @@ __global__ __launch_bounds__(Launch<C>::WG, 2) void patch_kernel(PatchParams p) 
   {
     STAMP(6);
     STAMP(7);
-    freq_step<C>(t, gids, v, kring, g, p.gs + (size_t)patch * C::GS_PER_PATCH, tw, reinterpret_cast<cf*>(lds));
+    freq_step<C>(t, gids, v, kring, g, p.gs + (size_t)patch * C::GS_PER_PATCH, tw, reinterpret_cast<cf*>(lds + C::PARK_OFFSET));
     STAMP(8);
   }
 

@@ -215,9 +215,14 @@ struct Cfg {
   static constexpr int X1_FLOATS = S3 ? (T / 64) * 64 * X1_ROW : 0;
   static constexpr int X2_STRIDE = S3 ? G : G + 1;
   static constexpr int X2_FLOATS = E * X2_STRIDE;
-  static constexpr int PARK_FLOATS = S3 ? 0 : 2 * E * T * 2;  // parked special slot (two-stage plans), cf = 2 floats
   static constexpr int LDS_FLOATS0 = X1_FLOATS > X2_FLOATS ? X1_FLOATS : X2_FLOATS;
-  static constexpr int LDS_FLOATS = LDS_FLOATS0 > PARK_FLOATS ? LDS_FLOATS0 : PARK_FLOATS;
+  // Parked special slot: thread-private LDS columns scratch[(h*E + e)*PARK_STRIDE + t].  Two-stage plans are
+  // single-wave workgroups and park inside the (idle) exchange buffer; three-stage plans park behind it,
+  // because faster waves are already rewriting the exchange buffer while a special wave still reads its columns.
+  static constexpr int PARK_STRIDE = S3 ? spec_t(0) : T;
+  static constexpr int PARK_FLOATS = 2 * E * PARK_STRIDE * 2;  // cf = 2 floats
+  static constexpr int PARK_OFFSET = S3 ? LDS_FLOATS0 : 0;
+  static constexpr int LDS_FLOATS = S3 ? LDS_FLOATS0 + PARK_FLOATS : (LDS_FLOATS0 > PARK_FLOATS ? LDS_FLOATS0 : PARK_FLOATS);
   static constexpr float SCALE = 1.0f / (2.0f * (float)N * (float)N);  // 1/4 (pair algebra) * 1/(N*N/2) (inverse DFT)
 };
 
@@ -536,60 +541,27 @@ RPSF_HD void load_k_chunk(int t, cf* k, const cf* __restrict__ g) {
 #endif
   });
 }
+#if !defined(RPSF_KRING)
+#define RPSF_KRING 1
+#endif
 template <class C>
 struct KRing {
-  cf k[2 * C::KCH];  // one chunk in flight: 128 data registers + butterfly temporaries leave no room for two
+  static constexpr int DEPTH = RPSF_KRING;  // chunks in flight
+  cf k[DEPTH][2 * C::KCH];
 };
 template <class C>
 RPSF_HD void kring_fill(int t, KRing<C>& r, const cf* __restrict__ g) {
-  load_k_chunk<C, 0>(t, r.k, g);
+  StaticFor<0, KRing<C>::DEPTH>::run([&]<int D>() RPSF_AI { load_k_chunk<C, D>(t, r.k[D], g); });
 }
 
-// Special slot, three-stage plans (E <= 8): whole slot at once, partners picked with selects.
-// k = the slot's E pair words (Ka(A_e), Ka(B_e)).
-template <class C, int S>
-RPSF_HD void special_slot_regs(int t, const GroupIds<C>& gids, cf* v, const cf* k, const cf* __restrict__ gs,
-                               const cf* __restrict__ tw) {
-  constexpr int E = C::E, EA = C::EA, EB = C::EB, ST = C::spec_t(S);
-  cf* za = v + (2 * S) * E;
-  cf* zb = za + E;
-  const int ga = gids[2 * S], gb = gids[2 * S + 1];
-  const bool self = partner_gid<C>(ga) == ga;
-  int qa, ma, qb, mb;
-  gid_to_qm<C>(ga, qa, ma);
-  gid_to_qm<C>(gb, qb, mb);
-  const bool qza = qa == 0, qzb = qb == 0, mza = ma == 0, mzb = mb == 0;
-  const cf* gsp = gs + (size_t)C::spec_prefix(S) * 2 * E + (size_t)t * 2;
-  cf ks[2 * E];  // all Nyquist-side values first: one latency, not E of them
-  StaticFor<0, E>::run([&]<int I>() RPSF_AI {
-    ks[2 * I] = gsp[(size_t)I * ST * 2];
-    ks[2 * I + 1] = gsp[(size_t)I * ST * 2 + 1];
-  });
-  cf na[E], nb[E];
-  StaticFor<0, E>::run([&]<int EE>() RPSF_AI {
-    // partner bin: each digit is reversed (E-1-e form) unless the group's q (resp. m) is zero, where it is negated
-    constexpr int K3 = EE / EB, L3 = EE % EB;
-    constexpr int RR = (EA - 1 - K3) * EB + (EB - 1 - L3), ZR = ((EA - K3) % EA) * EB + (EB - 1 - L3);
-    constexpr int RZ = (EA - 1 - K3) * EB + (EB - L3) % EB, ZZ = ((EA - K3) % EA) * EB + (EB - L3) % EB;
-    auto pick = [&](const cf* src, bool qz, bool mz) RPSF_AI {
-      cf rr = src[RR], zr = src[ZR], rz = src[RZ], zz = src[ZZ];
-      return sel(mz, sel(qz, zz, rz), sel(qz, zr, rr));
-    };
-    cf pa = sel(self, pick(za, qza, mza), pick(zb, qza, mza));
-    cf pb = sel(self, pick(zb, qzb, mzb), pick(za, qzb, mzb));
-    na[EE] = pair_op(za[EE], pa, k[2 * EE], ks[2 * EE], tw[ma + C::M * L3]).a;
-    nb[EE] = pair_op(zb[EE], pb, k[2 * EE + 1], ks[2 * EE + 1], tw[mb + C::M * L3]).a;
-  });
-  StaticFor<0, E>::run([&]<int EE>() RPSF_AI { za[EE] = na[EE]; zb[EE] = nb[EE]; });
-}
-
-// Special slot, two-stage plans (single-wave workgroups, E up to 32): the slot is parked in thread-private
-// LDS columns (scratch[(h*E + e)*T + t]) and every bin fetches its partner by computed address, so no
-// register temporaries and no 4-way selects are needed.
+// Special slot: parked in thread-private LDS columns (scratch[(h*E + e)*PARK_STRIDE + t]); every bin fetches
+// its partner by computed address, so no register temporaries and no 4-way selects are needed.  (The special
+// waves are the ones every barrier waits for: a register-select version of this path cost 8 % of the N=256
+// kernel.)
 template <class C, int S>
 RPSF_HD void special_slot_park(int t, const cf* v, cf* scratch) {
   constexpr int E = C::E;
-  StaticFor<0, 2 * E>::run([&]<int I>() RPSF_AI { scratch[(size_t)I * C::T + t] = v[(2 * S) * E + I]; });
+  StaticFor<0, 2 * E>::run([&]<int I>() RPSF_AI { scratch[(size_t)I * C::PARK_STRIDE + t] = v[(2 * S) * E + I]; });
 }
 template <class C, int S, int EE>
 RPSF_HD void special_pair_parked(int t, const GroupIds<C>& gids, cf* v, cf ka_a, cf ka_b, const cf* __restrict__ gs,
@@ -606,7 +578,7 @@ RPSF_HD void special_pair_parked(int t, const GroupIds<C>& gids, cf* v, cf ka_a,
     const int k3 = q == 0 ? (EA - K3) % EA : EA - 1 - K3;
     const int l3 = m == 0 ? (EB - L3) % EB : EB - 1 - L3;
     const int member = self ? own_member : 1 - own_member;
-    return scratch[(size_t)(member * E + k3 * EB + l3) * C::T + t];
+    return scratch[(size_t)(member * E + k3 * EB + l3) * C::PARK_STRIDE + t];
   };
   const cf* gsp = gs + (size_t)C::spec_prefix(S) * 2 * E + ((size_t)EE * ST + t) * 2;
   const cf ks_a = gsp[0], ks_b = gsp[1];
@@ -617,7 +589,7 @@ RPSF_HD void special_pair_parked(int t, const GroupIds<C>& gids, cf* v, cf ka_a,
 
 // The whole frequency step of one thread: 32 pair words in 4 chunks.  r holds chunk 0 (loaded by the caller
 // before the exchange into the last layout); each later chunk is requested as soon as its buffer is free.
-// scratch: thread-private LDS columns for the parked special path (two-stage plans), else unused.
+// scratch: thread-private LDS columns for the parked special path.
 // FUSE: the last stage is a DFT inside each group, so when chunks hold whole slots it runs slot by slot
 // around the multiplication (forward DFT of the chunk's groups, multiply, request the next chunk, inverse
 // DFT of the same groups): the K round trip of chunk i+1 hides behind the butterflies of chunks i and i+1.
@@ -629,6 +601,8 @@ RPSF_HD void pointwise(int t, const GroupIds<C>& gids, cf* v, KRing<C>& r, const
   static_assert(!FUSE || C::KCH % E == 0, "fused last stage needs whole slots per chunk");
   StaticFor<0, 32 / C::KCH>::run([&]<int CI>() RPSF_AI {
     StaticFor<0, GPC>::run([&]<int J>() RPSF_AI { stage_last_group<C, false, CI * GPC + J>(v); });
+    constexpr int DEPTH = KRing<C>::DEPTH;
+    cf* rk = r.k[CI % DEPTH];
     StaticFor<0, C::KCH>::run([&]<int I>() RPSF_AI {
       constexpr int W = CI * C::KCH + I, S = W / E, EE = W % E, ST = C::spec_t(S);
       cf* za = v + (2 * S) * E;
@@ -638,20 +612,16 @@ RPSF_HD void pointwise(int t, const GroupIds<C>& gids, cf* v, KRing<C>& r, const
       if (!special) {
         int qa, ma;
         gid_to_qm<C>(gids[2 * S], qa, ma);
-        PairOut o = pair_op(za[EE], zb[E - 1 - EE], r.k[2 * I], r.k[2 * I + 1], tw[ma + C::M * (EE % EB)]);
+        PairOut o = pair_op(za[EE], zb[E - 1 - EE], rk[2 * I], rk[2 * I + 1], tw[ma + C::M * (EE % EB)]);
         za[EE] = o.a;
         zb[E - 1 - EE] = o.b;
       } else if constexpr (ST > 0) {
-        if constexpr (C::S3) {
-          static_assert(!C::S3 || C::KCH % C::E == 0, "a slot must not straddle chunks in the register-select path");
-          if constexpr (EE == 0) special_slot_regs<C, S>(t, gids, v, r.k + 2 * I, gs, tw);
-        } else {
-          if constexpr (EE == 0) special_slot_park<C, S>(t, v, scratch);
-          special_pair_parked<C, S, EE>(t, gids, v, r.k[2 * I], r.k[2 * I + 1], gs, tw, scratch);
-        }
+        static_assert(!C::S3 || C::spec_t(S) <= C::PARK_STRIDE, "parking area sized by slot 0");
+        if constexpr (EE == 0) special_slot_park<C, S>(t, v, scratch);
+        special_pair_parked<C, S, EE>(t, gids, v, rk[2 * I], rk[2 * I + 1], gs, tw, scratch);
       }
     });
-    if constexpr (CI + 1 < 32 / C::KCH) load_k_chunk<C, CI + 1>(t, r.k, g);
+    if constexpr (CI + DEPTH < 32 / C::KCH) load_k_chunk<C, CI + DEPTH>(t, rk, g);
     StaticFor<0, GPC>::run([&]<int J>() RPSF_AI { stage_last_group<C, true, CI * GPC + J>(v); });
   });
 }

@@ -66,7 +66,7 @@ static int emu_apply_t(int n_patches, const int32_t* coords, int H, int W, int p
       cf* v = &regs[(size_t)t * 64];
       KRing<C> kring;
       kring_fill<C>(t, kring, g.data());
-      freq_step<C>(t, gids[t], v, kring, g.data(), gs.data(), tw.data(), reinterpret_cast<cf*>(lds.data()));
+      freq_step<C>(t, gids[t], v, kring, g.data(), gs.data(), tw.data(), reinterpret_cast<cf*>(lds.data() + C::PARK_OFFSET));
     }
     for (int t = 0; t < T; ++t) x2_last_write<C, 0>(gids[t], &regs[(size_t)t * 64], lds.data());
     for (int t = 0; t < T; ++t) x2_mid_read<C, 0>(t, &regs[(size_t)t * 64], lds.data());
