@@ -189,7 +189,7 @@ struct Cfg {
 #if defined(RPSF_NOFUSE)
   static constexpr bool FUSE_LAST = false;
 #else
-  static constexpr bool FUSE_LAST = KCH % E == 0;  // chunks hold whole slots: last stage runs slot by slot around the multiplication
+  static constexpr bool FUSE_LAST = true;  // the last stage runs slot by slot around the multiplication
 #endif
   static constexpr int T = N * NC / 64;       // threads per patch
   static constexpr int LQ = A1_ + A2_, Q = 1 << LQ, M = 1 << (B1_ + B2_), G = Q * M;  // kr = q + Q*k3, kc = m + M*l3
@@ -597,14 +597,15 @@ template <class C, bool FUSE>
 RPSF_HD void pointwise(int t, const GroupIds<C>& gids, cf* v, KRing<C>& r, const cf* __restrict__ g,
                        const cf* __restrict__ gs, const cf* __restrict__ tw, cf* scratch) {
   constexpr int E = C::E, EB = C::EB;
-  constexpr int GPC = FUSE ? 2 * C::KCH / E : 0;  // groups per chunk
-  static_assert(!FUSE || C::KCH % E == 0, "fused last stage needs whole slots per chunk");
   StaticFor<0, 32 / C::KCH>::run([&]<int CI>() RPSF_AI {
-    StaticFor<0, GPC>::run([&]<int J>() RPSF_AI { stage_last_group<C, false, CI * GPC + J>(v); });
     constexpr int DEPTH = KRing<C>::DEPTH;
     cf* rk = r.k[CI % DEPTH];
     StaticFor<0, C::KCH>::run([&]<int I>() RPSF_AI {
       constexpr int W = CI * C::KCH + I, S = W / E, EE = W % E, ST = C::spec_t(S);
+      if constexpr (FUSE && EE == 0) {  // first word of a slot: forward DFT of its two groups
+        stage_last_group<C, false, 2 * S>(v);
+        stage_last_group<C, false, 2 * S + 1>(v);
+      }
       cf* za = v + (2 * S) * E;
       cf* zb = za + E;
       bool special = false;
@@ -622,7 +623,13 @@ RPSF_HD void pointwise(int t, const GroupIds<C>& gids, cf* v, KRing<C>& r, const
       }
     });
     if constexpr (CI + DEPTH < 32 / C::KCH) load_k_chunk<C, CI + DEPTH>(t, rk, g);
-    StaticFor<0, GPC>::run([&]<int J>() RPSF_AI { stage_last_group<C, true, CI * GPC + J>(v); });
+    StaticFor<0, C::KCH>::run([&]<int I>() RPSF_AI {  // slots that ended in this chunk: inverse DFT of their groups
+      constexpr int W = CI * C::KCH + I, S = W / E, EE = W % E;
+      if constexpr (FUSE && EE == E - 1) {
+        stage_last_group<C, true, 2 * S>(v);
+        stage_last_group<C, true, 2 * S + 1>(v);
+      }
+    });
   });
 }
 // Last stage forward, multiplication by K, last stage inverse.
