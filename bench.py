@@ -34,6 +34,7 @@ MEASURED_COPY_GBS = 6290.0  # the same guide's measured device-copy ceiling (SUR
 CONFIGS = {  # name -> (height, width, patch, starfield seed)
     2: (2048, 2048, 128, 2),
     3: (4096, 4096, 256, 3),
+    4: (8192, 8192, 256, 4),   # BASELINE.json configs[3]: one 8192^2 frame, row bands over the ranks (strong scaling)
     5: (2048, 2048, 128, 100),  # batch of frames sharing config 2's transfer kernel (BASELINE.json configs[4])
 }
 
@@ -250,7 +251,8 @@ def main() -> None:
     from regularizepsf_amd.sharding import ShardedApply
 
     h1, w, n, seed = CONFIGS[args.config]
-    height = h1 * world
+    strong = args.config == 4  # fixed 8192^2 frame cut into `world` bands; every other config grows with the ranks
+    height = h1 if strong else h1 * world
     device = local_rank % max(1, _native.device_count()) if args.comm == "gloo" else local_rank
     pad = "symmetric"
 
@@ -268,7 +270,7 @@ def main() -> None:
         tgt = orc.psf_fft(orc.gaussian_psf(n, 1.8))[None]
         for first in range(0, len(index), 128):
             part = index[first:first + 128]
-            src = np.stack([orc.coma_psf(n, coords[i][0] % h1 if world > 1 else coords[i][0], coords[i][1], h1, w)
+            src = np.stack([orc.coma_psf(n, coords[i][0] % h1 if world > 1 and not strong else coords[i][0], coords[i][1], h1, w)
                             for i in part])
             s_fft = orc.psf_fft(src, workers=-1)
             with np.errstate(all="ignore"):
@@ -280,6 +282,8 @@ def main() -> None:
 
     def image_rows(lo, hi):
         """Rows [lo, hi) of the tall image = `world` independent starfields stacked vertically."""
+        if strong:
+            return orc.starfield(h1, w, seed)[lo:hi]
         parts = []
         for b in range(world):
             a0, a1 = max(lo, b * h1), min(hi, (b + 1) * h1)
@@ -358,10 +362,10 @@ def main() -> None:
     value = total_pixels / (ms_per_step * 1e-3) / 1e6
     cus, name = _native.device_info(device)
     line = {
-        "metric": "corrected Mpixels/sec + fraction of HBM roofline, 4096^2 image / 256-patch",
+        "metric": f"corrected Mpixels/sec + fraction of HBM roofline, {h1}^2 image / {n}-patch",
         "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
             "workload": f"{height}x{w} starfield, {n}x{n} patches, {len(coords)} patches "
                         f"({'whole image on one GPU' if world == 1 else f'{world} row bands, {args.comm.upper()} seam exchange'}), "
