@@ -10,6 +10,11 @@
 //   build_transfer_kernel  K2: transform.py:78-82 element-wise.
 //   psf_fft_kernel<C>      K3: psf.py:216-219, forward half of K1 written out as a full spectrum.
 //   add_rows_kernel        K4: seam accumulate for the multi-GPU row-band split.
+//   sum_planes_kernel      K5: output = sum of the four colour planes the patches of one parity class write.
+// Development-only build switches (never set by regularizepsf_amd/build.py): RPSF_STAMPS (per-phase
+// timestamps, scripts/stamps.py), RPSF_ABL_NOK / _NOLOAD / _NOSTORE / _NOATOMIC (traffic ablations: results
+// are wrong, timing only), RPSF_ONLY_N / RPSF_ONLY_CFG (single-plan library for quick A/B builds),
+// RPSF_KRING (K chunks in flight), RPSF_NOFUSE, RPSF_NO_NT.
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
@@ -197,12 +202,6 @@ struct Launch {
   static constexpr size_t LDS_BYTES = (size_t)(TABLE_FLOATS + TEAMS * C::LDS_FLOATS) * sizeof(float);
 };
 
-#if defined(RPSF_ABL_NOXCHG)
-template <class C, int PART, class A, class B, class D>
-__device__ __forceinline__ void x1_nop(A, B, D) {}
-template <class C, int PART, class A, class B, class D>
-__device__ __forceinline__ void x2_nop(A, B, D) {}
-#endif
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also makes hipcc drain every
 // outstanding global load/store (s_waitcnt vmcnt(0)), which would expose the HBM latency of the K
@@ -276,16 +275,6 @@ __global__ __launch_bounds__(Launch<C>::WG, 2) void patch_kernel(PatchParams p) 
   }
   GroupIds<C> gids;
   gids.load(p.tab, t);
-#if defined(RPSF_ABL_NOXCHG)
-#define x1_write x1_nop
-#define x1_read x1_nop
-#define x2_mid_write x2_nop
-#define x2_mid_read x2_nop
-#define x2_last_write x2_nop
-#define x2_last_read x2_nop
-#define lds_barrier() ((void)0)
-#define wave_lds_sync() ((void)0)
-#endif
 #if !defined(RPSF_ABL_NOLOAD)
   {
     int* maps = reinterpret_cast<int*>(lds);
@@ -296,16 +285,6 @@ __global__ __launch_bounds__(Launch<C>::WG, 2) void patch_kernel(PatchParams p) 
     load_patch<C>(t, v, im, pr, pc, win, fast, maps);
     lds_barrier();  // the maps share LDS with the exchange buffer
   }
-#endif
-#if defined(RPSF_ABL_NOXCHG)
-#define x1_write x1_nop
-#define x1_read x1_nop
-#define x2_mid_write x2_nop
-#define x2_mid_read x2_nop
-#define x2_last_write x2_nop
-#define x2_last_read x2_nop
-#define lds_barrier() ((void)0)
-#define wave_lds_sync() ((void)0)
 #endif
   STAMP(1);
   stage1<C, false>(t, v, tw);
@@ -381,16 +360,6 @@ __global__ __launch_bounds__(Launch<C>::WG, 2) void patch_kernel(PatchParams p) 
     store_patch<C>(t, v, ov, plane, pr, pc, win, [](float* a, float val) { unsafeAtomicAdd(a, val); });
 #endif
   }
-#if defined(RPSF_ABL_NOXCHG)
-#undef x1_write
-#undef x1_read
-#undef x2_mid_write
-#undef x2_mid_read
-#undef x2_last_write
-#undef x2_last_read
-#undef lds_barrier
-#undef wave_lds_sync
-#endif
   STAMP(13);
 }
 
