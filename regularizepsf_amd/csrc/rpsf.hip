@@ -630,6 +630,21 @@ static int setup_lattice(rpsf_plan* p) {
     std::sort(keyed.begin(), keyed.end());
     p->h_order.resize(n);
     for (int i = 0; i < n; ++i) p->h_order[i] = keyed[i].second;
+    if (p->n_tail == 0 && !std::getenv("RPSF_NO_BORDER_FIRST")) {
+      // Patches on the rim of the lattice hang over the image edge and take the slower padded gather / cropped
+      // store path.  Within each XCD's chunk they go first, so that the last, partial round of a launch - the
+      // one the whole chip waits for - is made of interior patches only.  Speed only.
+      const int t = p->N * p->N / 2 / 64, teams = t >= 64 ? 1 : 64 / t;
+      const int chunk = ((n + 7) / 8 + teams - 1) / teams * teams;  // as launch_patches cuts the order
+      auto rim = [&](int32_t i) {
+        const int r = p->h_coords[2 * i], c = p->h_coords[2 * i + 1];
+        return r == r0 || r == r1 || c == c0 || c == c1;
+      };
+      for (int x = 0; x < 8; ++x) {
+        const int lo = std::min(n, x * chunk), hi = std::min(n, lo + chunk);
+        std::stable_partition(p->h_order.begin() + lo, p->h_order.begin() + hi, rim);
+      }
+    }
   }
   bool ok = true;
   for (int i = 0; i < n && ok; ++i)
