@@ -564,6 +564,7 @@ struct rpsf_plan {
   int4* d_desc = nullptr;
   std::vector<int32_t> h_order;
   unsigned long long* d_stamps = nullptr;
+  float* d_sink = nullptr;  // write-only scratch for the out-of-image pixels of rim patches
   // batch entry point with host pointers: double-buffered device staging and two copy streams
   float* d_batch_in = nullptr;
   float* d_batch_out = nullptr;
@@ -765,6 +766,7 @@ extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int
     HIP_TRY(hipMalloc(&p->d_coords, sizeof(int32_t) * 2 * n_patches));
     HIP_TRY(hipMemcpy(p->d_coords, coords_rc, sizeof(int32_t) * 2 * n_patches, hipMemcpyHostToDevice));
     p->h_coords.assign(coords_rc, coords_rc + 2 * (size_t)n_patches);
+    HIP_TRY(hipMalloc(&p->d_sink, 128 * sizeof(float)));
     HIP_TRY(hipMalloc(&p->d_stamps, sizeof(unsigned long long) * 16 * (size_t)n_patches));
     HIP_TRY(hipMemset(p->d_stamps, 0, sizeof(unsigned long long) * 16 * (size_t)n_patches));
     int rl = dispatch_n(N, [&]<class C>() -> int {
@@ -821,6 +823,7 @@ extern "C" void rpsf_plan_destroy(rpsf_plan* p) {
   (void)hipFree(p->d_cover);
   (void)hipFree(p->d_desc);
   (void)hipFree(p->d_stamps);
+  (void)hipFree(p->d_sink);
   (void)hipFree(p->d_planes);
   (void)hipFree(p->d_batch_in);
   (void)hipFree(p->d_batch_out);
@@ -937,9 +940,9 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
     PatchParams pp;
     pp.im = ImageView{d_img, g.height, g.width, g.ld_image, g.pad_mode, g.pad_value, g.image_row0, g.image_rows};
     if (planes)
-      pp.ov = OutView{p->d_planes, g.height, g.width, g.width, g.out_row0, g.out_rows, p->planes_floats};
+      pp.ov = OutView{p->d_planes, g.height, g.width, g.width, g.out_row0, g.out_rows, p->planes_floats, p->d_sink};
     else
-      pp.ov = OutView{d_out, g.height, g.width, g.ld_out, g.out_row0, g.out_rows, 0};
+      pp.ov = OutView{d_out, g.height, g.width, g.ld_out, g.out_row0, g.out_rows, 0, p->d_sink};
     pp.origin_row = g.origin_row, pp.origin_col = g.origin_col;
     pp.desc = p->d_desc, pp.n_patches = count, pp.seq_base = seq_base;
     pp.tab = p->d_tab, pp.tw = p->d_tw, pp.win = p->d_win, pp.g = p->d_g, pp.gs = p->d_gs;

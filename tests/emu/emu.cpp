@@ -30,7 +30,8 @@ static int emu_apply_t(int n_patches, const int32_t* coords, int H, int W, int p
   std::vector<GroupIds<C>> gids(T);
   for (int t = 0; t < T; ++t) gids[t].load(tab.data(), t);
   ImageView im{img, H, W, W, pad_mode, pad_value, 0, H};
-  OutView ov{out, H, W, W, 0, H, 0};
+  std::vector<float> sink(128);
+  OutView ov{out, H, W, W, 0, H, 0, sink.data()};
   memset(out, 0, sizeof(float) * (size_t)H * W);
   auto add = [](float* p, float v) { *p += v; };
   for (int p = 0; p < n_patches; ++p) {
