@@ -378,10 +378,12 @@ __global__ void pack_kernel(const cf* __restrict__ kfull, int n_patches, const u
   int rho = 2 * i + b;
   const cf* kf = kfull + (size_t)patch * C::N * C::N;
   g[idx] = pack_value<C>(kf, tab, t, rho, 0);
-  const int w = rho >> 1, s = w / C::E, e = w % C::E;
-  if (slot_is_special<C>(s, t))
-    gs[(size_t)patch * C::GS_PER_PATCH + (size_t)C::spec_prefix(s) * 2 * C::E + ((size_t)e * C::spec_t(s) + t) * 2 + b] =
-        pack_value<C>(kf, tab, t, rho, 1);
+  if constexpr (!C::INLINE_GS) {
+    const int w = rho >> 1, s = w / C::E, e = w % C::E;
+    if (slot_is_special<C>(s, t))
+      gs[(size_t)patch * C::GS_PER_PATCH + (size_t)C::spec_prefix(s) * 2 * C::E + ((size_t)e * C::spec_t(s) + t) * 2 + b] =
+          pack_value<C>(kf, tab, t, rho, 1);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -208,8 +208,26 @@ struct Cfg {
     return acc;
   }
   static constexpr int NSPEC_THREADSLOTS = spec_prefix(NSLOT);
-  static constexpr int GS_PER_PATCH = NSPEC_THREADSLOTS * 2 * E;  // complex values
-  static constexpr int G_PER_PATCH = N * NC;                      // complex values
+  // Two-stage plans: a slot is special-format for the whole team or not at all, so the Nyquist-side factors of
+  // a special slot travel in the main stream (two words per bin: (Ka(A_e), Ka(B_e)) then (Ks(A_e), Ks(B_e)))
+  // instead of a side array read pair by pair in the middle of the multiplication (2048^2 / N=64: 113 -> 87 us
+  // with those reads taken out).  Three-stage plans keep the side array gs: only their leading waves are special.
+  static constexpr bool INLINE_GS = !S3;
+  static constexpr int slot_words(int s) { return (INLINE_GS && spec_t(s) > 0) ? 2 * E : E; }
+  static constexpr int word_base(int s) {
+    int acc = 0;
+    for (int i = 0; i < s; ++i) acc += slot_words(i);
+    return acc;
+  }
+  static constexpr int word_slot(int w) {  // slot that word w belongs to (NSLOT for padding words)
+    int s = 0;
+    while (s < NSLOT && w >= word_base(s + 1)) ++s;
+    return s;
+  }
+  static constexpr int NWORDS_USED = word_base(NSLOT);
+  static constexpr int NWORDS = (NWORDS_USED + KCH - 1) / KCH * KCH;  // whole chunks
+  static constexpr int GS_PER_PATCH = INLINE_GS ? 0 : NSPEC_THREADSLOTS * 2 * E;  // complex values
+  static constexpr int G_PER_PATCH = NWORDS * T * 2;                              // complex values
   // LDS floats for one exchange pass
   static constexpr int X1_ROW = 68;  // floats per X1 row: 16-byte aligned rows (wide reads), 4*lane + c mod 64 covers every bank once
   static constexpr int X1_FLOATS = S3 ? (T / 64) * 64 * X1_ROW : 0;
@@ -526,7 +544,9 @@ RPSF_HD PairOut pair_op(cf za, cf zb, cf ka, cf kb, cf w) {
 //       w = S*E + e addresses bins e of slot S.  General slot: (K'_h(p), K'_h(p + (0,N/2))) for p = bin e of
 //       member A - exactly the two factors of pair_op(A_e, B_{E-1-e}).  Special-format slot:
 //       (K'_h(A_e), K'_h(B_e)), and the Nyquist-side factors (K'_h(A_e + (0,N/2)), K'_h(B_e + (0,N/2))) sit in
-//   gs: cf index prefix(S)*2E + (e*spec_t(S) + t)*2, for t < spec_t(S).
+//   gs: cf index prefix(S)*2E + (e*spec_t(S) + t)*2, for t < spec_t(S)  (three-stage plans).
+//       Two-stage plans have no gs: a special slot takes 2E words, (Ka(A_e), Ka(B_e)) then (Ks(A_e), Ks(B_e))
+//       for e = 0..E-1 (Cfg::slot_words / word_base), and the stream is padded to whole chunks.
 // K is consumed in chunks of C::KCH pair words (8, or 4 for the plans with tiny groups whose other
 // temporaries are larger): 16-byte streaming loads, 1 KiB per wave instruction.
 // ------------------------------------------------------------------------------------------
@@ -564,9 +584,9 @@ RPSF_HD void special_slot_park(int t, const cf* v, cf* scratch) {
   StaticFor<0, 2 * E>::run([&]<int I>() RPSF_AI { scratch[(size_t)I * C::PARK_STRIDE + t] = v[(2 * S) * E + I]; });
 }
 template <class C, int S, int EE>
-RPSF_HD void special_pair_parked(int t, const GroupIds<C>& gids, cf* v, cf ka_a, cf ka_b, const cf* __restrict__ gs,
+RPSF_HD void special_pair_parked(int t, const GroupIds<C>& gids, cf* v, cf ka_a, cf ka_b, cf ks_a, cf ks_b,
                                  const cf* __restrict__ tw, const cf* scratch) {
-  constexpr int E = C::E, EA = C::EA, EB = C::EB, ST = C::spec_t(S), K3 = EE / EB, L3 = EE % EB;
+  constexpr int E = C::E, EA = C::EA, EB = C::EB, K3 = EE / EB, L3 = EE % EB;
   cf* za = v + (2 * S) * E;
   cf* zb = za + E;
   const int ga = gids[2 * S], gb = gids[2 * S + 1];
@@ -580,8 +600,6 @@ RPSF_HD void special_pair_parked(int t, const GroupIds<C>& gids, cf* v, cf ka_a,
     const int member = self ? own_member : 1 - own_member;
     return scratch[(size_t)(member * E + k3 * EB + l3) * C::PARK_STRIDE + t];
   };
-  const cf* gsp = gs + (size_t)C::spec_prefix(S) * 2 * E + ((size_t)EE * ST + t) * 2;
-  const cf ks_a = gsp[0], ks_b = gsp[1];
   const cf pa = partner(qa, ma, 0), pb = partner(qb, mb, 1);
   za[EE] = pair_op(za[EE], pa, ka_a, ks_a, tw[ma + C::M * L3]).a;
   zb[EE] = pair_op(zb[EE], pb, ka_b, ks_b, tw[mb + C::M * L3]).a;
@@ -597,37 +615,52 @@ template <class C, bool FUSE>
 RPSF_HD void pointwise(int t, const GroupIds<C>& gids, cf* v, KRing<C>& r, const cf* __restrict__ g,
                        const cf* __restrict__ gs, const cf* __restrict__ tw, cf* scratch) {
   constexpr int E = C::E, EB = C::EB;
-  StaticFor<0, 32 / C::KCH>::run([&]<int CI>() RPSF_AI {
+  StaticFor<0, C::NWORDS / C::KCH>::run([&]<int CI>() RPSF_AI {
     constexpr int DEPTH = KRing<C>::DEPTH;
     cf* rk = r.k[CI % DEPTH];
     StaticFor<0, C::KCH>::run([&]<int I>() RPSF_AI {
-      constexpr int W = CI * C::KCH + I, S = W / E, EE = W % E, ST = C::spec_t(S);
-      if constexpr (FUSE && EE == 0) {  // first word of a slot: forward DFT of its two groups
-        stage_last_group<C, false, 2 * S>(v);
-        stage_last_group<C, false, 2 * S + 1>(v);
-      }
-      cf* za = v + (2 * S) * E;
-      cf* zb = za + E;
-      bool special = false;
-      if constexpr (ST > 0) special = (t & ~(C::WAVE - 1)) < ST;  // uniform over a 64-thread team
-      if (!special) {
-        int qa, ma;
-        gid_to_qm<C>(gids[2 * S], qa, ma);
-        PairOut o = pair_op(za[EE], zb[E - 1 - EE], rk[2 * I], rk[2 * I + 1], tw[ma + C::M * (EE % EB)]);
-        za[EE] = o.a;
-        zb[E - 1 - EE] = o.b;
-      } else if constexpr (ST > 0) {
-        static_assert(!C::S3 || C::spec_t(S) <= C::PARK_STRIDE, "parking area sized by slot 0");
-        if constexpr (EE == 0) special_slot_park<C, S>(t, v, scratch);
-        special_pair_parked<C, S, EE>(t, gids, v, rk[2 * I], rk[2 * I + 1], gs, tw, scratch);
+      constexpr int W = CI * C::KCH + I;
+      if constexpr (W < C::NWORDS_USED) {
+        constexpr int S = C::word_slot(W), R = W - C::word_base(S), ST = C::spec_t(S);
+        constexpr bool WIDE = C::INLINE_GS && ST > 0;        // two words per bin, the second one completes it
+        constexpr int EE = WIDE ? R / 2 : R;
+        if constexpr (FUSE && R == 0) {  // first word of a slot: forward DFT of its two groups
+          stage_last_group<C, false, 2 * S>(v);
+          stage_last_group<C, false, 2 * S + 1>(v);
+        }
+        cf* za = v + (2 * S) * E;
+        cf* zb = za + E;
+        bool special = false;
+        if constexpr (ST > 0) special = (t & ~(C::WAVE - 1)) < ST;  // uniform over a 64-thread team
+        if (!special) {
+          int qa, ma;
+          gid_to_qm<C>(gids[2 * S], qa, ma);
+          PairOut o = pair_op(za[EE], zb[E - 1 - EE], rk[2 * I], rk[2 * I + 1], tw[ma + C::M * (EE % EB)]);
+          za[EE] = o.a;
+          zb[E - 1 - EE] = o.b;
+        } else if constexpr (ST > 0) {
+          static_assert(!C::S3 || C::spec_t(S) <= C::PARK_STRIDE, "parking area sized by slot 0");
+          if constexpr (R == 0) special_slot_park<C, S>(t, v, scratch);
+          if constexpr (WIDE) {
+            static_assert(C::KCH % 2 == 0, "both words of a bin in one chunk");
+            if constexpr (R % 2 == 1)
+              special_pair_parked<C, S, EE>(t, gids, v, rk[2 * I - 2], rk[2 * I - 1], rk[2 * I], rk[2 * I + 1], tw, scratch);
+          } else {
+            const cf* gsp = gs + (size_t)C::spec_prefix(S) * 2 * E + ((size_t)EE * ST + t) * 2;
+            special_pair_parked<C, S, EE>(t, gids, v, rk[2 * I], rk[2 * I + 1], gsp[0], gsp[1], tw, scratch);
+          }
+        }
       }
     });
-    if constexpr (CI + DEPTH < 32 / C::KCH) load_k_chunk<C, CI + DEPTH>(t, rk, g);
+    if constexpr (CI + DEPTH < C::NWORDS / C::KCH) load_k_chunk<C, CI + DEPTH>(t, rk, g);
     StaticFor<0, C::KCH>::run([&]<int I>() RPSF_AI {  // slots that ended in this chunk: inverse DFT of their groups
-      constexpr int W = CI * C::KCH + I, S = W / E, EE = W % E;
-      if constexpr (FUSE && EE == E - 1) {
-        stage_last_group<C, true, 2 * S>(v);
-        stage_last_group<C, true, 2 * S + 1>(v);
+      constexpr int W = CI * C::KCH + I;
+      if constexpr (W < C::NWORDS_USED) {
+        constexpr int S = C::word_slot(W), R = W - C::word_base(S);
+        if constexpr (FUSE && R == C::slot_words(S) - 1) {
+          stage_last_group<C, true, 2 * S>(v);
+          stage_last_group<C, true, 2 * S + 1>(v);
+        }
       }
     });
   });
@@ -659,14 +692,19 @@ RPSF_HD bool slot_is_special(int s, int t) {
 }
 template <class C>
 RPSF_HD cf pack_value(const cf* __restrict__ kfull, const uint16_t* __restrict__ tab, int t, int rho, int which) {
-  // rho = 2*w + b, pair word w = S*E + e;  which = 0: g, 1: gs (special-format slots only)
-  const int w = rho >> 1, b = rho & 1, s = w / C::E, e = w % C::E;
+  // rho = 2*w + b, w = word index in the thread's stream;  which = 0: g, 1: gs (special-format slots of
+  // three-stage plans only).  See the layout comment above load_k_chunk.
+  const int w = rho >> 1, b = rho & 1;
+  if (w >= C::NWORDS_USED) return cf{0.f, 0.f};  // padding to whole chunks
+  const int s = C::word_slot(w), r = w - C::word_base(s);
   const bool special = slot_is_special<C>(s, t);
+  const bool wide = C::INLINE_GS && special;
+  const int e = wide ? r / 2 : r;
   const int member = special ? b : 0;  // general words describe bin e of member A only
   int q, m;
   gid_to_qm<C>(tab[(t * C::NSLOT + s) * 2 + member], q, m);
   const int kr = q + C::Q * (e / C::EB), kc = m + C::M * (e % C::EB);
-  const bool nyquist_side = special ? which == 1 : b == 1;
+  const bool nyquist_side = wide ? (r & 1) == 1 : special ? which == 1 : b == 1;
   return kh_at<C>(kfull, kr, nyquist_side ? kc + C::NC : kc);
 }
 

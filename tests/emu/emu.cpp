@@ -38,12 +38,14 @@ static int emu_apply_t(int n_patches, const int32_t* coords, int H, int W, int p
     const cf* kf = reinterpret_cast<const cf*>(kfull) + (size_t)p * N * N;
     // pack K for this patch (what the pack kernel does)
     for (int t = 0; t < T; ++t)
-      for (int rho = 0; rho < 64; ++rho) {
+      for (int rho = 0; rho < 2 * C::NWORDS; ++rho) {
         g[((size_t)(rho / 2) * T + t) * 2 + (rho & 1)] = pack_value<C>(kf, tab.data(), t, rho, 0);
-        const int w = rho >> 1, b = rho & 1, s = w / C::E, e = w % C::E;
-        if (slot_is_special<C>(s, t))
-          gs[(size_t)C::spec_prefix(s) * 2 * C::E + ((size_t)e * C::spec_t(s) + t) * 2 + b] =
-              pack_value<C>(kf, tab.data(), t, rho, 1);
+        if constexpr (!C::INLINE_GS) {
+          const int w = rho >> 1, b = rho & 1, s = w / C::E, e = w % C::E;
+          if (slot_is_special<C>(s, t))
+            gs[(size_t)C::spec_prefix(s) * 2 * C::E + ((size_t)e * C::spec_t(s) + t) * 2 + b] =
+                pack_value<C>(kf, tab.data(), t, rho, 1);
+        }
       }
     int pr = coords[2 * p], pc = coords[2 * p + 1];
     const bool fast = patch_inside<C>(pr, pc, H, W, 0, H) && pairs_aligned(img, W, pc);
