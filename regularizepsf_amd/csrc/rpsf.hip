@@ -200,6 +200,10 @@ struct Launch {
   static constexpr int TEAMS = WG / C::T;
   static constexpr int TABLE_FLOATS = 3 * C::N;  // twiddles (N complex) + window (N), shared by the workgroup
   static constexpr size_t LDS_BYTES = (size_t)(TABLE_FLOATS + TEAMS * C::LDS_FLOATS) * sizeof(float);
+  // Waves per SIMD the kernel is compiled for.  Where LDS already limits a CU to four single-wave workgroups
+  // (N = 64: each team parks its whole patch), one wave per SIMD may as well use the other half of the
+  // register file: spills then go to AGPRs instead of scratch memory.
+  static constexpr int WAVES_PER_SIMD = (WG == 64 && 4 * LDS_BYTES <= 160 * 1024 && 5 * LDS_BYTES > 160 * 1024) ? 1 : 2;
 };
 
 
@@ -220,7 +224,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 #endif
 
 template <class C>
-__global__ __launch_bounds__(Launch<C>::WG, 2) void patch_kernel(PatchParams p) {  // 2 waves per SIMD: 256 registers, no AGPR overflow
+__global__ __launch_bounds__(Launch<C>::WG, Launch<C>::WAVES_PER_SIMD) void patch_kernel(PatchParams p) {  // 2 waves per SIMD: 256 registers
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int T = C::T;
   if ((int)blockIdx.x >= p.patch_blocks) {  // workgroup-uniform
