@@ -204,6 +204,7 @@ struct Launch {
   // (N = 64: each team parks its whole patch), one wave per SIMD may as well use the other half of the
   // register file: spills then go to AGPRs instead of scratch memory.
   static constexpr int WAVES_PER_SIMD = (WG == 64 && 4 * LDS_BYTES <= 160 * 1024 && 5 * LDS_BYTES > 160 * 1024) ? 1 : 2;
+  static_assert(C::KDEPTH == 1 || WAVES_PER_SIMD == 1, "two K chunks in flight need the 512-register budget");
 };
 
 

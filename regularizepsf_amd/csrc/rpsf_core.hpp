@@ -186,6 +186,10 @@ struct Cfg {
   static constexpr int P = 64 / E;            // groups per thread in the last layout
   static constexpr int NSLOT = P / 2;         // pair slots per thread
   static constexpr int KCH = E >= 8 ? 8 : 4;   // pair words of K per streaming chunk (2 cf = 4 registers each)
+  // K chunks in flight.  One everywhere a wave has 256 registers (a second chunk spills, and spill reloads queue
+  // behind the K stream); two in the N = 64 plan, which is compiled for one wave per SIMD (see Launch in
+  // rpsf.hip) and has the registers: 2048^2 / N=64 81 -> 71.5 us, a depth of four gives nothing more.
+  static constexpr int KDEPTH = (LOGN_ == 6 && A2_ + B2_ == 0) ? 2 : 1;
 #if defined(RPSF_NOFUSE)
   static constexpr bool FUSE_LAST = false;
 #else
@@ -566,7 +570,7 @@ RPSF_HD void load_k_chunk(int t, cf* k, const cf* __restrict__ g) {
 #endif
 template <class C>
 struct KRing {
-  static constexpr int DEPTH = RPSF_KRING;  // chunks in flight
+  static constexpr int DEPTH = C::KDEPTH > RPSF_KRING ? C::KDEPTH : RPSF_KRING;  // chunks in flight
   cf k[DEPTH][2 * C::KCH];
 };
 template <class C>
