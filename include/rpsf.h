@@ -24,7 +24,8 @@ extern "C" {
 
 #define RPSF_OK 0
 #define RPSF_E_BADARG (-1)      /* null pointer, negative size, coordinate outside the padded image ... */
-#define RPSF_E_UNSUPPORTED (-2) /* patch size that has no compiled plan (supported: 16, 32, 64, 128, 256) */
+#define RPSF_E_UNSUPPORTED (-2) /* patch size outside 2..4096; or a size without a compiled plan (compiled: 16, 32, 64,
+                                   128, 256) when libhipfft.so, which the fallback needs, cannot be loaded */
 #define RPSF_E_HIP (-3)         /* HIP runtime error (message has the hipError string) */
 #define RPSF_E_NOMEM (-4)       /* device allocation failed */
 #define RPSF_E_RCCL (-5)        /* RCCL missing or failed */
@@ -48,7 +49,9 @@ int rpsf_device_info(int device, int* compute_units, char* name, size_t name_len
 
 /* A plan is the device-side form of one ArrayPSFTransform: patch size N (psf_shape, square,
  * regularizepsf/transform.py:37-40), the patch corner list (transform.coordinates, (row, col) pairs,
- * transform.py:141-149) and, once installed, the transfer kernel. */
+ * transform.py:141-149) and, once installed, the transfer kernel.  N = 16, 32, 64, 128, 256 use the
+ * hand-written kernels; any other N in 2..4096 (the reference takes every size) a hipFFT-based fallback with
+ * the same results and tolerance (whole-image geometry only). */
 int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int n_patches, const int32_t* coords_rc);
 void rpsf_plan_destroy(rpsf_plan* plan);
 

@@ -572,6 +572,13 @@ struct rpsf_plan {
   std::vector<int32_t> h_order;
   unsigned long long* d_stamps = nullptr;
   float* d_sink = nullptr;  // write-only scratch for the out-of-image pixels of rim patches
+  // generic (hipFFT) plans: any patch size without a compiled kernel
+  bool generic = false;
+  cf* d_kfull = nullptr;       // the caller's K, (n, N, N) complex64, unfolded
+  cf* d_fft_buf = nullptr;     // fft_chunk x N x N complex work buffer
+  float* d_win_generic = nullptr;
+  void* fft_plan = nullptr;    // hipfftHandle for fft_chunk patches
+  int fft_chunk = 0;
   // batch entry point with host pointers: double-buffered device staging and two copy streams
   float* d_batch_in = nullptr;
   float* d_batch_out = nullptr;
@@ -753,18 +760,114 @@ extern "C" int rpsf_device_info(int device, int* compute_units, char* name, size
   return RPSF_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Any other patch size: fallback through hipFFT (loaded with dlopen, like RCCL).
+// The reference accepts every square patch size (odd ones included, transform.py:151-164); the
+// hand-written plans cover 16..256.  For the rest: gather+pad+window into a complex batch, batched
+// 2-D C2C forward, times the caller's full K (no folding: Re(ifft2(.)) is taken literally), C2C
+// inverse, window again, float atomic overlap-add.  Correctness path, not a tuned one.
+// ------------------------------------------------------------------------------------------------
+struct HipfftApi {
+  void* lib = nullptr;
+  int (*plan_many)(void**, int, int*, int*, int, int, int*, int, int, int, int) = nullptr;
+  int (*set_stream)(void*, hipStream_t) = nullptr;
+  int (*exec_c2c)(void*, void*, void*, int) = nullptr;
+  int (*destroy)(void*) = nullptr;
+  std::string error;
+  bool load() {
+    if (lib) return true;
+    if (!error.empty()) return false;
+    for (const char* n : {"libhipfft.so", "libhipfft.so.0", "/opt/rocm/lib/libhipfft.so"}) {
+      lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+      if (lib) break;
+    }
+    if (!lib) {
+      error = "patch sizes other than 16, 32, 64, 128, 256 need libhipfft.so, which could not be loaded";
+      return false;
+    }
+    plan_many = reinterpret_cast<decltype(plan_many)>(dlsym(lib, "hipfftPlanMany"));
+    set_stream = reinterpret_cast<decltype(set_stream)>(dlsym(lib, "hipfftSetStream"));
+    exec_c2c = reinterpret_cast<decltype(exec_c2c)>(dlsym(lib, "hipfftExecC2C"));
+    destroy = reinterpret_cast<decltype(destroy)>(dlsym(lib, "hipfftDestroy"));
+    if (!plan_many || !set_stream || !exec_c2c || !destroy) {
+      error = "libhipfft.so lacks hipfftPlanMany / hipfftSetStream / hipfftExecC2C / hipfftDestroy";
+      lib = nullptr;
+      return false;
+    }
+    return true;
+  }
+};
+static HipfftApi g_hipfft;
+
+struct GenericGeom {
+  int N, first, count;         // patches [first, first + count) of the plan
+  int origin_row, origin_col;
+  ImageView im;
+  OutView ov;
+};
+// one thread per (patch, r, c) of the chunk
+__global__ void generic_gather_kernel(GenericGeom gg, const int32_t* __restrict__ coords, const float* __restrict__ win,
+                                      cf* __restrict__ buf) {
+  const size_t per = (size_t)gg.N * gg.N;
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= per * gg.count) return;
+  const int k = (int)(idx / per), rem = (int)(idx % per), r = rem / gg.N, c = rem % gg.N;
+  const int y = pad_index(coords[2 * (gg.first + k)] + gg.origin_row + r, gg.im.H, gg.im.pad_mode);
+  const int x = pad_index(coords[2 * (gg.first + k) + 1] + gg.origin_col + c, gg.im.W, gg.im.pad_mode);
+  const float px = (y < 0 || x < 0) ? gg.im.pad_value : gg.im.img[(size_t)(y - gg.im.row0) * gg.im.ld + x];
+  buf[idx] = cf{px * (win[r] * win[c]), 0.0f};
+}
+__global__ void generic_multiply_kernel(cf* __restrict__ buf, const cf* __restrict__ k, size_t count, float scale) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) buf[i] = cmul(buf[i], k[i]) * scale;
+}
+__global__ void generic_scatter_kernel(GenericGeom gg, const int32_t* __restrict__ coords, const float* __restrict__ win,
+                                       const cf* __restrict__ buf) {
+  const size_t per = (size_t)gg.N * gg.N;
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= per * gg.count) return;
+  const int k = (int)(idx / per), rem = (int)(idx % per), r = rem / gg.N, c = rem % gg.N;
+  const int y = coords[2 * (gg.first + k)] + gg.origin_row + r, x = coords[2 * (gg.first + k) + 1] + gg.origin_col + c;
+  if (y < 0 || y >= gg.ov.H || x < 0 || x >= gg.ov.W) return;  // the crop of transform.py:174-177
+  unsafeAtomicAdd(gg.ov.out + (size_t)(y - gg.ov.row0) * gg.ov.ld + x, buf[idx].x * (win[r] * win[c]));
+}
+
 extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int n_patches, const int32_t* coords_rc) {
   if (!out || !coords_rc) return fail(RPSF_E_BADARG, "null argument");
   if (n_patches <= 0) return fail(RPSF_E_BADARG, "n_patches must be positive");
   const int N = patch_size;
-  int rc = dispatch_n(N, []<class C>() { return RPSF_OK; });
-  if (rc != RPSF_OK) return rc;
+  const bool compiled = dispatch_n(N, []<class C>() { return RPSF_OK; }) == RPSF_OK;
+  if (!compiled) {
+    if (N < 2 || N > 4096) return fail(RPSF_E_UNSUPPORTED, "patch size " + std::to_string(N) + " is outside 2..4096");
+    if (!g_hipfft.load()) return fail(RPSF_E_UNSUPPORTED, g_hipfft.error);
+  }
   auto* p = new rpsf_plan;
   p->device = device, p->N = N, p->n_patches = n_patches;
+  p->generic = !compiled;
   auto body = [&]() -> int {
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     for (auto& e : p->ev) HIP_TRY(hipEventCreate(&e));
+    if (p->generic) {
+      HIP_TRY(hipMalloc(&p->d_coords, sizeof(int32_t) * 2 * n_patches));
+      HIP_TRY(hipMemcpy(p->d_coords, coords_rc, sizeof(int32_t) * 2 * n_patches, hipMemcpyHostToDevice));
+      p->h_coords.assign(coords_rc, coords_rc + 2 * (size_t)n_patches);
+      std::vector<float> win(N);
+      for (int i = 0; i < N; ++i) win[i] = (float)std::sin((i + 0.5) * M_PI / N);  // transform.py:151-155
+      HIP_TRY(hipMalloc(&p->d_win_generic, sizeof(float) * N));
+      HIP_TRY(hipMemcpy(p->d_win_generic, win.data(), sizeof(float) * N, hipMemcpyHostToDevice));
+      const size_t per = (size_t)N * N;
+      HIP_TRY(hipMalloc(&p->d_kfull, per * n_patches * sizeof(cf)));
+      p->g_elems = per * n_patches;
+      p->fft_chunk = (int)std::min<size_t>((size_t)n_patches, std::max<size_t>(1, ((size_t)256 << 20) / (per * sizeof(cf))));
+      HIP_TRY(hipMalloc(&p->d_fft_buf, per * p->fft_chunk * sizeof(cf)));
+      int dims[2] = {N, N};
+      if (g_hipfft.plan_many(&p->fft_plan, 2, dims, nullptr, 1, (int)per, nullptr, 1, (int)per, /*HIPFFT_C2C*/ 0x29, p->fft_chunk) != 0)
+        return fail(RPSF_E_HIP, "hipfftPlanMany failed");
+      if (g_hipfft.set_stream(p->fft_plan, p->stream) != 0) return fail(RPSF_E_HIP, "hipfftSetStream failed");
+      return RPSF_OK;
+    }
     {
       hipDeviceProp_t prop;
       HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -802,7 +905,7 @@ extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int
       return RPSF_OK;
     });
   };
-  rc = body();
+  const int rc = body();
   if (rc != RPSF_OK) {
     std::string keep = g_err;
     rpsf_plan_destroy(p);
@@ -831,6 +934,10 @@ extern "C" void rpsf_plan_destroy(rpsf_plan* p) {
   (void)hipFree(p->d_desc);
   (void)hipFree(p->d_stamps);
   (void)hipFree(p->d_sink);
+  (void)hipFree(p->d_kfull);
+  (void)hipFree(p->d_fft_buf);
+  (void)hipFree(p->d_win_generic);
+  if (p->fft_plan && g_hipfft.destroy) (void)g_hipfft.destroy(p->fft_plan);
   (void)hipFree(p->d_planes);
   (void)hipFree(p->d_batch_in);
   (void)hipFree(p->d_batch_out);
@@ -866,6 +973,11 @@ extern "C" int rpsf_plan_set_transfer(rpsf_plan* p, const float* k_host) {
   if (!p || !k_host) return fail(RPSF_E_BADARG, "null argument");
   HIP_TRY(hipSetDevice(p->device));
   const size_t per = (size_t)p->N * p->N;
+  if (p->generic) {
+    HIP_TRY(hipMemcpy(p->d_kfull, k_host, per * p->n_patches * sizeof(cf), hipMemcpyHostToDevice));
+    p->have_k = true;
+    return RPSF_OK;
+  }
   int chunk = (int)std::max<size_t>(1, (size_t)(64u << 20) / (per * sizeof(cf)));
   if (chunk > p->n_patches) chunk = p->n_patches;
   cf* d_tmp = nullptr;
@@ -890,6 +1002,11 @@ extern "C" int rpsf_plan_set_transfer(rpsf_plan* p, const float* k_host) {
 extern "C" int rpsf_plan_set_transfer_device(rpsf_plan* p, const void* k_dev) {
   if (!p || !k_dev) return fail(RPSF_E_BADARG, "null argument");
   HIP_TRY(hipSetDevice(p->device));
+  if (p->generic) {
+    HIP_TRY(hipMemcpy(p->d_kfull, k_dev, (size_t)p->N * p->N * p->n_patches * sizeof(cf), hipMemcpyDeviceToDevice));
+    p->have_k = true;
+    return RPSF_OK;
+  }
   int rc = pack_range(p, reinterpret_cast<const cf*>(k_dev), 0, p->n_patches);
   if (rc != RPSF_OK) return rc;
   HIP_TRY(hipStreamSynchronize(p->stream));
@@ -991,8 +1108,51 @@ static int launch_sum(rpsf_plan* p, float* d_out, const rpsf_geometry& g, int ro
 static bool use_planes(const rpsf_plan* p) { return p->overlap_mode == 2 || (p->overlap_mode == 0 && p->lattice); }
 static size_t plane_floats_needed(const rpsf_geometry& g) { return ((size_t)g.out_rows * g.width + 3) & ~(size_t)3; }
 
+static int launch_apply_generic(rpsf_plan* p, const float* d_img, float* d_out, const rpsf_geometry& g, hipStream_t st,
+                                hipEvent_t ev_k0, hipEvent_t ev_k1, Batch b) {
+  if (g.image_row0 != 0 || g.image_rows != g.height || g.out_row0 != 0 || g.out_rows != g.height)
+    return fail(RPSF_E_UNSUPPORTED, "row-band windows need a patch size with a compiled plan (16, 32, 64, 128, 256)");
+  if (st != p->stream) {
+    HIP_TRY(hipStreamSynchronize(p->stream));  // the FFT plan is bound to one stream at a time
+    if (g_hipfft.set_stream(p->fft_plan, st) != 0) return fail(RPSF_E_HIP, "hipfftSetStream failed");
+  }
+  const size_t per = (size_t)p->N * p->N;
+  const float scale = 1.0f / (float)per;  // hipFFT's inverse is unnormalised
+  if (ev_k0) HIP_TRY(hipEventRecord(ev_k0, st));
+  for (int f = 0; f < b.frames; ++f) {
+    const float* img = d_img + (size_t)f * b.im_stride;
+    float* out = d_out + (size_t)f * b.out_stride;
+    HIP_TRY(hipMemset2DAsync(out, (size_t)g.ld_out * sizeof(float), 0, (size_t)g.width * sizeof(float), g.out_rows, st));
+    for (int first = 0; first < p->n_patches; first += p->fft_chunk) {
+      GenericGeom gg;
+      gg.N = p->N, gg.first = first, gg.count = std::min(p->fft_chunk, p->n_patches - first);
+      gg.origin_row = g.origin_row, gg.origin_col = g.origin_col;
+      gg.im = ImageView{img, g.height, g.width, g.ld_image, g.pad_mode, g.pad_value, 0, g.height};
+      gg.ov = OutView{out, g.height, g.width, g.ld_out, 0, g.height, 0, nullptr};
+      const size_t total = per * gg.count;
+      const unsigned grid = (unsigned)((total + 255) / 256);
+      generic_gather_kernel<<<dim3(grid), dim3(256), 0, st>>>(gg, p->d_coords, p->d_win_generic, p->d_fft_buf);
+      // a short last chunk still runs the full-size plan: the surplus patches hold stale data and are never scattered
+      if (g_hipfft.exec_c2c(p->fft_plan, p->d_fft_buf, p->d_fft_buf, /*HIPFFT_FORWARD*/ -1) != 0)
+        return fail(RPSF_E_HIP, "hipfftExecC2C (forward) failed");
+      generic_multiply_kernel<<<dim3(grid), dim3(256), 0, st>>>(p->d_fft_buf, p->d_kfull + (size_t)first * per, total, scale);
+      if (g_hipfft.exec_c2c(p->fft_plan, p->d_fft_buf, p->d_fft_buf, /*HIPFFT_BACKWARD*/ 1) != 0)
+        return fail(RPSF_E_HIP, "hipfftExecC2C (inverse) failed");
+      generic_scatter_kernel<<<dim3(grid), dim3(256), 0, st>>>(gg, p->d_coords, p->d_win_generic, p->d_fft_buf);
+      HIP_TRY(hipGetLastError());
+    }
+  }
+  if (ev_k1) HIP_TRY(hipEventRecord(ev_k1, st));
+  if (st != p->stream) {
+    HIP_TRY(hipStreamSynchronize(st));
+    if (g_hipfft.set_stream(p->fft_plan, p->stream) != 0) return fail(RPSF_E_HIP, "hipfftSetStream failed");
+  }
+  return RPSF_OK;
+}
+
 static int launch_apply(rpsf_plan* p, const float* d_img, float* d_out, const rpsf_geometry& g, hipStream_t st,
                         hipEvent_t ev_k0, hipEvent_t ev_k1 = nullptr, Batch b = Batch()) {
+  if (p->generic) return launch_apply_generic(p, d_img, d_out, g, st, ev_k0, ev_k1, b);
   const bool planes = use_planes(p);
   if (planes && !p->lattice) return fail(RPSF_E_STATE, "colour planes need a regular half-overlap lattice of patch corners");
   if (planes) {
@@ -1099,7 +1259,7 @@ extern "C" int rpsf_apply(rpsf_plan* p, const float* image_host, int height, int
 // Frames per launch group: the colour planes take 16 bytes per output pixel per frame in flight; keep
 // them under a quarter of the device memory.
 static int batch_group_frames(const rpsf_plan* p, const rpsf_geometry& g, int n_frames) {
-  if (!use_planes(p)) return n_frames;
+  if (p->generic || !use_planes(p)) return n_frames;
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) total_b = (size_t)64 << 30;
   const size_t per_frame = 16 * plane_floats_needed(g);

@@ -102,8 +102,8 @@ class ArrayPSFTransform:
         if n0 != n1:
             msg = f"operands could not be broadcast together: PSF samples must be square, got {self.psf_shape}"
             raise ValueError(msg)
-        if n0 not in _native.SUPPORTED_PATCH_SIZES:
-            msg = f"patch size {n0} has no compiled kernel; supported sizes are {_native.SUPPORTED_PATCH_SIZES}"
+        if not 2 <= n0 <= 4096:  # 16..256 (powers of two) run the hand-written kernels, the rest the hipFFT fallback
+            msg = f"patch size {n0} is outside the supported range 2..4096"
             raise NotImplementedError(msg)
         return n0
 

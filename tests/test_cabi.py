@@ -41,8 +41,9 @@ def test_bad_arguments_are_reported_not_crashed():
     assert b"null" in handle.rpsf_last_error()
     out = ctypes.c_void_p()
     coords = np.zeros((1, 2), np.int32)
-    rc = handle.rpsf_plan_create(ctypes.byref(out), 0, 24, 1, coords.ctypes.data_as(ctypes.c_void_p))
-    assert rc == _native.E_UNSUPPORTED and b"24" in handle.rpsf_last_error()
+    for size in (1, 5000):  # 16..256 have compiled plans, 2..4096 the hipFFT fallback, nothing else exists
+        rc = handle.rpsf_plan_create(ctypes.byref(out), 0, size, 1, coords.ctypes.data_as(ctypes.c_void_p))
+        assert rc == _native.E_UNSUPPORTED and str(size).encode() in handle.rpsf_last_error()
 
 
 def _gpu_present():

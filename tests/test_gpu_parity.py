@@ -476,3 +476,21 @@ def test_randomized_shapes_pads_and_corner_lists(seed):
     image = (rng.standard_normal((h, w)) * 20 + 50).astype(np.float32)
     out = rp.ArrayPSFTransform(rp.IndexedCube(coords, k)).apply(image, pad_mode=pad_mode)
     check(out, orc.apply_transfer(image, coords, k, pad_mode=pad_mode))
+
+
+@pytest.mark.parametrize(("n", "shape", "pad_mode"), [(24, (100, 130), "symmetric"), (9, (40, 33), "reflect"),
+                                                        (100, (260, 300), "wrap"), (48, (96, 96), "constant"),
+                                                        (7, (20, 20), "mean")])
+def test_any_patch_size_goes_through_the_hipfft_fallback(n, shape, pad_mode):
+    """The reference takes every square patch size, odd ones included (transform.py:151-164); sizes without a
+    hand-written plan run gather -> hipFFT -> x K -> hipFFT -> overlap-add and meet the same tolerance."""
+    rng = np.random.default_rng(n)
+    coords = [tuple(int(v) for v in c) for c in rp.calculate_covering(shape, n)]
+    k = (rng.standard_normal((len(coords), n, n)) + 1j * rng.standard_normal((len(coords), n, n))).astype(np.complex64)
+    image = (rng.standard_normal(shape) * 10 + 40).astype(np.float32)
+    t = rp.ArrayPSFTransform(rp.IndexedCube(coords, k))
+    out = t.apply(image, pad_mode=pad_mode)
+    check(out, orc.apply_transfer(image, coords, k, pad_mode=pad_mode))
+    stack = t.apply_batch(np.stack([image, image[::-1].copy()]), pad_mode="symmetric")
+    check(stack[1], orc.apply_transfer(image[::-1], coords, k))
+    assert t.apply(image, saturation_threshold=55.0).shape == shape  # host-padded route (shifted origin) also works
