@@ -217,18 +217,26 @@ class Plan:
         check(lib().rpsf_apply(self._handle, _ptr(img), img.shape[0], img.shape[1], pad_mode, pad_value, _ptr(out)))
         return out
 
-    def apply_host(self, image: np.ndarray, pad_mode: int, pad_value: float = 0.0, out_dtype=np.float64) -> np.ndarray:
+    def apply_host(self, image: np.ndarray, pad_mode: int, pad_value: float = 0.0, out_dtype=np.float64,
+                   out: np.ndarray | None = None) -> np.ndarray:
         """Host array in (float32/float64 taken as they are, anything else through float32), host array out
-        (float64 like the reference, or float32); dtype conversions happen inside the library."""
+        (float64 like the reference, or float32); dtype conversions happen inside the library.  ``out``: an
+        existing C-contiguous float32/float64 array of the image's shape to write into."""
         img = np.asarray(image)
         if img.dtype not in (np.float32, np.float64) or img.dtype.byteorder == ">":
             img = img.astype(np.float32)
         img = np.ascontiguousarray(img)
+        if out is not None:
+            if out.shape != img.shape or not out.flags.c_contiguous or not out.flags.writeable:
+                msg = "out must be a writeable C-contiguous array of the image's shape"
+                raise ValueError(msg)
+            out_dtype = out.dtype
         out_dtype = np.dtype(out_dtype)
         if out_dtype not in (np.float32, np.float64):
             msg = "out_dtype must be float32 or float64"
             raise ValueError(msg)
-        out = np.empty(img.shape, out_dtype)
+        if out is None:
+            out = np.empty(img.shape, out_dtype)
         check(lib().rpsf_apply_host(self._handle, _ptr(img), int(img.dtype == np.float64), img.shape[0], img.shape[1],
                                     pad_mode, pad_value, _ptr(out), int(out_dtype == np.float64)))
         return out

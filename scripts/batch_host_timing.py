@@ -18,3 +18,10 @@ for rep in range(2):
     b = plan.apply_batch(images, pad); t2 = time.perf_counter()
     print(f"{frames} frames {h}x{w}: loop over rpsf_apply {1e3*(t1-t0):.1f} ms ({frames*h*w/(t1-t0)/1e6:.0f} Mpx/s), "
           f"rpsf_apply_batch {1e3*(t2-t1):.1f} ms ({frames*h*w/(t2-t1)/1e6:.0f} Mpx/s), identical: {np.array_equal(np.stack(a), b)}")
+
+import regularizepsf_amd as rp
+t = rp.ArrayPSFTransform(rp.IndexedCube(coords, k))
+t.apply_batch(images[:2]); t.apply_batch(images[:2], dtype=np.float32)
+for dt in (np.float64, np.float32):
+    t0 = time.perf_counter(); o = t.apply_batch(images, dtype=dt); t1 = time.perf_counter()
+    print(f"ArrayPSFTransform.apply_batch -> {np.dtype(dt).name}: {1e3*(t1-t0):.1f} ms ({frames*h*w/(t1-t0)/1e6:.0f} Mpx/s)")
