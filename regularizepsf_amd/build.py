@@ -9,7 +9,7 @@ import sys
 
 PKG = pathlib.Path(__file__).resolve().parent
 SOURCES = [PKG / "csrc" / "rpsf.hip"]
-HEADERS = [PKG / "csrc" / "rpsf_core.hpp", PKG.parent / "include" / "rpsf.h"]
+HEADERS = [PKG / "csrc" / "rpsf_core.hpp", PKG / "csrc" / "rpsf_kernels.hpp", PKG.parent / "include" / "rpsf.h"]
 TARGET = PKG / "librpsf_hip.so"
 
 

@@ -1,6 +1,7 @@
-// rpsf.hip - HIP kernels (gfx950) and the C ABI of include/rpsf.h.
+// rpsf.hip - host side of librpsf_hip.so: plans, launches and the C ABI of include/rpsf.h; the RCCL and
+// hipFFT loaders.  The device code is in rpsf_kernels.hpp (kernels) and rpsf_core.hpp (per-thread phases).
 //
-// Kernels:
+// Kernels (rpsf_kernels.hpp):
 //   patch_kernel<C>        K1: fused gather+pad+window -> 2-D DFT -> x folded K -> inverse DFT -> window ->
 //                          overlap-add; one workgroup per patch (or several small patches per workgroup),
 //                          patch resident in registers, LDS used only for the inter-stage transposes.
@@ -11,6 +12,7 @@
 //   psf_fft_kernel<C>      K3: psf.py:216-219, forward half of K1 written out as a full spectrum.
 //   add_rows_kernel        K4: seam accumulate for the multi-GPU row-band split.
 //   sum_planes_kernel      K5: output = sum of the four colour planes the patches of one parity class write.
+//   generic_*_kernel       gather / multiply / scatter around hipFFT for patch sizes without a plan.
 // Development-only build switches (never set by regularizepsf_amd/build.py): RPSF_STAMPS (per-phase
 // timestamps, scripts/stamps.py), RPSF_ABL_NOK / _NOLOAD / _NOSTORE / _NOATOMIC (traffic ablations: results
 // are wrong, timing only), RPSF_ONLY_N / RPSF_ONLY_CFG (single-plan library for quick A/B builds),
@@ -52,490 +54,7 @@ static int fail(int code, const std::string& msg) {
 
 extern "C" const char* rpsf_last_error(void) { return g_err.c_str(); }
 
-// ------------------------------------------------------------------------------------------------
-// K5: out = sum of the colour planes that have a patch over the pixel (fixed order: deterministic)
-// ------------------------------------------------------------------------------------------------
-struct SumParams {
-  const float* planes;
-  size_t plane_stride;
-  float* out;
-  int rows, W, ld_planes, ld_out;
-  int row_begin;       // first window row this launch sums
-  int row0;            // full-image row of window row 0
-  int lat_r0, lat_c0;  // full-image coordinates of lattice tile (0, 0)
-  int half_shift;      // log2(N/2)
-  int nti, ntj;
-  const uint8_t* cover;  // nti x ntj, 4-bit class masks
-  size_t planes_frame_floats, out_frame_floats;  // batch: frame f (= blockIdx.y) at planes + f*..., out + f*...
-};
-
-__device__ __forceinline__ int cover_at(const SumParams& p, int y, int x) {
-  int ty = (y - p.lat_r0) >> p.half_shift, tx = (x - p.lat_c0) >> p.half_shift;
-  if (y < p.lat_r0 || x < p.lat_c0 || ty >= p.nti || tx >= p.ntj) return 0;
-  return p.cover[ty * p.ntj + tx];
-}
-
-__device__ __forceinline__ bool sum_vector_ok(const SumParams& p) {
-  return ((p.ld_planes | p.ld_out) & 3) == 0 &&
-         ((reinterpret_cast<uintptr_t>(p.planes) | reinterpret_cast<uintptr_t>(p.out) | (p.plane_stride * 4)) & 15) == 0;
-}
-// Branch-free 16-byte read of plane k: a plane without a patch over the tile is never read (its content is
-// stale) - the load is redirected to one always-valid line and its result discarded.  Keeping the loads
-// unconditional matters: a load under a branch is waited for at the join, which serialises the four planes.
-__device__ __forceinline__ float4 load_plane4(const SumParams& p, int k, size_t off, int cov) {
-  const bool on = (cov >> k) & 1;
-  const float* src = on ? p.planes + k * p.plane_stride + off : p.planes;
-  typedef float f4 __attribute__((ext_vector_type(4)));
-  f4 a = __builtin_nontemporal_load(reinterpret_cast<const f4*>(src));
-  return make_float4(on ? a.x : 0.f, on ? a.y : 0.f, on ? a.z : 0.f, on ? a.w : 0.f);
-}
-__device__ __forceinline__ void store_out4(float* o, float4 v) {
-  typedef float f4 __attribute__((ext_vector_type(4)));
-  f4 w = {v.x, v.y, v.z, v.w};
-  __builtin_nontemporal_store(w, reinterpret_cast<f4*>(o));
-}
-
-// four consecutive pixels (x .. x+3) of window row yl
-__device__ __forceinline__ void sum_planes_group(const SumParams& p, int yl, int x, bool vector_ok) {
-  int y = yl + p.row0;
-  size_t off = (size_t)yl * p.ld_planes + x;
-  float* o = p.out + (size_t)yl * p.ld_out + x;
-  int c0 = cover_at(p, y, x), c3 = cover_at(p, y, x + 3);
-  if (vector_ok && x + 3 < p.W && c0 == c3) {  // one tile, aligned: four 16-byte loads, one 16-byte store
-    float4 a0 = load_plane4(p, 0, off, c0), a1 = load_plane4(p, 1, off, c0), a2 = load_plane4(p, 2, off, c0),
-           a3 = load_plane4(p, 3, off, c0);
-    store_out4(o, make_float4(((a0.x + a1.x) + a2.x) + a3.x, ((a0.y + a1.y) + a2.y) + a3.y,
-                              ((a0.z + a1.z) + a2.z) + a3.z, ((a0.w + a1.w) + a2.w) + a3.w));
-  } else {
-    for (int i = 0; i < 4 && x + i < p.W; ++i) o[i] = sum_planes_at(p.planes, p.plane_stride, off + i, cover_at(p, y, x + i));
-  }
-}
-
-__global__ void sum_planes_kernel(SumParams p) {
-  p.planes += (size_t)blockIdx.y * p.planes_frame_floats;
-  p.out += (size_t)blockIdx.y * p.out_frame_floats;
-  const unsigned groups = (unsigned)(p.W + 3) >> 2;
-  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (size_t)groups * p.rows) return;
-  const bool small = (size_t)groups * p.rows < ((size_t)1 << 32);
-  const int yl = small ? (int)((unsigned)idx / groups) : (int)(idx / groups);
-  const int xg = small ? (int)((unsigned)idx % groups) : (int)(idx % groups);
-  sum_planes_group(p, yl + p.row_begin, xg * 4, sum_vector_ok(p));
-}
-
-// the same work done by `nblocks` co-operating workgroups of a larger launch (grid-stride).  These
-// workgroups are as register-heavy as the patch kernel (one per CU), so each thread keeps eight
-// independent 4-pixel groups (32 loads) in flight to cover the HBM latency.
-__device__ __forceinline__ void sum_planes_worker(const SumParams& p, int block, int nblocks) {
-  const unsigned groups = (unsigned)(p.W + 3) >> 2;
-  const size_t total = (size_t)groups * p.rows;
-  const size_t stride = (size_t)nblocks * blockDim.x;
-  size_t idx = (size_t)block * blockDim.x + threadIdx.x;
-  const bool vector_ok = sum_vector_ok(p) && (p.W & 3) == 0;
-  const bool small = total < ((size_t)1 << 32);
-  constexpr int SU = 8;
-  if (vector_ok) {
-    for (; idx + (SU - 1) * stride < total; idx += SU * stride) {
-      int cov[SU], yl[SU], x[SU];
-      bool uniform = true;
-#pragma unroll
-      for (int u = 0; u < SU; ++u) {
-        size_t i = idx + u * stride;
-        yl[u] = (small ? (int)((unsigned)i / groups) : (int)(i / groups)) + p.row_begin;
-        x[u] = (small ? (int)((unsigned)i % groups) : (int)(i % groups)) * 4;
-        cov[u] = cover_at(p, yl[u] + p.row0, x[u]);
-        uniform = uniform && cov[u] == cover_at(p, yl[u] + p.row0, x[u] + 3);
-      }
-      if (!uniform) {  // a group straddles two lattice tiles: generic path
-#pragma unroll
-        for (int u = 0; u < SU; ++u) sum_planes_group(p, yl[u], x[u], true);
-        continue;
-      }
-      float4 v[SU][4];
-#pragma unroll
-      for (int u = 0; u < SU; ++u)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[u][k] = load_plane4(p, k, (size_t)yl[u] * p.ld_planes + x[u], cov[u]);
-#pragma unroll
-      for (int u = 0; u < SU; ++u)
-        store_out4(p.out + (size_t)yl[u] * p.ld_out + x[u],
-                   make_float4(((v[u][0].x + v[u][1].x) + v[u][2].x) + v[u][3].x, ((v[u][0].y + v[u][1].y) + v[u][2].y) + v[u][3].y,
-                               ((v[u][0].z + v[u][1].z) + v[u][2].z) + v[u][3].z, ((v[u][0].w + v[u][1].w) + v[u][2].w) + v[u][3].w));
-    }
-  }
-  for (; idx < total; idx += stride)
-    sum_planes_group(p, (int)(idx / groups) + p.row_begin, (int)(idx % groups) * 4, vector_ok);
-}
-
-// ------------------------------------------------------------------------------------------------
-// K1
-// ------------------------------------------------------------------------------------------------
-struct PatchParams {
-  ImageView im;
-  OutView ov;
-  int origin_row, origin_col;
-  const int4* desc;         // per processing-order slot: {corner row, corner col, patch index, colour plane}
-                            // (one 16-byte load instead of the order -> coords -> plane pointer chase)
-  int chunk;                // patches per XCD chunk
-  int seq_base;             // first processing-order slot of this launch (the apply may be split in two launches)
-  int patch_blocks;         // blocks [0, patch_blocks) process patches; blocks beyond it sum colour planes
-  SumParams sum;            // (tail launch: the rows the tail patches do not touch are summed by the idle CUs)
-  unsigned long long* stamps;  // diagnostic builds (RPSF_STAMPS): 16 phase timestamps per patch
-  int stagger_ticks;        // start-up stagger of the first resident workgroups, in 10 ns ticks (0 = off)
-  int stagger_blocks;       // how many leading blocks are staggered (= resident workgroup capacity)
-  int n_patches;
-  int n_frames;             // batch: every patch slot is processed for n_frames frames that share the transfer kernel
-  size_t im_frame_floats;   // frame f reads im.img + f * im_frame_floats ...
-  size_t ov_frame_floats;   // ... and writes ov.out + f * ov_frame_floats
-  const uint16_t* tab;
-  const cf* tw;
-  const float* win;
-  const cf* g;
-  const cf* gs;
-};
-
-template <class C>
-struct Launch {
-  static constexpr int WG = C::T < 64 ? 64 : C::T;
-  static constexpr int TEAMS = WG / C::T;
-  static constexpr int TABLE_FLOATS = 3 * C::N;  // twiddles (N complex) + window (N), shared by the workgroup
-  static constexpr size_t LDS_BYTES = (size_t)(TABLE_FLOATS + TEAMS * C::LDS_FLOATS) * sizeof(float);
-  // Waves per SIMD the kernel is compiled for.  Where LDS already limits a CU to four single-wave workgroups
-  // (N = 64: each team parks its whole patch), one wave per SIMD may as well use the other half of the
-  // register file: spills then go to AGPRs instead of scratch memory.
-  static constexpr int WAVES_PER_SIMD = (WG == 64 && 4 * LDS_BYTES <= 160 * 1024 && 5 * LDS_BYTES > 160 * 1024) ? 1 : 2;
-  static_assert(C::KDEPTH == 1 || WAVES_PER_SIMD == 1, "two K chunks in flight need the 512-register budget");
-};
-
-
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also makes hipcc drain every
-// outstanding global load/store (s_waitcnt vmcnt(0)), which would expose the HBM latency of the K
-// prefetch and of the plane stores at each of the ~20 exchange barriers of a patch.
-// Orders one wave's own LDS traffic (a wave's DS operations complete in order; no other wave is involved).
-__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-#if defined(RPSF_STAMPS)
-#define STAMP(i)                                                                                         \
-  do {                                                                                                   \
-    if (threadIdx.x == 0) p.stamps[(size_t)patch * 16 + (i)] = __builtin_amdgcn_s_memrealtime();          \
-  } while (0)
-#else
-#define STAMP(i) ((void)0)
-#endif
-
-template <class C>
-__global__ __launch_bounds__(Launch<C>::WG, Launch<C>::WAVES_PER_SIMD) void patch_kernel(PatchParams p) {  // 2 waves per SIMD: 256 registers
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int T = C::T;
-  if ((int)blockIdx.x >= p.patch_blocks) {  // workgroup-uniform
-    sum_planes_worker(p.sum, blockIdx.x - p.patch_blocks, gridDim.x - p.patch_blocks);
-    return;
-  }
-  const int team = threadIdx.x / T, t = threadIdx.x % T;
-  // Blocks are dealt round-robin over the 8 XCDs (b and b+8 share one).  `order` lists the patches
-  // along a Z-order curve of the lattice, cut into 8 contiguous chunks: XCD x works through chunk x,
-  // so the four patches that overlap a pixel usually read it through the same L2.  Speed only.
-  // Batch: the n_frames workgroups of one patch slot are consecutive on their XCD, so the slot's packed
-  // K comes from HBM once and from that XCD's L2 for the other frames.
-  int frame = 0, xrow = blockIdx.x >> 3;
-  if (p.n_frames > 1) {
-    frame = xrow % p.n_frames;
-    xrow /= p.n_frames;
-  }
-  ImageView im = p.im;
-  OutView ov = p.ov;
-  im.img += (size_t)frame * p.im_frame_floats;
-  ov.out += (size_t)frame * p.ov_frame_floats;
-  const int slot = xrow * Launch<C>::TEAMS + team;
-  const int seq = (blockIdx.x & 7) * p.chunk + slot;
-  const bool active = slot < p.chunk && seq < p.n_patches;
-  const int4 dsc = p.desc[p.seq_base + (active ? seq : p.n_patches - 1)];  // inactive teams stay in step with the barriers
-  const int patch = dsc.z;
-  // De-phase the chip: without this every CU gathers, streams K and stores at the same instants, HBM
-  // alternates between saturated and idle, and no memory phase overlaps any compute phase.  Delaying
-  // the first resident workgroup of each CU by a different amount spreads the phases for the whole
-  // launch (later workgroups inherit the offset of the one they replace).  Speed only.
-  if (p.stagger_ticks > 0 && (int)blockIdx.x < p.stagger_blocks) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    const unsigned long long wait = (unsigned long long)(((blockIdx.x >> 3) * 0x9E3779B1u >> 22) & 1023) * p.stagger_ticks >> 10;
-    while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
-  }
-  float* lds = smem + Launch<C>::TABLE_FLOATS + team * C::LDS_FLOATS;
-  STAMP(0);
-  const int pr = dsc.x + p.origin_row, pc = dsc.y + p.origin_col;
-  const cf* g = p.g + (size_t)patch * C::G_PER_PATCH;
-  cf v[64];
-#if defined(RPSF_ABL_NOLOAD)
-#pragma unroll
-  for (int j = 0; j < 64; ++j) v[j] = cf{(float)(t + j), (float)(t - j)};
-#endif
-  const bool fast = patch_inside<C>(pr, pc, im.H, im.W, im.row0, im.rows) && pairs_aligned(im.img, im.ld, pc);
-  // twiddle and window tables live in LDS: their reads must not queue behind the patch's global loads
-  cf* tw = reinterpret_cast<cf*>(smem);
-  float* win = smem + 2 * C::N;
-  for (int i = threadIdx.x; i < C::N; i += Launch<C>::WG) {
-    tw[i] = p.tw[i];
-    win[i] = p.win[i];
-  }
-  GroupIds<C> gids;
-  gids.load(p.tab, t);
-#if !defined(RPSF_ABL_NOLOAD)
-  {
-    int* maps = reinterpret_cast<int*>(lds);
-    if (!fast) build_pad_maps<C>(t, maps, im, pr, pc);
-    lds_barrier();
-    // (VMEM returns in order: issuing these loads before the table staging above would make the tables
-    //  wait for all 64 of them and lose the load -> stage-1 overlap; measured 9.0 -> 12.8 us)
-    load_patch<C>(t, v, im, pr, pc, win, fast, maps);
-    lds_barrier();  // the maps share LDS with the exchange buffer
-  }
-#endif
-  STAMP(1);
-  stage1<C, false>(t, v, tw);
-  STAMP(2);
-  if constexpr (C::S3) {
-    // X1 is a register<->lane transpose inside each wave (private LDS region): wave-level ordering is enough
-    x1_write<C, 0>(t, v, lds);
-    wave_lds_sync();
-    x1_read<C, 0>(t, v, lds);
-    wave_lds_sync();
-    x1_write<C, 1>(t, v, lds);
-    wave_lds_sync();
-    x1_read<C, 1>(t, v, lds);
-    STAMP(3);
-    stage2<C, false>(t, v, tw);
-    STAMP(4);
-  }
-  KRing<C> kring;
-  kring_fill<C>(t, kring, g);  // first K slots: in flight across the exchange below (raw barriers do not drain VMEM)
-  lds_barrier();  // every wave has left its X1 region (X2 uses the whole buffer)
-  x2_mid_write<C, 0>(t, v, lds);
-  lds_barrier();
-  x2_last_read<C, 0>(gids, v, lds);
-  lds_barrier();
-  x2_mid_write<C, 1>(t, v, lds);
-  lds_barrier();
-  x2_last_read<C, 1>(gids, v, lds);
-  // no barrier: every X2 word is read by exactly one thread, the same one that rewrites it below
-
-  STAMP(5);
-  {
-    STAMP(6);
-    STAMP(7);
-    freq_step<C>(t, gids, v, kring, g, p.gs + (size_t)patch * C::GS_PER_PATCH, tw, reinterpret_cast<cf*>(lds + C::PARK_OFFSET));
-    STAMP(8);
-  }
-
-  x2_last_write<C, 0>(gids, v, lds);
-  lds_barrier();
-  x2_mid_read<C, 0>(t, v, lds);
-  lds_barrier();
-  x2_last_write<C, 1>(gids, v, lds);
-  lds_barrier();
-  x2_mid_read<C, 1>(t, v, lds);
-  lds_barrier();
-  STAMP(9);
-  if constexpr (C::S3) {
-    stage2<C, true>(t, v, tw);
-    STAMP(10);
-    x1_write<C, 0>(t, v, lds);
-    wave_lds_sync();
-    x1_read<C, 0>(t, v, lds);
-    wave_lds_sync();
-    x1_write<C, 1>(t, v, lds);
-    wave_lds_sync();
-    x1_read<C, 1>(t, v, lds);
-  }
-  STAMP(11);
-  stage1<C, true>(t, v, tw);
-  STAMP(12);
-  if (active) {
-    const int plane = ov.plane_stride ? dsc.w : 0;
-#if defined(RPSF_ABL_NOSTORE)
-    {  // keep every value live but store (almost) nothing
-      float acc = 0.f;
-#pragma unroll
-      for (int j = 0; j < 64; ++j) acc += v[j].x * v[j].y;
-      if (acc == 123456.789f) ov.out[threadIdx.x] = acc;
-    }
-#elif defined(RPSF_ABL_NOATOMIC)
-    store_patch<C>(t, v, ov, plane, pr, pc, win, [](float* a, float val) { *a = val; });
-#else
-    store_patch<C>(t, v, ov, plane, pr, pc, win, [](float* a, float val) { unsafeAtomicAdd(a, val); });
-#endif
-  }
-  STAMP(13);
-}
-
-// ------------------------------------------------------------------------------------------------
-// K-pack
-// ------------------------------------------------------------------------------------------------
-template <class C>
-__global__ void pack_kernel(const cf* __restrict__ kfull, int n_patches, const uint16_t* __restrict__ tab,
-                            cf* __restrict__ g, cf* __restrict__ gs) {
-  const size_t per = (size_t)C::G_PER_PATCH;
-  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= per * n_patches) return;
-  int patch = (int)(idx / per);
-  int rem = (int)(idx % per);
-  int b = rem & 1, t = (rem >> 1) % C::T, i = (rem >> 1) / C::T;
-  int rho = 2 * i + b;
-  const cf* kf = kfull + (size_t)patch * C::N * C::N;
-  g[idx] = pack_value<C>(kf, tab, t, rho, 0);
-  if constexpr (!C::INLINE_GS) {
-    const int w = rho >> 1, s = w / C::E, e = w % C::E;
-    if (slot_is_special<C>(s, t))
-      gs[(size_t)patch * C::GS_PER_PATCH + (size_t)C::spec_prefix(s) * 2 * C::E + ((size_t)e * C::spec_t(s) + t) * 2 + b] =
-          pack_value<C>(kf, tab, t, rho, 1);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K2: transform.py:78-82.  Mirrors NumPy's evaluation order: |.| by hypot, scalar powers with
-// NumPy's fast paths (0, 1, 2, 0.5, -1), complex * real as a full complex product with (r, 0),
-// complex / real as NumPy's scaled division, then a plain complex product with T.
-// ------------------------------------------------------------------------------------------------
-template <class R>
-__device__ __forceinline__ R np_pow(R x, R e) {
-  if (e == R(0)) return R(1);
-  if (e == R(1)) return x;
-  if (e == R(2)) return x * x;
-  if (e == R(0.5)) return sqrt(x);
-  if (e == R(-1)) return R(1) / x;
-  return pow(x, e);
-}
-
-template <class R>
-__global__ void build_transfer_kernel(const R* __restrict__ s, const R* __restrict__ t, R* __restrict__ k,
-                                      size_t count, R alpha, R eps) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  R sr = s[2 * i], si = s[2 * i + 1], tr = t[2 * i], ti = t[2 * i + 1];
-  R sabs = hypot(sr, si), tabs = hypot(tr, ti);
-  R pw = np_pow(sabs, alpha - R(1));
-  // conj(S) * (pw + 0i)
-  R cr = sr, ci = -si;
-  R nr = cr * pw - ci * R(0), ni = cr * R(0) + ci * pw;
-  R den = np_pow(sabs, alpha + R(1)) + np_pow(eps * tabs, alpha + R(1));
-  // (nr + i ni) / (den + 0i), NumPy's algorithm for |re| >= |im|
-  R qr, qi;
-  if (fabs(den) == R(0)) {
-    qr = nr / fabs(den);
-    qi = ni / fabs(den);
-  } else {
-    R rat = R(0) / den;
-    R scl = R(1) / (den + R(0) * rat);
-    qr = (nr + ni * rat) * scl;
-    qi = (ni - nr * rat) * scl;
-  }
-  k[2 * i] = qr * tr - qi * ti;
-  k[2 * i + 1] = qr * ti + qi * tr;
-}
-
-// ------------------------------------------------------------------------------------------------
-// K3: batched 2-D FFT of real N x N arrays -> full N x N complex spectrum (psf.py:216-219)
-// ------------------------------------------------------------------------------------------------
-template <class C>
-__global__ __launch_bounds__(Launch<C>::WG) void psf_fft_kernel(const float* __restrict__ values, int count,
-                                                                 const uint16_t* __restrict__ tab,
-                                                                 const cf* __restrict__ tw, cf* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int T = C::T, N = C::N, NC = C::NC, E = C::E;
-  const int team = threadIdx.x / T, t = threadIdx.x % T;
-  int item = blockIdx.x * Launch<C>::TEAMS + team;
-  const bool active = item < count;
-  if (!active) item = count - 1;
-  float* lds = smem + team * C::LDS_FLOATS;
-  GroupIds<C> gids;
-  gids.load(tab, t);
-  const float* src = values + (size_t)item * N * N;
-  cf v[64];
-  {
-    ThreadPos<C> tp(t);
-    constexpr int NR = 1 << C::A1, NCOL = 1 << C::B1;
-    StaticFor<0, NR>::run([&]<int R1>() RPSF_AI {
-      int r = (R1 << (C::A2 + C::AL)) + tp.r_rest;
-      StaticFor<0, NCOL>::run([&]<int C1>() RPSF_AI {
-        int c = (C1 << (C::B2 + C::BL)) + tp.c_rest;
-        v[R1 * NCOL + C1] = cf{src[(size_t)r * N + 2 * c], src[(size_t)r * N + 2 * c + 1]};
-      });
-    });
-  }
-  stage1<C, false>(t, v, tw);
-  if constexpr (C::S3) {
-    x1_write<C, 0>(t, v, lds);
-    __syncthreads();
-    x1_read<C, 0>(t, v, lds);
-    __syncthreads();
-    x1_write<C, 1>(t, v, lds);
-    __syncthreads();
-    x1_read<C, 1>(t, v, lds);
-    __syncthreads();
-    stage2<C, false>(t, v, tw);
-  }
-  x2_mid_write<C, 0>(t, v, lds);
-  __syncthreads();
-  x2_last_read<C, 0>(gids, v, lds);
-  __syncthreads();
-  x2_mid_write<C, 1>(t, v, lds);
-  __syncthreads();
-  x2_last_read<C, 1>(gids, v, lds);
-  stage_last<C, false>(v);
-  if (!active) return;
-  cf* dst = out + (size_t)item * N * N;
-  // unpack X[kr][kc] = E + W^kc O and X[kr][kc + N/2] = E - W^kc O for every bin this thread holds
-  StaticFor<0, C::NSLOT>::run([&]<int S>() RPSF_AI {
-    cf* za = v + (2 * S) * E;
-    cf* zb = za + E;
-    int ga = gids[2 * S], gb = gids[2 * S + 1];
-    bool self = partner_gid<C>(ga) == ga;
-    int qa, ma, qb, mb;
-    gid_to_qm<C>(ga, qa, ma);
-    gid_to_qm<C>(gb, qb, mb);
-    const bool qza = qa == 0, qzb = qb == 0, mza = ma == 0, mzb = mb == 0;
-    StaticFor<0, E>::run([&]<int EE>() RPSF_AI {
-      constexpr int EA = C::EA, EB = C::EB, K3 = EE / EB, L3 = EE % EB;
-      constexpr int RR = (EA - 1 - K3) * EB + (EB - 1 - L3), ZR = ((EA - K3) % EA) * EB + (EB - 1 - L3);
-      constexpr int RZ = (EA - 1 - K3) * EB + (EB - L3) % EB, ZZ = ((EA - K3) % EA) * EB + (EB - L3) % EB;
-      auto pick = [&](const cf* src, bool qz, bool mz) RPSF_AI {
-        cf rr = src[RR], zr = src[ZR], rz = src[RZ], zz = src[ZZ];
-        return sel(mz, sel(qz, zz, rz), sel(qz, zr, rr));
-      };
-      cf pa = sel(self, pick(za, qza, mza), pick(zb, qza, mza));
-      cf pb = sel(self, pick(zb, qzb, mzb), pick(za, qzb, mzb));
-      {
-        const int kr = qa + C::Q * K3, kc = ma + C::M * L3;
-        cf zc = cconj(pa);
-        cf e2 = (za[EE] + zc) * 0.5f, wo = cmul(tw[kc], mul_mi(za[EE] - zc)) * 0.5f;
-        dst[(size_t)kr * N + kc] = e2 + wo;
-        dst[(size_t)kr * N + kc + NC] = e2 - wo;
-      }
-      {
-        const int kr = qb + C::Q * K3, kc = mb + C::M * L3;
-        cf zc = cconj(pb);
-        cf e2 = (zb[EE] + zc) * 0.5f, wo = cmul(tw[kc], mul_mi(zb[EE] - zc)) * 0.5f;
-        dst[(size_t)kr * N + kc] = e2 + wo;
-        dst[(size_t)kr * N + kc + NC] = e2 - wo;
-      }
-    });
-  });
-}
-
-// ------------------------------------------------------------------------------------------------
-// K4: accum[i] += src[i]
-// ------------------------------------------------------------------------------------------------
-__global__ void add_rows_kernel(float* __restrict__ accum, const float* __restrict__ src, size_t count) {
-  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (i + 3 < count) {
-    float4 a = *reinterpret_cast<float4*>(accum + i);
-    float4 b = *reinterpret_cast<const float4*>(src + i);
-    a.x += b.x, a.y += b.y, a.z += b.z, a.w += b.w;
-    *reinterpret_cast<float4*>(accum + i) = a;
-  } else {
-    for (; i < count; ++i) accum[i] += src[i];
-  }
-}
+#include "rpsf_kernels.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // plan
@@ -799,39 +318,6 @@ struct HipfftApi {
   }
 };
 static HipfftApi g_hipfft;
-
-struct GenericGeom {
-  int N, first, count;         // patches [first, first + count) of the plan
-  int origin_row, origin_col;
-  ImageView im;
-  OutView ov;
-};
-// one thread per (patch, r, c) of the chunk
-__global__ void generic_gather_kernel(GenericGeom gg, const int32_t* __restrict__ coords, const float* __restrict__ win,
-                                      cf* __restrict__ buf) {
-  const size_t per = (size_t)gg.N * gg.N;
-  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= per * gg.count) return;
-  const int k = (int)(idx / per), rem = (int)(idx % per), r = rem / gg.N, c = rem % gg.N;
-  const int y = pad_index(coords[2 * (gg.first + k)] + gg.origin_row + r, gg.im.H, gg.im.pad_mode);
-  const int x = pad_index(coords[2 * (gg.first + k) + 1] + gg.origin_col + c, gg.im.W, gg.im.pad_mode);
-  const float px = (y < 0 || x < 0) ? gg.im.pad_value : gg.im.img[(size_t)(y - gg.im.row0) * gg.im.ld + x];
-  buf[idx] = cf{px * (win[r] * win[c]), 0.0f};
-}
-__global__ void generic_multiply_kernel(cf* __restrict__ buf, const cf* __restrict__ k, size_t count, float scale) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < count) buf[i] = cmul(buf[i], k[i]) * scale;
-}
-__global__ void generic_scatter_kernel(GenericGeom gg, const int32_t* __restrict__ coords, const float* __restrict__ win,
-                                       const cf* __restrict__ buf) {
-  const size_t per = (size_t)gg.N * gg.N;
-  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= per * gg.count) return;
-  const int k = (int)(idx / per), rem = (int)(idx % per), r = rem / gg.N, c = rem % gg.N;
-  const int y = coords[2 * (gg.first + k)] + gg.origin_row + r, x = coords[2 * (gg.first + k) + 1] + gg.origin_col + c;
-  if (y < 0 || y >= gg.ov.H || x < 0 || x >= gg.ov.W) return;  // the crop of transform.py:174-177
-  unsafeAtomicAdd(gg.ov.out + (size_t)(y - gg.ov.row0) * gg.ov.ld + x, buf[idx].x * (win[r] * win[c]));
-}
 
 extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int n_patches, const int32_t* coords_rc) {
   if (!out || !coords_rc) return fail(RPSF_E_BADARG, "null argument");
