@@ -6,10 +6,12 @@ One "step" = one full apply (output clear + fused patch kernel) of the headline 
 (BASELINE.json configs[2]: 4096x4096 image, 256x256 patches, 1089-patch lattice, coma PSF grid ->
 Gaussian target, alpha=3, eps=0.1) with image, output and packed transfer kernel resident in HBM.
 For N > 1 (launched by torch.distributed.run, one process per GPU) the image grows to (4096*N) x 4096
-and is split into N row bands of the patch lattice; each rank runs its band and the seam rows are
-exchanged with RCCL send/recv (weak scaling: per-GPU work is fixed).  torch is used here only for the
-launcher's rendezvous: a gloo group broadcasts the 128-byte RCCL unique id; the compute path and the
-seam exchange are ctypes -> librpsf_hip.so (RCCL is loaded by the library itself).
+and is split into N row bands of the patch lattice (weak scaling: per-GPU work is fixed).  The seam between
+two bands is handled without a data-path collective by default (`--seam recompute`: a band also runs the one
+lattice row above it that reaches into its rows, +3 % patches); `--seam exchange` sends the spill rows to the
+next rank with RCCL send/recv instead.  torch is used here only for the launcher's rendezvous: a gloo group
+broadcasts the 128-byte RCCL unique id; the compute path, the barrier/max-reduction around the timed region
+and the optional seam exchange are ctypes -> librpsf_hip.so (RCCL is loaded by the library itself).
 
 Prints ONE JSON line on rank 0 (see the "Measurement" section of DESIGN.md for every field).
 """
@@ -238,6 +240,10 @@ def main() -> None:
                          "multi-rank flow on a box with fewer GPUs than ranks")
     ap.add_argument("--verify", action="store_true", help="check every rank's owned rows against the CPU oracle")
     ap.add_argument("--frames", type=int, default=8, help="config 5: frames per GPU in one batch")
+    ap.add_argument("--seam", choices=["recompute", "exchange"], default="recompute",
+                    help="N > 1: 'recompute' - every band also runs the lattice row above it that reaches into its rows "
+                         "(no data-path collective, +3 %% patches); 'exchange' - the spill rows of a band are sent to the "
+                         "next rank with RCCL send/recv and added there")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -304,7 +310,7 @@ def main() -> None:
             comm = GlooSeam(rank, world, device)
     if args.config == 5:
         return run_batch(args, rank, world, device, comm)
-    shard = ShardedApply(coords, kernel_for, n, height, w, rank, world, device, comm, pad_mode=pad)
+    shard = ShardedApply(coords, kernel_for, n, height, w, rank, world, device, comm, pad_mode=pad, seam=args.seam)
     band = shard.band
     band_image = image_rows(band.image_row0, band.image_row0 + band.image_rows)
     shard.upload_rows(band_image)
@@ -368,7 +374,7 @@ def main() -> None:
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
             "workload": f"{height}x{w} starfield, {n}x{n} patches, {len(coords)} patches "
-                        f"({'whole image on one GPU' if world == 1 else f'{world} row bands, {args.comm.upper()} seam exchange'}), "
+                        f"({'whole image on one GPU' if world == 1 else f'{world} row bands, seam rows ' + ('recomputed by both neighbours (no data-path collective)' if args.seam == 'recompute' else f'exchanged over {args.comm.upper()}')}), "
                         f"coma PSF grid -> Gaussian target, alpha=3 eps=0.1, pad symmetric",
             "image": [height, w], "patch": n, "patches": len(coords), "device": name, "compute_units": cus,
             "resident": "image, output and packed transfer kernel in HBM before the timed region",

@@ -189,6 +189,16 @@ def test_row_bands_on_one_gpu(world):
         bufs[g][: bands[g].recv_rows] += bufs[g - 1][p.send_offset_rows : p.send_offset_rows + p.send_rows]
     got = np.concatenate([buf[: b.own_rows] for buf, b in zip(bufs, bands)])
     check(got, ref)
+    # seam="recompute": every band also runs the patches above it that reach into its rows; nothing to add afterwards
+    parts = []
+    for rank in range(world):
+        sh = ShardedApply(coords, lambda idx: k[idx], n, h, w, rank, world, 0, None, seam="recompute")
+        b = sh.band
+        assert b.send_rows == 0 and b.recv_rows == 0 and b.out_rows == b.own_rows
+        sh.upload_rows(image[b.image_row0 : b.image_row0 + b.image_rows])
+        sh.step()
+        parts.append(sh.owned_rows().astype(np.float64))
+    check(np.concatenate(parts), ref)
 
 
 def test_rccl_wrapper_single_rank():

@@ -55,6 +55,27 @@ def test_band_plans_partition_patches_and_rows(world):
         assert mapped.min() >= p.image_row0 and mapped.max() < p.image_row0 + p.image_rows
 
 
+@pytest.mark.parametrize("world", [1, 2, 3, 4])
+def test_recompute_bands_need_no_exchange(world):
+    """seam="recompute": a band runs every patch that reaches into its rows and keeps its own rows only."""
+    h, w, n, coords, k, image = small_case()
+    plans = make_band_plans(coords, n, h, world, seam="recompute")
+    assert sum(p.own_rows for p in plans) == h and all(p.send_rows == 0 and p.recv_rows == 0 for p in plans)
+    assert all(p.out_rows == p.own_rows for p in plans)
+    full = orc.apply_transfer(image, coords, k)
+    got = np.concatenate([band_buffer(p, image, coords, k) for p in plans])
+    assert np.allclose(got, full, rtol=0, atol=1e-9 * np.abs(full).max())
+    exchange = make_band_plans(coords, n, h, world)
+    extra = sum(len(p.patch_index) for p in plans) - sum(len(p.patch_index) for p in exchange)
+    assert extra == (world - 1) * len({c for _, c in coords})  # one lattice row recomputed per seam
+    for p in plans:
+        rows = [r for i in p.patch_index for r in range(coords[i][0], coords[i][0] + n)]
+        mapped = pad_rows(np.array(rows), h, "symmetric")
+        assert mapped.min() >= p.image_row0 and mapped.max() < p.image_row0 + p.image_rows
+    with pytest.raises(ValueError):
+        make_band_plans(coords, n, h, world, seam="magic")
+
+
 def test_headline_lattice_splits_into_eight_even_bands():
     coords = orc.calculate_covering((8 * 4096, 4096), 256)
     plans = make_band_plans(coords, 256, 8 * 4096, 8)
