@@ -27,6 +27,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -294,7 +295,9 @@ struct HipfftApi {
   int (*exec_c2c)(void*, void*, void*, int) = nullptr;
   int (*destroy)(void*) = nullptr;
   std::string error;
+  std::mutex guard;  // plans may be created from several threads
   bool load() {
+    std::lock_guard<std::mutex> lock(guard);
     if (lib) return true;
     if (!error.empty()) return false;
     for (const char* n : {"libhipfft.so", "libhipfft.so.0", "/opt/rocm/lib/libhipfft.so"}) {
@@ -1192,6 +1195,8 @@ static struct {
 } g_rccl;
 
 static int load_rccl() {
+  static std::mutex guard;  // communicators may be created from several threads
+  std::lock_guard<std::mutex> lock(guard);
   if (g_rccl.h) return RPSF_OK;
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   void* h = nullptr;
