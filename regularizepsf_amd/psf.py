@@ -26,11 +26,13 @@ class ArrayPSF:
         self._values_cube = values_cube
         self._workers = workers
         if fft_cube is None:
-            if device is None:
+            from regularizepsf_amd import _native
+
+            shape = values_cube.sample_shape
+            if device is None or shape[0] != shape[1] or shape[0] not in _native.SUPPORTED_PATCH_SIZES:
+                # reference backend; also for sample sizes the GPU spectrum kernel has no plan for
                 spectra = scipy.fft.fft2(values_cube.values, workers=workers)
             else:
-                from regularizepsf_amd import _native
-
                 spectra = _native.psf_fft(values_cube.values, device=device)
             fft_cube = IndexedCube(values_cube.coordinates, spectra)
         self._fft_cube = fft_cube
