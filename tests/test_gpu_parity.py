@@ -504,3 +504,27 @@ def test_any_patch_size_goes_through_the_hipfft_fallback(n, shape, pad_mode):
     stack = t.apply_batch(np.stack([image, image[::-1].copy()]), pad_mode="symmetric")
     check(stack[1], orc.apply_transfer(image[::-1], coords, k))
     assert t.apply(image, saturation_threshold=55.0).shape == shape  # host-padded route (shifted origin) also works
+
+
+def test_integration_stub_call_sequence():
+    """The reference-side binding shown in INTEGRATION.md, call for call (raw ctypes, no helper layer)."""
+    import ctypes
+
+    from regularizepsf_amd import build
+
+    fx, coords, k = load_apply_case("n32_sym")
+    lib = ctypes.CDLL(str(build.TARGET))
+    lib.rpsf_last_error.restype = ctypes.c_char_p
+    handle = ctypes.c_void_p()
+    c = np.ascontiguousarray(np.array(coords, np.int32))
+    assert lib.rpsf_plan_create(ctypes.byref(handle), 0, 32, len(c), c.ctypes.data_as(ctypes.c_void_p)) == 0, lib.rpsf_last_error()
+    kk = np.ascontiguousarray(k, np.complex64)
+    assert lib.rpsf_plan_set_transfer(handle, kk.ctypes.data_as(ctypes.c_void_p)) == 0, lib.rpsf_last_error()
+    img = np.ascontiguousarray(fx["image"], float)
+    out = np.empty_like(img)
+    pad = {"constant": 0, "symmetric": 1, "reflect": 2, "edge": 3, "wrap": 4}[str(fx["pad_mode"])]
+    rc = lib.rpsf_apply_host(handle, img.ctypes.data_as(ctypes.c_void_p), 1, img.shape[0], img.shape[1], pad,
+                             ctypes.c_float(0.0), out.ctypes.data_as(ctypes.c_void_p), 1)
+    assert rc == 0, lib.rpsf_last_error()
+    lib.rpsf_plan_destroy(handle)
+    check(out, fx["expected"])
