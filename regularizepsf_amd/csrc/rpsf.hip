@@ -366,8 +366,10 @@ extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int
     HIP_TRY(hipMemcpy(p->d_coords, coords_rc, sizeof(int32_t) * 2 * n_patches, hipMemcpyHostToDevice));
     p->h_coords.assign(coords_rc, coords_rc + 2 * (size_t)n_patches);
     HIP_TRY(hipMalloc(&p->d_sink, 128 * sizeof(float)));
+#if defined(RPSF_STAMPS)
     HIP_TRY(hipMalloc(&p->d_stamps, sizeof(unsigned long long) * 16 * (size_t)n_patches));
     HIP_TRY(hipMemset(p->d_stamps, 0, sizeof(unsigned long long) * 16 * (size_t)n_patches));
+#endif
     int rl = dispatch_n(N, [&]<class C>() -> int {
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_kernel<C>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)Launch<C>::LDS_BYTES));
@@ -694,6 +696,7 @@ extern "C" int rpsf_plan_set_overlap_mode(rpsf_plan* p, int mode) {
 // Diagnostic builds only (-DRPSF_STAMPS): copy out the 16 per-patch phase timestamps (10 ns ticks).
 extern "C" int rpsf_plan_debug_stamps(rpsf_plan* p, unsigned long long* host, size_t count) {
   if (!p || !host) return fail(RPSF_E_BADARG, "null argument");
+  if (!p->d_stamps) return fail(RPSF_E_STATE, "phase timestamps exist only in builds with -DRPSF_STAMPS");
   HIP_TRY(hipSetDevice(p->device));
   HIP_TRY(hipDeviceSynchronize());
   count = std::min(count, (size_t)16 * p->n_patches);
