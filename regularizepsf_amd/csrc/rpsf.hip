@@ -93,6 +93,7 @@ struct rpsf_plan {
   unsigned long long* d_stamps = nullptr;
   float* d_sink = nullptr;  // write-only scratch for the out-of-image pixels of rim patches
   // generic (hipFFT) plans: any patch size without a compiled kernel
+  int corner_min[2] = {0, 0}, corner_max[2] = {0, 0};  // extreme patch corners (row, col)
   bool generic = false;
   cf* d_kfull = nullptr;       // the caller's K, (n, N, N) complex64, unfolded
   cf* d_fft_buf = nullptr;     // fft_chunk x N x N complex work buffer
@@ -322,6 +323,15 @@ struct HipfftApi {
 };
 static HipfftApi g_hipfft;
 
+static void set_corner_extremes(rpsf_plan* p) {
+  for (int d = 0; d < 2; ++d) p->corner_min[d] = p->corner_max[d] = p->h_coords[d];
+  for (int i = 1; i < p->n_patches; ++i)
+    for (int d = 0; d < 2; ++d) {
+      p->corner_min[d] = std::min(p->corner_min[d], p->h_coords[2 * i + d]);
+      p->corner_max[d] = std::max(p->corner_max[d], p->h_coords[2 * i + d]);
+    }
+}
+
 extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int n_patches, const int32_t* coords_rc) {
   if (!out || !coords_rc) return fail(RPSF_E_BADARG, "null argument");
   if (n_patches <= 0) return fail(RPSF_E_BADARG, "n_patches must be positive");
@@ -342,6 +352,7 @@ extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int
       HIP_TRY(hipMalloc(&p->d_coords, sizeof(int32_t) * 2 * n_patches));
       HIP_TRY(hipMemcpy(p->d_coords, coords_rc, sizeof(int32_t) * 2 * n_patches, hipMemcpyHostToDevice));
       p->h_coords.assign(coords_rc, coords_rc + 2 * (size_t)n_patches);
+      set_corner_extremes(p);
       std::vector<float> win(N);
       for (int i = 0; i < N; ++i) win[i] = (float)std::sin((i + 0.5) * M_PI / N);  // transform.py:151-155
       HIP_TRY(hipMalloc(&p->d_win_generic, sizeof(float) * N));
@@ -365,6 +376,7 @@ extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int
     HIP_TRY(hipMalloc(&p->d_coords, sizeof(int32_t) * 2 * n_patches));
     HIP_TRY(hipMemcpy(p->d_coords, coords_rc, sizeof(int32_t) * 2 * n_patches, hipMemcpyHostToDevice));
     p->h_coords.assign(coords_rc, coords_rc + 2 * (size_t)n_patches);
+    set_corner_extremes(p);
     HIP_TRY(hipMalloc(&p->d_sink, 128 * sizeof(float)));
 #if defined(RPSF_STAMPS)
     HIP_TRY(hipMalloc(&p->d_stamps, sizeof(unsigned long long) * 16 * (size_t)n_patches));
@@ -520,11 +532,16 @@ static int check_geometry(const rpsf_plan* p, const rpsf_geometry* g) {
       g->out_rows <= 0 || g->out_row0 + g->out_rows > g->height)
     return fail(RPSF_E_BADARG, "resident row window lies outside the image");
   const int N = p->N;
-  for (int i = 0; i < p->n_patches; ++i) {  // same reach as the reference's 2N padding (transform.py:119-123,141-149)
-    long r = (long)p->h_coords[2 * i] + g->origin_row, c = (long)p->h_coords[2 * i + 1] + g->origin_col;
-    if (r < -2L * N || r > (long)g->height + N || c < -2L * N || c > (long)g->width + N)
-      return fail(RPSF_E_BADARG, "patch corner (" + std::to_string(r) + ", " + std::to_string(c) +
-                                     ") lies outside the 2N-padded image");
+  // same reach as the reference's 2N padding (transform.py:119-123,141-149); the extreme corners decide
+  const long rlo = (long)p->corner_min[0] + g->origin_row, rhi = (long)p->corner_max[0] + g->origin_row;
+  const long clo = (long)p->corner_min[1] + g->origin_col, chi = (long)p->corner_max[1] + g->origin_col;
+  if (rlo < -2L * N || rhi > (long)g->height + N || clo < -2L * N || chi > (long)g->width + N) {
+    for (int i = 0; i < p->n_patches; ++i) {  // name the first offender
+      long r = (long)p->h_coords[2 * i] + g->origin_row, c = (long)p->h_coords[2 * i + 1] + g->origin_col;
+      if (r < -2L * N || r > (long)g->height + N || c < -2L * N || c > (long)g->width + N)
+        return fail(RPSF_E_BADARG, "patch corner (" + std::to_string(r) + ", " + std::to_string(c) +
+                                       ") lies outside the 2N-padded image");
+    }
   }
   return RPSF_OK;
 }

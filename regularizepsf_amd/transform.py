@@ -27,6 +27,7 @@ class ArrayPSFTransform:
         self._device = device
         self._plan: _native.Plan | None = None
         self._plan_stamp: tuple | None = None
+        self._corner_bounds: tuple | None = None
 
     # ------------------------------------------------------------------ accessors (transform.py:37-51)
     @property
@@ -122,6 +123,18 @@ class ArrayPSFTransform:
             self._plan, self._plan_stamp = plan, stamp
         return self._plan
 
+    def _check_corners(self, n: int, height: int, width: int) -> None:
+        """Outside the 2N pad the reference's np.stack is ragged -> ValueError (transform.py:141-162)."""
+        coords = self.coordinates
+        if self._corner_bounds is None or self._corner_bounds[0] != len(coords):  # extremes, once per corner list
+            arr = np.asarray(coords).reshape(-1, 2)
+            self._corner_bounds = (len(coords), arr[:, 0].min(), arr[:, 0].max(), arr[:, 1].min(), arr[:, 1].max())
+        _, rlo, rhi, clo, chi = self._corner_bounds
+        if rlo < -2 * n or rhi > height + n or clo < -2 * n or chi > width + n:
+            bad = next((r, c) for r, c in coords if r < -2 * n or r > height + n or c < -2 * n or c > width + n)
+            msg = f"patch corner {bad} lies outside the padded image"
+            raise ValueError(msg)
+
     # ------------------------------------------------------------------ apply (transform.py:85-177)
     def apply(self, image: np.ndarray, workers: int | None = None, pad_mode: str = "symmetric",
               saturation_threshold: float = math.inf, saturation_dilation: int = 1,
@@ -144,10 +157,7 @@ class ArrayPSFTransform:
         n = self._checked_patch_size()
         plan = self._device_plan()
         height, width = image.shape
-        for r, c in self.coordinates:  # outside the 2N pad the reference's np.stack is ragged -> ValueError
-            if r < -2 * n or r > height + n or c < -2 * n or c > width + n:
-                msg = f"patch corner {(r, c)} lies outside the padded image"
-                raise ValueError(msg)
+        self._check_corners(n, height, width)
 
         if saturation_threshold == math.inf and pad_mode in _native.PAD_MODES:  # nothing can exceed +inf
             return plan.apply_host(image, _native.PAD_MODES[pad_mode])  # float64 out; conversions inside the library
@@ -220,10 +230,7 @@ class ArrayPSFTransform:
         n = self._checked_patch_size()
         plan = self._device_plan()
         _, height, width = images.shape
-        for r, c in self.coordinates:
-            if r < -2 * n or r > height + n or c < -2 * n or c > width + n:
-                msg = f"patch corner {(r, c)} lies outside the padded image"
-                raise ValueError(msg)
+        self._check_corners(n, height, width)
         dtype = np.dtype(dtype)
         if dtype not in (np.float32, np.float64):
             return plan.apply_batch(images.astype(np.float32, copy=False), _native.PAD_MODES[pad_mode]).astype(dtype)
