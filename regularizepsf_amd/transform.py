@@ -3,7 +3,7 @@
 ``construct`` evaluates the regularized transfer kernel with the K2 HIP kernel and ``apply`` runs the
 fused K1 patch kernel; both go through the C ABI of include/rpsf.h.  There is no CPU fallback.
 Differences from the reference that a caller can observe are listed in INTEGRATION.md (float32
-arithmetic inside the kernel, patch sizes limited to 16..256 powers of two).
+arithmetic inside the kernels; patch sizes other than 16..256 powers of two run a hipFFT-based fallback).
 """
 
 from __future__ import annotations
