@@ -303,9 +303,18 @@ def main() -> None:
 
         dist.init_process_group(backend="gloo")  # env:// rendezvous from torch.distributed.run (works with its agent store)
         if args.comm == "rccl":
-            box = [_native.Comm.unique_id() if rank == 0 else None]
+            try:
+                box = [_native.Comm.unique_id() if rank == 0 else None]
+            except _native.NativeError as e:  # librccl missing: every rank must take the same branch
+                box = [None]
+                print(f"[bench] RCCL unavailable on rank 0 ({e})", file=sys.stderr, flush=True)
             dist.broadcast_object_list(box, src=0)
-            comm = _native.Comm(device, rank, world, bytes(box[0]))
+            if box[0] is not None:
+                comm = _native.Comm(device, rank, world, bytes(box[0]))
+            elif args.seam == "recompute" or args.config == 5:  # no data-path exchange: gloo can carry the barrier
+                comm = GlooSeam(rank, world, device)
+            else:
+                raise SystemExit("--seam exchange needs RCCL")
         else:
             comm = GlooSeam(rank, world, device)
     if args.config == 5:
