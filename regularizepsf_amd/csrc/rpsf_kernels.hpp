@@ -204,10 +204,10 @@ __global__ __launch_bounds__(Launch<C>::WG, Launch<C>::WAVES_PER_SIMD) void patc
   const bool active = slot < p.chunk && seq < p.n_patches;
   const int4 dsc = p.desc[p.seq_base + (active ? seq : p.n_patches - 1)];  // inactive teams stay in step with the barriers
   const int patch = dsc.z;
-  // De-phase the chip: without this every CU gathers, streams K and stores at the same instants, HBM
-  // alternates between saturated and idle, and no memory phase overlaps any compute phase.  Delaying
-  // the first resident workgroup of each CU by a different amount spreads the phases for the whole
-  // launch (later workgroups inherit the offset of the one they replace).  Speed only.
+  // Optional start-up stagger (rpsf_plan_set_stagger, off by default): every CU gathers, streams K and stores
+  // at the same instants; delaying the first resident workgroup of each CU by a different amount spreads the
+  // phases for the whole launch (later workgroups inherit the offset of the one they replace).  Measured: a patch
+  // gets 9 % shorter with a 50 us spread, and the delay itself costs as much - kept as a diagnostic knob.
   if (p.stagger_ticks > 0 && (int)blockIdx.x < p.stagger_blocks) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long wait = (unsigned long long)(((blockIdx.x >> 3) * 0x9E3779B1u >> 22) & 1023) * p.stagger_ticks >> 10;
