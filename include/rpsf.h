@@ -114,8 +114,9 @@ int rpsf_apply_device_timed(rpsf_plan* plan, const void* image_dev, void* out_de
  * what a caller of the reference does with a Python loop over ArrayPSFTransform.apply
  * (transform.py:85-177) on a stack of exposures.  The frames of one patch are scheduled next to each other so
  * the packed transfer kernel is read from HBM once per batch, not once per frame.
- * Host variant: images_host / outs_host are (n_frames, height, width) float32, C-contiguous; copies in and
- * out overlap the computation. */
+ * Host variant: images_host / outs_host are (n_frames, height, width) float32, C-contiguous; the frames go one
+ * by one through rpsf_apply (PCIe-bound; the shared-K launch below is for frames that already live on the
+ * device). */
 int rpsf_apply_batch(rpsf_plan* plan, const float* images_host, int n_frames, int height, int width, int pad_mode,
                      float pad_value, float* outs_host);
 /* Device variant: frame f is at images_dev + f * image_stride and outs_dev + f * out_stride (strides in

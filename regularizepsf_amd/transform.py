@@ -238,6 +238,8 @@ class ArrayPSFTransform:
         # rpsf_apply_host moves a frame faster than the shared-K batch launch saves (32 frames of 2048^2: 68 ms
         # against 85 ms).  The shared-K launch is for frames that already live on the device
         # (_native.Plan.apply_batch_device / rpsf_apply_batch_device).
+        if images.dtype == np.float32 and dtype == np.float32:  # no conversion anywhere: the plain float32 entry point
+            return plan.apply_batch(images, _native.PAD_MODES[pad_mode])
         out = np.empty(images.shape, dtype)
         for f in range(images.shape[0]):
             plan.apply_host(images[f], _native.PAD_MODES[pad_mode], out=out[f])
