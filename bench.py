@@ -299,6 +299,11 @@ def main() -> None:
 
     comm = None
     if world > 1:
+        # stdout carries exactly one JSON line: RCCL's own banner / debug output (NCCL_DEBUG=VERSION is set on
+        # the GPU boxes) goes to stderr instead
+        if os.environ.get("NCCL_DEBUG", "").upper() in ("", "VERSION"):
+            os.environ["NCCL_DEBUG"] = "WARN"  # the VERSION banner is printf'ed to stdout at process exit, after the JSON line
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
         import torch.distributed as dist  # launcher plumbing only: a gloo group carries the 128-byte RCCL unique id
 
         dist.init_process_group(backend="gloo")  # env:// rendezvous from torch.distributed.run (works with its agent store)
