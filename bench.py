@@ -41,6 +41,29 @@ CONFIGS = {  # name -> (height, width, patch, starfield seed)
 }
 
 
+_REAL_STDOUT = None
+
+
+def quiet_stdout() -> None:
+    """stdout carries exactly one JSON line.  Libraries print there as well (gloo's connection messages, RCCL's
+    banner with NCCL_DEBUG=VERSION - flushed at exit, i.e. after our line), so file descriptor 1 is pointed at
+    stderr for the duration of the run and the JSON line is written to the saved original descriptor."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_json(line: dict) -> None:
+    data = (json.dumps(line) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, data)
+
+
 def cpu_baseline(image, coords, k, budget_s: float = 20.0):
     """Time the CPU oracle (bit-identical restatement of the reference) on a bounded sample.
 
@@ -225,7 +248,7 @@ def run_batch(args, rank, world, device, comm):
     }
     if not args.no_cpu and world == 1:
         line["cpu_baseline"] = cpu_baseline(images[0], coords, k)
-    print(json.dumps(line), flush=True)
+    emit_json(line)
 
 
 def main() -> None:
@@ -245,6 +268,7 @@ def main() -> None:
                          "(no data-path collective, +3 %% patches); 'exchange' - the spill rows of a band are sent to the "
                          "next rank with RCCL send/recv and added there")
     args = ap.parse_args()
+    quiet_stdout()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -410,7 +434,7 @@ def main() -> None:
         line["roofline"]["traffic_source"] = tr["source"]
     if not args.no_cpu and world == 1:
         line["cpu_baseline"] = cpu_baseline(band_image, coords, kernel_for(list(range(len(coords)))))
-    print(json.dumps(line), flush=True)
+    emit_json(line)
 
 
 if __name__ == "__main__":
