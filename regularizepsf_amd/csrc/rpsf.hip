@@ -65,6 +65,7 @@ struct rpsf_plan {
   size_t stage_bytes = 0;
   int32_t* d_coords = nullptr;
   uint16_t* d_tab = nullptr;
+  uint32_t* d_pairtab = nullptr;
   cf* d_tw = nullptr;
   float* d_win = nullptr;
   cf* d_g = nullptr;
@@ -241,9 +242,16 @@ static void host_tables(int N, std::vector<cf>& tw, std::vector<float>& win) {
 }
 
 template <class C>
-static int upload_tables(int device, uint16_t** d_tab, cf** d_tw, float** d_win) {
+static int upload_tables(int device, uint16_t** d_tab, cf** d_tw, float** d_win, uint32_t** d_pairtab = nullptr) {
   std::vector<uint16_t> tab((size_t)C::T * C::NSLOT * 2);
   build_slot_table<C>(tab.data());
+  if (d_pairtab) {
+    std::vector<uint32_t> pt((size_t)C::PT_WORDS + 1);
+    if (build_pair_table<C>(tab.data(), pt.data()) > C::NP) return fail(RPSF_E_STATE, "pair table overflow (internal)");
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMalloc(d_pairtab, pt.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpy(*d_pairtab, pt.data(), pt.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
   std::vector<cf> tw;
   std::vector<float> win;
   host_tables(C::N, tw, win);
@@ -391,7 +399,7 @@ extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int
     rl = setup_lattice(p);
     if (rl != RPSF_OK) return rl;
     return dispatch_n(N, [&]<class C>() -> int {
-      int r2 = upload_tables<C>(device, &p->d_tab, &p->d_tw, &p->d_win);
+      int r2 = upload_tables<C>(device, &p->d_tab, &p->d_tw, &p->d_win, &p->d_pairtab);
       if (r2 != RPSF_OK) return r2;
       p->g_elems = (size_t)C::G_PER_PATCH * n_patches;
       p->gs_elems = (size_t)C::GS_PER_PATCH * n_patches;
@@ -421,6 +429,7 @@ extern "C" void rpsf_plan_destroy(rpsf_plan* p) {
   if (p->stream) (void)hipStreamSynchronize(p->stream);
   (void)hipFree(p->d_coords);
   (void)hipFree(p->d_tab);
+  (void)hipFree(p->d_pairtab);
   (void)hipFree(p->d_tw);
   (void)hipFree(p->d_win);
   (void)hipFree(p->d_g);
@@ -452,7 +461,7 @@ static int pack_range(rpsf_plan* p, const cf* d_kfull, int first_patch, int coun
     int block = 256;
     size_t grid = (total + block - 1) / block;
     pack_kernel<C><<<dim3((unsigned)grid), dim3(block), 0, p->stream>>>(
-        d_kfull, count, p->d_tab, p->d_g + (size_t)first_patch * C::G_PER_PATCH,
+        d_kfull, count, p->d_tab, p->d_pairtab, p->d_g + (size_t)first_patch * C::G_PER_PATCH,
         p->d_gs + (size_t)first_patch * C::GS_PER_PATCH);
     HIP_TRY(hipGetLastError());
     return RPSF_OK;
@@ -564,7 +573,7 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
       pp.ov = OutView{d_out, g.height, g.width, g.ld_out, g.out_row0, g.out_rows, 0, p->d_sink};
     pp.origin_row = g.origin_row, pp.origin_col = g.origin_col;
     pp.desc = p->d_desc, pp.n_patches = count, pp.seq_base = seq_base;
-    pp.tab = p->d_tab, pp.tw = p->d_tw, pp.win = p->d_win, pp.g = p->d_g, pp.gs = p->d_gs;
+    pp.tab = p->d_tab, pp.pairtab = p->d_pairtab, pp.tw = p->d_tw, pp.win = p->d_win, pp.g = p->d_g, pp.gs = p->d_gs;
     pp.stamps = p->d_stamps;
     constexpr int TEAMS = Launch<C>::TEAMS;
     pp.chunk = ((count + 7) / 8 + TEAMS - 1) / TEAMS * TEAMS;  // patches per XCD, whole workgroups

@@ -212,12 +212,24 @@ struct Cfg {
     return acc;
   }
   static constexpr int NSPEC_THREADSLOTS = spec_prefix(NSLOT);
-  // Two-stage plans: a slot is special-format for the whole team or not at all, so the Nyquist-side factors of
-  // a special slot travel in the main stream (two words per bin: (Ka(A_e), Ka(B_e)) then (Ks(A_e), Ks(B_e)))
-  // instead of a side array read pair by pair in the middle of the multiplication (2048^2 / N=64: 113 -> 87 us
-  // with those reads taken out).  Three-stage plans keep the side array gs: only their leading waves are special.
-  static constexpr bool INLINE_GS = !S3;
-  static constexpr int slot_words(int s) { return (INLINE_GS && spec_t(s) > 0) ? 2 * E : E; }
+  // Two-stage plans: a slot is special-format for the whole team or not at all.  Such a slot is worked through as
+  // a list of bin pairs ("orbits" of k -> -k inside the slot's two groups) read from a small table: both bins of
+  // a pair are fetched from the LDS parking area by computed address, one pair_op serves both, both results go
+  // back to the parking area, and the stream carries one ordinary K word per pair - (K_h(p), K_h(p + (0,N/2)))
+  // for the first bin p of the pair - instead of separate words for the two members.  (Before: two pair_ops
+  // per bin pair and twice the K bytes, because the partner of a bin was a run-time-indexed register.)
+  // Three-stage plans keep the per-bin variant with the side array gs: only their leading waves are special.
+  static constexpr bool ORBIT = !S3;
+  static constexpr bool INLINE_GS = ORBIT;                  // no side array
+  static constexpr int NP = E + 2;                          // pair words of a special slot: E orbits, two more in the slot that holds group (0,0) and its four fixed points
+  static constexpr int slot_words(int s) { return (ORBIT && spec_t(s) > 0) ? NP : E; }
+  static constexpr int special_index(int s) {               // special slots before s
+    int acc = 0;
+    for (int i = 0; i < s; ++i) acc += spec_t(i) > 0 ? 1 : 0;
+    return acc;
+  }
+  static constexpr int NSS = special_index(NSLOT);          // special slots per thread
+  static constexpr int PT_WORDS = ORBIT ? T * NSS * NP : 0; // pair table, uint32 per (thread, special slot, pair)
   static constexpr int word_base(int s) {
     int acc = 0;
     for (int i = 0; i < s; ++i) acc += slot_words(i);
@@ -312,6 +324,51 @@ inline void build_slot_table(uint16_t* tab) {
   }
   delete[] seen;
   delete[] slots;
+}
+
+// Pair table of the special slots of two-stage plans (Cfg::ORBIT).  Entry (t, special slot i, j):
+//   bits 0-7 x1, 8-15 x2: positions of the pair's two bins among the slot's 2E parked values (member*E + e),
+//   bits 16-23 the twiddle index kc of the first bin (W_N^kc), bit 31 valid.  A fixed point has x1 == x2.
+RPSF_HD uint32_t pair_entry(int x1, int x2, int kc) { return (uint32_t)x1 | ((uint32_t)x2 << 8) | ((uint32_t)kc << 16) | 0x80000000u; }
+template <class C>
+RPSF_HD int partner_element(int q, int m, int e) {  // element index of bin -p inside the partner group
+  const int k3 = e / C::EB, l3 = e % C::EB;
+  const int pk = q == 0 ? (C::EA - k3) % C::EA : C::EA - 1 - k3;
+  const int pl = m == 0 ? (C::EB - l3) % C::EB : C::EB - 1 - l3;
+  return pk * C::EB + pl;
+}
+// Host only.  Returns the largest number of pairs any slot needs (must be <= C::NP).
+template <class C>
+inline int build_pair_table(const uint16_t* tab, uint32_t* pt) {
+  int worst = 0;
+  if constexpr (C::ORBIT) {
+    for (int i = 0; i < C::PT_WORDS; ++i) pt[i] = 0;
+    for (int t = 0; t < C::T; ++t)
+      for (int s = 0; s < C::NSLOT; ++s) {
+        if (C::spec_t(s) == 0) continue;
+        uint32_t* out = pt + ((size_t)t * C::NSS + C::special_index(s)) * C::NP;
+        const int ga = tab[(t * C::NSLOT + s) * 2], gb = tab[(t * C::NSLOT + s) * 2 + 1];
+        int qa, ma, qb, mb, n = 0;
+        gid_to_qm<C>(ga, qa, ma);
+        gid_to_qm<C>(gb, qb, mb);
+        if (partner_gid<C>(ga) != ga) {  // two groups that are each other's partners: bin e of A with its mirror in B
+          for (int e = 0; e < C::E; ++e, ++n)
+            if (n < C::NP) out[n] = pair_entry(e, C::E + partner_element<C>(qa, ma, e), ma + C::M * (e % C::EB));
+        } else {  // two self-paired groups: the orbits inside A, then inside B
+          for (int member = 0; member < 2; ++member) {
+            const int q = member ? qb : qa, m = member ? mb : ma;
+            for (int e = 0; e < C::E; ++e) {
+              const int pe = partner_element<C>(q, m, e);
+              if (e > pe) continue;
+              if (n < C::NP) out[n] = pair_entry(member * C::E + e, member * C::E + pe, m + C::M * (e % C::EB));
+              ++n;
+            }
+          }
+        }
+        worst = n > worst ? n : worst;
+      }
+  }
+  return worst;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -549,8 +606,8 @@ RPSF_HD PairOut pair_op(cf za, cf zb, cf ka, cf kb, cf w) {
 //       member A - exactly the two factors of pair_op(A_e, B_{E-1-e}).  Special-format slot:
 //       (K'_h(A_e), K'_h(B_e)), and the Nyquist-side factors (K'_h(A_e + (0,N/2)), K'_h(B_e + (0,N/2))) sit in
 //   gs: cf index prefix(S)*2E + (e*spec_t(S) + t)*2, for t < spec_t(S)  (three-stage plans).
-//       Two-stage plans have no gs: a special slot takes 2E words, (Ka(A_e), Ka(B_e)) then (Ks(A_e), Ks(B_e))
-//       for e = 0..E-1 (Cfg::slot_words / word_base), and the stream is padded to whole chunks.
+//       Two-stage plans have no gs: a special slot takes NP ordinary words, one per bin pair of its pair table
+//       (Cfg::ORBIT, build_pair_table), and the stream is padded to whole chunks.
 // K is consumed in chunks of C::KCH pair words (8, or 4 for the plans with tiny groups whose other
 // temporaries are larger): 16-byte streaming loads, 1 KiB per wave instruction.
 // ------------------------------------------------------------------------------------------
@@ -609,6 +666,24 @@ RPSF_HD void special_pair_parked(int t, const GroupIds<C>& gids, cf* v, cf ka_a,
   zb[EE] = pair_op(zb[EE], pb, ka_b, ks_b, tw[mb + C::M * L3]).a;
 }
 
+// Two-stage plans: pair J of special slot S, both bins through the parking area (see Cfg::ORBIT).
+template <class C, int S, int J>
+RPSF_HD void orbit_pair(int t, const uint32_t* pt, cf ka, cf kb, const cf* __restrict__ tw, cf* scratch) {
+  const uint32_t ent = pt[((size_t)t * C::NSS + C::special_index(S)) * C::NP + J];
+  const int x1 = ent & 0xff, x2 = (ent >> 8) & 0xff, kc = (ent >> 16) & 0xff;
+  const cf z1 = scratch[(size_t)x1 * C::PARK_STRIDE + t], z2 = scratch[(size_t)x2 * C::PARK_STRIDE + t];
+  const PairOut o = pair_op(z1, z2, ka, kb, tw[kc]);
+  if (ent >> 31) {
+    scratch[(size_t)x1 * C::PARK_STRIDE + t] = o.a;
+    if (x2 != x1) scratch[(size_t)x2 * C::PARK_STRIDE + t] = o.b;
+  }
+}
+template <class C, int S>
+RPSF_HD void special_slot_unpark(int t, cf* v, const cf* scratch) {
+  constexpr int E = C::E;
+  StaticFor<0, 2 * E>::run([&]<int I>() RPSF_AI { v[(2 * S) * E + I] = scratch[(size_t)I * C::PARK_STRIDE + t]; });
+}
+
 // The whole frequency step of one thread: 32 pair words in 4 chunks.  r holds chunk 0 (loaded by the caller
 // before the exchange into the last layout); each later chunk is requested as soon as its buffer is free.
 // scratch: thread-private LDS columns for the parked special path.
@@ -617,7 +692,7 @@ RPSF_HD void special_pair_parked(int t, const GroupIds<C>& gids, cf* v, cf ka_a,
 // DFT of the same groups): the K round trip of chunk i+1 hides behind the butterflies of chunks i and i+1.
 template <class C, bool FUSE>
 RPSF_HD void pointwise(int t, const GroupIds<C>& gids, cf* v, KRing<C>& r, const cf* __restrict__ g,
-                       const cf* __restrict__ gs, const cf* __restrict__ tw, cf* scratch) {
+                       const cf* __restrict__ gs, const cf* __restrict__ tw, cf* scratch, const uint32_t* pt) {
   constexpr int E = C::E, EB = C::EB;
   StaticFor<0, C::NWORDS / C::KCH>::run([&]<int CI>() RPSF_AI {
     constexpr int DEPTH = KRing<C>::DEPTH;
@@ -626,8 +701,8 @@ RPSF_HD void pointwise(int t, const GroupIds<C>& gids, cf* v, KRing<C>& r, const
       constexpr int W = CI * C::KCH + I;
       if constexpr (W < C::NWORDS_USED) {
         constexpr int S = C::word_slot(W), R = W - C::word_base(S), ST = C::spec_t(S);
-        constexpr bool WIDE = C::INLINE_GS && ST > 0;        // two words per bin, the second one completes it
-        constexpr int EE = WIDE ? R / 2 : R;
+        constexpr bool WIDE = C::ORBIT && ST > 0;            // a special slot of a two-stage plan: word R is pair R of its table
+        constexpr int EE = WIDE ? 0 : R;
         if constexpr (FUSE && R == 0) {  // first word of a slot: forward DFT of its two groups
           stage_last_group<C, false, 2 * S>(v);
           stage_last_group<C, false, 2 * S + 1>(v);
@@ -646,9 +721,8 @@ RPSF_HD void pointwise(int t, const GroupIds<C>& gids, cf* v, KRing<C>& r, const
           static_assert(!C::S3 || C::spec_t(S) <= C::PARK_STRIDE, "parking area sized by slot 0");
           if constexpr (R == 0) special_slot_park<C, S>(t, v, scratch);
           if constexpr (WIDE) {
-            static_assert(C::KCH % 2 == 0, "both words of a bin in one chunk");
-            if constexpr (R % 2 == 1)
-              special_pair_parked<C, S, EE>(t, gids, v, rk[2 * I - 2], rk[2 * I - 1], rk[2 * I], rk[2 * I + 1], tw, scratch);
+            orbit_pair<C, S, R>(t, pt, rk[2 * I], rk[2 * I + 1], tw, scratch);
+            if constexpr (R == C::NP - 1) special_slot_unpark<C, S>(t, v, scratch);
           } else {
             const cf* gsp = gs + (size_t)C::spec_prefix(S) * 2 * E + ((size_t)EE * ST + t) * 2;
             special_pair_parked<C, S, EE>(t, gids, v, rk[2 * I], rk[2 * I + 1], gsp[0], gsp[1], tw, scratch);
@@ -672,12 +746,12 @@ RPSF_HD void pointwise(int t, const GroupIds<C>& gids, cf* v, KRing<C>& r, const
 // Last stage forward, multiplication by K, last stage inverse.
 template <class C>
 RPSF_HD void freq_step(int t, const GroupIds<C>& gids, cf* v, KRing<C>& r, const cf* __restrict__ g,
-                       const cf* __restrict__ gs, const cf* __restrict__ tw, cf* scratch) {
+                       const cf* __restrict__ gs, const cf* __restrict__ tw, cf* scratch, const uint32_t* pt) {
   if constexpr (C::FUSE_LAST) {
-    pointwise<C, true>(t, gids, v, r, g, gs, tw, scratch);
+    pointwise<C, true>(t, gids, v, r, g, gs, tw, scratch, pt);
   } else {
     stage_last<C, false>(v);
-    pointwise<C, false>(t, gids, v, r, g, gs, tw, scratch);
+    pointwise<C, false>(t, gids, v, r, g, gs, tw, scratch, pt);
     stage_last<C, true>(v);
   }
 }
@@ -695,20 +769,25 @@ RPSF_HD bool slot_is_special(int s, int t) {
   return (t & ~(C::WAVE - 1)) < C::spec_t(s);
 }
 template <class C>
-RPSF_HD cf pack_value(const cf* __restrict__ kfull, const uint16_t* __restrict__ tab, int t, int rho, int which) {
+RPSF_HD cf pack_value(const cf* __restrict__ kfull, const uint16_t* __restrict__ tab, const uint32_t* __restrict__ pt, int t,
+                      int rho, int which) {
   // rho = 2*w + b, w = word index in the thread's stream;  which = 0: g, 1: gs (special-format slots of
   // three-stage plans only).  See the layout comment above load_k_chunk.
   const int w = rho >> 1, b = rho & 1;
   if (w >= C::NWORDS_USED) return cf{0.f, 0.f};  // padding to whole chunks
   const int s = C::word_slot(w), r = w - C::word_base(s);
   const bool special = slot_is_special<C>(s, t);
-  const bool wide = C::INLINE_GS && special;
-  const int e = wide ? r / 2 : r;
-  const int member = special ? b : 0;  // general words describe bin e of member A only
+  int member = special ? b : 0, e = r;  // general words describe bin e of member A only
+  bool nyquist_side = special ? which == 1 : b == 1;
+  if (C::ORBIT && special) {  // word r = pair r of the slot's table: (K_h(p), K_h(p + (0,N/2))) of its first bin p
+    const uint32_t ent = pt[((size_t)t * C::NSS + C::special_index(s)) * C::NP + r];
+    if (!(ent >> 31)) return cf{0.f, 0.f};
+    const int x1 = ent & 0xff;
+    member = x1 / C::E, e = x1 % C::E, nyquist_side = b == 1;
+  }
   int q, m;
   gid_to_qm<C>(tab[(t * C::NSLOT + s) * 2 + member], q, m);
   const int kr = q + C::Q * (e / C::EB), kc = m + C::M * (e % C::EB);
-  const bool nyquist_side = wide ? (r & 1) == 1 : special ? which == 1 : b == 1;
   return kh_at<C>(kfull, kr, nyquist_side ? kc + C::NC : kc);
 }
 

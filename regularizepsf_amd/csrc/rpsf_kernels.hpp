@@ -140,6 +140,7 @@ struct PatchParams {
   size_t im_frame_floats;   // frame f reads im.img + f * im_frame_floats ...
   size_t ov_frame_floats;   // ... and writes ov.out + f * ov_frame_floats
   const uint16_t* tab;
+  const uint32_t* pairtab;  // two-stage plans: bin pairs of the special slots (build_pair_table)
   const cf* tw;
   const float* win;
   const cf* g;
@@ -150,7 +151,8 @@ template <class C>
 struct Launch {
   static constexpr int WG = C::T < 64 ? 64 : C::T;
   static constexpr int TEAMS = WG / C::T;
-  static constexpr int TABLE_FLOATS = 3 * C::N;  // twiddles (N complex) + window (N), shared by the workgroup
+  static constexpr int PT_FLOATS = (C::PT_WORDS + 3) / 4 * 4;  // pair table of the special slots (two-stage plans), one copy per workgroup
+  static constexpr int TABLE_FLOATS = 3 * C::N + PT_FLOATS;    // twiddles (N complex) + window (N) + pair table, shared by the workgroup
   static constexpr size_t LDS_BYTES = (size_t)(TABLE_FLOATS + TEAMS * C::LDS_FLOATS) * sizeof(float);
   // Waves per SIMD the kernel is compiled for.  Where LDS already limits a CU to four single-wave workgroups
   // (N = 64: each team parks its whole patch), one wave per SIMD may as well use the other half of the
@@ -230,6 +232,8 @@ __global__ __launch_bounds__(Launch<C>::WG, Launch<C>::WAVES_PER_SIMD) void patc
     tw[i] = p.tw[i];
     win[i] = p.win[i];
   }
+  uint32_t* pt = reinterpret_cast<uint32_t*>(smem + 3 * C::N);
+  for (int i = threadIdx.x; i < C::PT_WORDS; i += Launch<C>::WG) pt[i] = p.pairtab[i];
   GroupIds<C> gids;
   gids.load(p.tab, t);
 #if !defined(RPSF_ABL_NOLOAD)
@@ -275,7 +279,7 @@ __global__ __launch_bounds__(Launch<C>::WG, Launch<C>::WAVES_PER_SIMD) void patc
   {
     STAMP(6);
     STAMP(7);
-    freq_step<C>(t, gids, v, kring, g, p.gs + (size_t)patch * C::GS_PER_PATCH, tw, reinterpret_cast<cf*>(lds + C::PARK_OFFSET));
+    freq_step<C>(t, gids, v, kring, g, p.gs + (size_t)patch * C::GS_PER_PATCH, tw, reinterpret_cast<cf*>(lds + C::PARK_OFFSET), pt);
     STAMP(8);
   }
 
@@ -325,7 +329,7 @@ __global__ __launch_bounds__(Launch<C>::WG, Launch<C>::WAVES_PER_SIMD) void patc
 // ------------------------------------------------------------------------------------------------
 template <class C>
 __global__ void pack_kernel(const cf* __restrict__ kfull, int n_patches, const uint16_t* __restrict__ tab,
-                            cf* __restrict__ g, cf* __restrict__ gs) {
+                            const uint32_t* __restrict__ pt, cf* __restrict__ g, cf* __restrict__ gs) {
   const size_t per = (size_t)C::G_PER_PATCH;
   size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= per * n_patches) return;
@@ -334,12 +338,12 @@ __global__ void pack_kernel(const cf* __restrict__ kfull, int n_patches, const u
   int b = rem & 1, t = (rem >> 1) % C::T, i = (rem >> 1) / C::T;
   int rho = 2 * i + b;
   const cf* kf = kfull + (size_t)patch * C::N * C::N;
-  g[idx] = pack_value<C>(kf, tab, t, rho, 0);
+  g[idx] = pack_value<C>(kf, tab, pt, t, rho, 0);
   if constexpr (!C::INLINE_GS) {
     const int w = rho >> 1, s = w / C::E, e = w % C::E;
     if (slot_is_special<C>(s, t))
       gs[(size_t)patch * C::GS_PER_PATCH + (size_t)C::spec_prefix(s) * 2 * C::E + ((size_t)e * C::spec_t(s) + t) * 2 + b] =
-          pack_value<C>(kf, tab, t, rho, 1);
+          pack_value<C>(kf, tab, pt, t, rho, 1);
   }
 }
 

@@ -24,6 +24,8 @@ static int emu_apply_t(int n_patches, const int32_t* coords, int H, int W, int p
   }
   std::vector<uint16_t> tab((size_t)T * C::NSLOT * 2);
   build_slot_table<C>(tab.data());
+  std::vector<uint32_t> pt((size_t)C::PT_WORDS + 1);
+  if (build_pair_table<C>(tab.data(), pt.data()) > C::NP) return -3;
   std::vector<cf> regs((size_t)T * 64);
   std::vector<float> lds(C::LDS_FLOATS);
   std::vector<cf> g((size_t)C::G_PER_PATCH), gs((size_t)C::GS_PER_PATCH + 1);
@@ -39,12 +41,12 @@ static int emu_apply_t(int n_patches, const int32_t* coords, int H, int W, int p
     // pack K for this patch (what the pack kernel does)
     for (int t = 0; t < T; ++t)
       for (int rho = 0; rho < 2 * C::NWORDS; ++rho) {
-        g[((size_t)(rho / 2) * T + t) * 2 + (rho & 1)] = pack_value<C>(kf, tab.data(), t, rho, 0);
+        g[((size_t)(rho / 2) * T + t) * 2 + (rho & 1)] = pack_value<C>(kf, tab.data(), pt.data(), t, rho, 0);
         if constexpr (!C::INLINE_GS) {
           const int w = rho >> 1, b = rho & 1, s = w / C::E, e = w % C::E;
           if (slot_is_special<C>(s, t))
             gs[(size_t)C::spec_prefix(s) * 2 * C::E + ((size_t)e * C::spec_t(s) + t) * 2 + b] =
-                pack_value<C>(kf, tab.data(), t, rho, 1);
+                pack_value<C>(kf, tab.data(), pt.data(), t, rho, 1);
         }
       }
     int pr = coords[2 * p], pc = coords[2 * p + 1];
@@ -69,7 +71,7 @@ static int emu_apply_t(int n_patches, const int32_t* coords, int H, int W, int p
       cf* v = &regs[(size_t)t * 64];
       KRing<C> kring;
       kring_fill<C>(t, kring, g.data());
-      freq_step<C>(t, gids[t], v, kring, g.data(), gs.data(), tw.data(), reinterpret_cast<cf*>(lds.data() + C::PARK_OFFSET));
+      freq_step<C>(t, gids[t], v, kring, g.data(), gs.data(), tw.data(), reinterpret_cast<cf*>(lds.data() + C::PARK_OFFSET), pt.data());
     }
     for (int t = 0; t < T; ++t) x2_last_write<C, 0>(gids[t], &regs[(size_t)t * 64], lds.data());
     for (int t = 0; t < T; ++t) x2_mid_read<C, 0>(t, &regs[(size_t)t * 64], lds.data());
