@@ -231,6 +231,31 @@ def test_forced_atomic_mode_matches_planes():
     assert np.abs(outs["planes"] - outs["atomic"]).max() <= 2e-6 * np.abs(fx["expected"]).max()
 
 
+@pytest.mark.parametrize(("n", "size"), [(256, 2048), (128, 2048)])
+def test_processing_order_knobs_do_not_change_the_result(n, size, monkeypatch):
+    """RPSF_SPLIT=1 (tail patches fused with the plane sum) and RPSF_NO_BORDER_FIRST=1 only reorder the launches:
+    every plane cell is still written by one patch and summed in a fixed order, so the output is bit-identical."""
+    from regularizepsf_amd import _native
+
+    coords = [tuple(int(v) for v in c) for c in rp.calculate_covering((size, size), n)]
+    rng = np.random.default_rng(n)
+    k = (rng.standard_normal((len(coords), n, n), dtype=np.float32)
+         + 1j * rng.standard_normal((len(coords), n, n), dtype=np.float32)).astype(np.complex64)
+    image = rng.standard_normal((size, size), dtype=np.float32)
+    outs = {}
+    for knob in (None, "RPSF_SPLIT", "RPSF_NO_BORDER_FIRST"):
+        if knob:
+            monkeypatch.setenv(knob, "1")
+        plan = _native.Plan(n, coords)  # the knobs are read when the plan is created
+        plan.set_transfer(k)
+        outs[knob] = plan.apply(image, _native.PAD_MODES["symmetric"])
+        if knob:
+            monkeypatch.delenv(knob)
+    assert np.array_equal(outs[None], outs["RPSF_SPLIT"])
+    assert np.array_equal(outs[None], outs["RPSF_NO_BORDER_FIRST"])
+    assert np.isfinite(outs[None]).all()
+
+
 @pytest.mark.parametrize("pad_mode", ["symmetric", "reflect", "edge", "wrap", "constant"])
 @pytest.mark.parametrize("shape", [(5, 7), (1, 1), (33, 9)])
 def test_images_smaller_than_a_patch(shape, pad_mode):
