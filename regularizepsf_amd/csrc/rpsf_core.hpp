@@ -248,6 +248,11 @@ struct Cfg {
   static constexpr int X1_ROW = 68;  // floats per X1 row: 16-byte aligned rows (wide reads), 4*lane + c mod 64 covers every bank once
   static constexpr int X1_FLOATS = S3 ? (T / 64) * 64 * X1_ROW : 0;
   static constexpr int X2_STRIDE = S3 ? G : G + 1;
+#if defined(RPSF_ONE_PASS_SPECIAL)
+  static constexpr bool TWO_PASS_SPECIAL = false;
+#else
+  static constexpr bool TWO_PASS_SPECIAL = S3 && KCH == E;  // see special_pass1 (N = 256; at N = 128 a chunk holds four slots)
+#endif
   static constexpr int X2_FLOATS = E * X2_STRIDE;
   static constexpr int LDS_FLOATS0 = X1_FLOATS > X2_FLOATS ? X1_FLOATS : X2_FLOATS;
   // Parked special slot: thread-private LDS columns scratch[(h*E + e)*PARK_STRIDE + t].  Two-stage plans are
@@ -666,6 +671,52 @@ RPSF_HD void special_pair_parked(int t, const GroupIds<C>& gids, cf* v, cf ka_a,
   zb[EE] = pair_op(zb[EE], pb, ka_b, ks_b, tw[mb + C::M * L3]).a;
 }
 
+// The same step in two passes, for plans whose K chunk is exactly one slot (E == KCH): r.a of pair_op is linear in
+// (ka, ks), so pass 1 applies the main-stream factor, each word's registers are refilled with its side factors as
+// soon as it is consumed, and pass 2 adds the side term from the parked originals.  One-pass code reads the side
+// factors word by word inside the loop - eight dependent memory round trips in the waves every barrier waits for.
+template <class C, int S, int EE, int MEMBER>
+RPSF_HD void special_terms(int t, const GroupIds<C>& gids, const cf* __restrict__ tw, const cf* scratch, cf z, cf& e2,
+                           cf& wo, cf& w) {
+  constexpr int E = C::E, EA = C::EA, EB = C::EB, K3 = EE / EB, L3 = EE % EB;
+  const int ga = gids[2 * S], gm = gids[2 * S + MEMBER];
+  const bool self = partner_gid<C>(ga) == ga;
+  int q, m;
+  gid_to_qm<C>(gm, q, m);
+  const int k3 = q == 0 ? (EA - K3) % EA : EA - 1 - K3;  // bin of -p: digit negated if the low part is zero, else reversed
+  const int l3 = m == 0 ? (EB - L3) % EB : EB - 1 - L3;
+  const int member = self ? MEMBER : 1 - MEMBER;
+  const cf pc = cconj(scratch[(size_t)(member * E + k3 * EB + l3) * C::PARK_STRIDE + t]);
+  w = tw[m + C::M * L3];
+  e2 = z + pc;
+  wo = cmul(w, mul_mi(z - pc));
+}
+template <class C, int S, int EE>
+RPSF_HD void special_pass1(int t, const GroupIds<C>& gids, cf* v, cf ka_a, cf ka_b, const cf* __restrict__ tw,
+                           const cf* scratch) {
+  cf* za = v + (2 * S) * C::E;
+  cf* zb = za + C::E;
+  cf e2, wo, w;
+  special_terms<C, S, EE, 0>(t, gids, tw, scratch, za[EE], e2, wo, w);
+  za[EE] = cmul(e2 + wo, ka_a);
+  special_terms<C, S, EE, 1>(t, gids, tw, scratch, zb[EE], e2, wo, w);
+  zb[EE] = cmul(e2 + wo, ka_b);
+}
+template <class C, int S, int EE>
+RPSF_HD void special_pass2(int t, const GroupIds<C>& gids, cf* v, cf ks_a, cf ks_b, const cf* __restrict__ tw,
+                           const cf* scratch) {
+  constexpr int E = C::E;
+  cf* za = v + (2 * S) * E;
+  cf* zb = za + E;
+  cf e2, wo, w;
+  special_terms<C, S, EE, 0>(t, gids, tw, scratch, scratch[(size_t)EE * C::PARK_STRIDE + t], e2, wo, w);
+  cf y2 = cmul(e2 - wo, ks_a);
+  za[EE] = (za[EE] + y2) + mul_pi(cmulc(za[EE] - y2, w));
+  special_terms<C, S, EE, 1>(t, gids, tw, scratch, scratch[(size_t)(E + EE) * C::PARK_STRIDE + t], e2, wo, w);
+  y2 = cmul(e2 - wo, ks_b);
+  zb[EE] = (zb[EE] + y2) + mul_pi(cmulc(zb[EE] - y2, w));
+}
+
 // Two-stage plans: pair J of special slot S, both bins through the parking area (see Cfg::ORBIT).
 template <class C, int S, int J>
 RPSF_HD void orbit_pair(int t, const uint32_t* pt, cf ka, cf kb, const cf* __restrict__ tw, cf* scratch) {
@@ -723,6 +774,17 @@ RPSF_HD void pointwise(int t, const GroupIds<C>& gids, cf* v, KRing<C>& r, const
           if constexpr (WIDE) {
             orbit_pair<C, S, R>(t, pt, rk[2 * I], rk[2 * I + 1], tw, scratch);
             if constexpr (R == C::NP - 1) special_slot_unpark<C, S>(t, v, scratch);
+          } else if constexpr (C::TWO_PASS_SPECIAL) {
+            static_assert(C::KCH == E && I == EE, "the chunk in the ring is this slot");
+            const cf* gsp = gs + (size_t)C::spec_prefix(S) * 2 * E + ((size_t)EE * ST + t) * 2;
+            special_pass1<C, S, EE>(t, gids, v, rk[2 * I], rk[2 * I + 1], tw, scratch);
+            load_stream16(gsp, rk[2 * I], rk[2 * I + 1]);  // the word's registers now wait for its side factors
+            if constexpr (EE == E - 1)
+              StaticFor<0, E>::run([&]<int E2>() RPSF_AI {
+                special_pass2<C, S, E2>(t, gids, v, rk[2 * E2], rk[2 * E2 + 1], tw, scratch);
+                if constexpr (CI + DEPTH < C::NWORDS / C::KCH)  // ... and then for the next chunk's word (instead of the refill below)
+                  load_stream16(g + ((size_t)((CI + DEPTH) * C::KCH + E2) * C::T + t) * 2, rk[2 * E2], rk[2 * E2 + 1]);
+              });
           } else {
             const cf* gsp = gs + (size_t)C::spec_prefix(S) * 2 * E + ((size_t)EE * ST + t) * 2;
             special_pair_parked<C, S, EE>(t, gids, v, rk[2 * I], rk[2 * I + 1], gsp[0], gsp[1], tw, scratch);
@@ -730,7 +792,12 @@ RPSF_HD void pointwise(int t, const GroupIds<C>& gids, cf* v, KRing<C>& r, const
         }
       }
     });
-    if constexpr (CI + DEPTH < C::NWORDS / C::KCH) load_k_chunk<C, CI + DEPTH>(t, rk, g);
+    if constexpr (CI + DEPTH < C::NWORDS / C::KCH) {
+      constexpr int SC = C::word_slot(CI * C::KCH), STC = C::spec_t(SC);
+      bool refilled = false;  // the two-pass special path has already asked for the next chunk, word by word
+      if constexpr (C::TWO_PASS_SPECIAL && STC > 0) refilled = (t & ~(C::WAVE - 1)) < STC;
+      if (!refilled) load_k_chunk<C, CI + DEPTH>(t, rk, g);
+    }
     StaticFor<0, C::KCH>::run([&]<int I>() RPSF_AI {  // slots that ended in this chunk: inverse DFT of their groups
       constexpr int W = CI * C::KCH + I;
       if constexpr (W < C::NWORDS_USED) {
