@@ -1,6 +1,6 @@
 #!/bin/bash
 # run on the GPU box from the repo root
-R=r01h
+R=${1:-r01i}
 mkdir -p gpurun_out/$R
 python -m pytest tests -m gpu -x -q > gpurun_out/$R/pytest_gpu.log 2>&1; tail -2 gpurun_out/$R/pytest_gpu.log
 python bench.py --steps 50 --warmup 5 > gpurun_out/$R/bench.json 2> gpurun_out/$R/bench.err; cat gpurun_out/$R/bench.json | cut -c1-300
