@@ -190,8 +190,9 @@ class Plan:
         check(lib().rpsf_plan_set_transfer_device(self._handle, ptr))
 
     def set_overlap_mode(self, mode: str) -> None:
-        """'auto' (colour planes on lattices, atomics otherwise), 'atomic' or 'planes'."""
-        check(lib().rpsf_plan_set_overlap_mode(self._handle, {"auto": 0, "atomic": 1, "planes": 2}[mode]))
+        """'auto' (on lattices: 'direct' for 128/256-pixel patches, 'planes' for smaller ones; 'atomic' otherwise),
+        'atomic', 'planes' or 'direct'."""
+        check(lib().rpsf_plan_set_overlap_mode(self._handle, {"auto": 0, "atomic": 1, "planes": 2, "direct": 3}[mode]))
 
     def debug_stamps(self) -> np.ndarray:
         out = np.zeros((self.n_patches, 16), np.uint64)

@@ -77,16 +77,24 @@ struct rpsf_plan {
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t g_elems = 0, gs_elems = 0;
   std::vector<int32_t> h_coords;
-  // overlap-add strategy: colour planes on regular half-overlap lattices, float atomics otherwise
-  int overlap_mode = 0;  // 0 auto, 1 atomics, 2 planes
+  // overlap-add strategy: on regular half-overlap lattices direct accumulation through the XCD's L2 (three-stage
+  // plans) or colour planes + plane sum (the small-patch plans); float atomics for any other corner list
+  int overlap_mode = 0;  // 0 auto, 1 atomics, 2 planes, 3 direct
   int stagger_us = 0, cu_count = 256;
-  // Tail overlap (opt-in, RPSF_SPLIT=1): the last, partial round of patches (ordered last: the bottom lattice
-  // rows) is a second launch whose spare workgroups sum the colour planes of the rows it does not touch.
-  int n_tail = 0;        // patches in the tail launch (0 = no split)
-  int tail_row = 0;      // smallest corner row among the tail patches
-  int split_mode = 0;    // 0 auto, 1 never
   int round_capacity = 0;  // patches the chip holds at once (CUs x resident workgroups x patches per workgroup)
   bool lattice = false;
+  bool direct_ok = false;  // lattice and one patch per workgroup
+  uint4* d_quads = nullptr;        // per processing-order slot: quadrant words (rpsf_core.hpp, store_patch_direct)
+  uint8_t* d_tile_info = nullptr;  // per lattice tile: static side mask | 16 if any patch covers it
+  uint32_t* d_flags = nullptr;     // per (frame, tile)
+  uint32_t* d_dyn = nullptr;       // per (frame, tile)
+  uint32_t* d_chunk_xcc = nullptr; // 8 words
+  size_t flag_frames = 0;
+  uint32_t epoch = 0;
+  int orphan_mod = 0;              // testing aid (RPSF_DEBUG_ORPHAN)
+  hipEvent_t ev_busy = nullptr;    // end of the last apply (applies on different streams are serialised)
+  hipStream_t last_stream = nullptr;
+  bool busy_valid = false;
   int lat_r0 = 0, lat_c0 = 0, nti = 0, ntj = 0;
   uint8_t* d_cover = nullptr;
   int4* d_desc = nullptr;
@@ -124,7 +132,7 @@ static uint64_t morton2(uint32_t a, uint32_t b) {
   return (spread(a) << 1) | spread(b);
 }
 
-// Regular lattice test + colour classes + tile coverage + processing order (host, at plan creation)
+// Regular lattice test + colour classes + tile tables + processing order (host, at plan creation)
 static int setup_lattice(rpsf_plan* p) {
   const int n = p->n_patches, half = p->N / 2;
   int r0 = p->h_coords[0], c0 = p->h_coords[1], r1 = r0, c1 = c0;
@@ -132,73 +140,65 @@ static int setup_lattice(rpsf_plan* p) {
     r0 = std::min(r0, p->h_coords[2 * i]), r1 = std::max(r1, p->h_coords[2 * i]);
     c0 = std::min(c0, p->h_coords[2 * i + 1]), c1 = std::max(c1, p->h_coords[2 * i + 1]);
   }
-  {
-    // tail = the last, partial round of patches: the bottom-most lattice rows, so that the rows above
-    // them are final as soon as the main launch is done
-    std::vector<char> in_tail(n, 0);
-    p->n_tail = 0;
-    const int cap = p->round_capacity;
-    const int n_full = cap > 0 ? (n / cap) * cap : 0, tail = n - n_full;
-    if (p->split_mode == 0 && n_full > 0 && tail > 0 && tail * 10 <= cap * 6) {
-      std::vector<int32_t> by_row(n);
-      for (int i = 0; i < n; ++i) by_row[i] = i;
-      std::sort(by_row.begin(), by_row.end(), [&](int a, int b) {
-        if (p->h_coords[2 * a] != p->h_coords[2 * b]) return p->h_coords[2 * a] > p->h_coords[2 * b];
-        return p->h_coords[2 * a + 1] > p->h_coords[2 * b + 1];
-      });
-      p->tail_row = p->h_coords[2 * by_row[0]];
-      for (int k = 0; k < tail; ++k) {
-        in_tail[by_row[k]] = 1;
-        p->tail_row = std::min(p->tail_row, p->h_coords[2 * by_row[k]]);
-      }
-      p->n_tail = tail;
-    }
-    std::vector<std::pair<uint64_t, int32_t>> keyed(n);
-    for (int i = 0; i < n; ++i)
-      keyed[i] = {((uint64_t)in_tail[i] << 62) |
-                      morton2((uint32_t)((p->h_coords[2 * i] - r0) / half), (uint32_t)((p->h_coords[2 * i + 1] - c0) / half)),
-                  i};
-    std::sort(keyed.begin(), keyed.end());
-    p->h_order.resize(n);
-    for (int i = 0; i < n; ++i) p->h_order[i] = keyed[i].second;
-    if (p->n_tail == 0 && !std::getenv("RPSF_NO_BORDER_FIRST")) {
-      // Patches on the rim of the lattice hang over the image edge and take the slower padded gather / cropped
-      // store path.  Within each XCD's chunk they go first, so that the last, partial round of a launch - the
-      // one the whole chip waits for - is made of interior patches only.  Speed only.
-      const int t = p->N * p->N / 2 / 64, teams = t >= 64 ? 1 : 64 / t;
-      const int chunk = ((n + 7) / 8 + teams - 1) / teams * teams;  // as launch_patches cuts the order
-      auto rim = [&](int32_t i) {
-        const int r = p->h_coords[2 * i], c = p->h_coords[2 * i + 1];
-        return r == r0 || r == r1 || c == c0 || c == c1;
-      };
-      for (int x = 0; x < 8; ++x) {
-        const int lo = std::min(n, x * chunk), hi = std::min(n, lo + chunk);
-        std::stable_partition(p->h_order.begin() + lo, p->h_order.begin() + hi, rim);
-      }
-    }
-  }
   bool ok = true;
   for (int i = 0; i < n && ok; ++i)
     ok = (p->h_coords[2 * i] - r0) % half == 0 && (p->h_coords[2 * i + 1] - c0) % half == 0;
-  std::vector<uint8_t> cls(n, 0), cover;
   int nti = 0, ntj = 0;
   if (ok) {
     nti = (r1 - r0) / half + 2, ntj = (c1 - c0) / half + 2;
-    if ((size_t)nti * ntj > ((size_t)1 << 26)) ok = false;
+    if ((size_t)nti * ntj >= ((size_t)1 << 24)) ok = false;
   }
+  std::vector<uint8_t> cls(n, 0);
+  std::vector<int32_t> cell;  // lattice cell -> patch (or -1)
+  const int nli = nti - 1, nlj = ntj - 1;
   if (ok) {
-    std::vector<uint8_t> seen((size_t)nti * ntj, 0);
-    cover.assign((size_t)nti * ntj, 0);
+    cell.assign((size_t)nli * nlj, -1);
     for (int i = 0; i < n && ok; ++i) {
-      int li = (p->h_coords[2 * i] - r0) / half, lj = (p->h_coords[2 * i + 1] - c0) / half;
-      if (seen[(size_t)li * ntj + lj]) ok = false;  // duplicate corner: two patches in one plane cell
-      seen[(size_t)li * ntj + lj] = 1;
+      const int li = (p->h_coords[2 * i] - r0) / half, lj = (p->h_coords[2 * i + 1] - c0) / half;
+      if (cell[(size_t)li * nlj + lj] >= 0) ok = false;  // duplicate corner: two patches in one plane cell
+      cell[(size_t)li * nlj + lj] = i;
       cls[i] = (uint8_t)(((li & 1) << 1) | (lj & 1));
-      for (int a = 0; a < 2; ++a)
-        for (int b = 0; b < 2; ++b) cover[(size_t)(li + a) * ntj + lj + b] |= (uint8_t)(1u << cls[i]);
     }
   }
   p->lattice = ok;
+  const int t = p->N * p->N / 2 / 64, teams = t >= 64 ? 1 : 64 / t;
+  const int chunk = ((n + 7) / 8 + teams - 1) / teams * teams;  // as launch_patches cuts the order
+  p->direct_ok = ok && teams == 1;
+  // ---- processing order: 8 chunks, one per XCD (workgroups b and b + 8 share one) ----
+  p->h_order.resize(n);
+  if (ok) {
+    // Column strips walked boustrophedon, cut into 8 equal runs: compact regions, so that the four patches over a
+    // tile mostly run on one XCD (they read the same pixels through one L2, and the tile can be accumulated there).
+    const int strips = nlj >= 8 ? 4 : 1;
+    int k = 0;
+    for (int s2 = 0; s2 < strips; ++s2) {
+      const int ja = (int)((long)nlj * s2 / strips), jb = (int)((long)nlj * (s2 + 1) / strips);
+      for (int step = 0; step < nli; ++step) {
+        const int li = (s2 & 1) ? nli - 1 - step : step;
+        for (int lj = ja; lj < jb; ++lj)
+          if (cell[(size_t)li * nlj + lj] >= 0) p->h_order[k++] = cell[(size_t)li * nlj + lj];
+      }
+    }
+    // Inside a chunk: runs of as many patches as one XCD holds at a time, each run sorted by colour.  A run is a
+    // compact lattice region (its patches share pixels through the L2 while they are resident together), and its
+    // four colours reach their store phase one after the other: a CU that ran a colour-0 patch frees first and is
+    // handed the next run's colour-0 patch, so after the first run the colours stay staggered by one store phase
+    // and a patch finds its overlapping predecessors (earlier in this order) already done.
+    const int run = std::max(4, p->round_capacity / 8);
+    if (!std::getenv("RPSF_NO_COLOUR_RUNS"))
+      for (int x = 0; x < 8; ++x) {
+        const int lo = std::min(n, x * chunk), hi = std::min(n, lo + chunk);
+        for (int a2 = lo; a2 < hi; a2 += run)
+          std::stable_sort(p->h_order.begin() + a2, p->h_order.begin() + std::min(hi, a2 + run),
+                           [&](int32_t u, int32_t w2) { return cls[u] < cls[w2]; });
+      }
+  } else {
+    std::vector<std::pair<uint64_t, int32_t>> keyed(n);
+    for (int i = 0; i < n; ++i)
+      keyed[i] = {morton2((uint32_t)((p->h_coords[2 * i] - r0) / half), (uint32_t)((p->h_coords[2 * i + 1] - c0) / half)), i};
+    std::sort(keyed.begin(), keyed.end());
+    for (int i = 0; i < n; ++i) p->h_order[i] = keyed[i].second;
+  }
   {
     std::vector<int4> desc(n);
     for (int s2 = 0; s2 < n; ++s2) {
@@ -210,8 +210,60 @@ static int setup_lattice(rpsf_plan* p) {
   }
   if (!ok) return RPSF_OK;
   p->lat_r0 = r0, p->lat_c0 = c0, p->nti = nti, p->ntj = ntj;
+  // ---- tiles: coverage, owner chunk, ranks ----
+  std::vector<int> chunk_of(n), seq_of(n);
+  for (int s2 = 0; s2 < n; ++s2) chunk_of[p->h_order[s2]] = s2 / chunk, seq_of[p->h_order[s2]] = s2;
+  std::vector<uint8_t> cover((size_t)nti * ntj, 0), tile_info((size_t)nti * ntj, 0);
+  std::vector<uint32_t> quad_of((size_t)n * 4, quad_word(QUAD_NONE, 0, 0));
+  for (int ti = 0; ti < nti; ++ti)
+    for (int tj = 0; tj < ntj; ++tj) {
+      int who[4], nwho = 0;  // contributors by colour
+      for (int a2 = 0; a2 < 2; ++a2)
+        for (int b2 = 0; b2 < 2; ++b2) {
+          const int li = ti - a2, lj = tj - b2;
+          if (li < 0 || lj < 0 || li >= nli || lj >= nlj) continue;
+          const int i = cell[(size_t)li * nlj + lj];
+          if (i >= 0) who[nwho++] = i;
+        }
+      std::sort(who, who + nwho, [&](int a2, int b2) { return seq_of[a2] < seq_of[b2]; });  // accumulation order = processing order
+      const size_t tile = (size_t)ti * ntj + tj;
+      int owner = -1, best = 0;
+      for (int k = 0; k < nwho; ++k) {
+        cover[tile] |= (uint8_t)(1u << cls[who[k]]);
+        int cnt = 0;
+        for (int m = 0; m < nwho; ++m) cnt += chunk_of[who[m]] == chunk_of[who[k]];
+        if (cnt > best) best = cnt, owner = chunk_of[who[k]];  // ties: the chunk of the earliest contributor
+      }
+      int rank = 0;
+      uint8_t side = 0;
+      for (int k = 0; k < nwho; ++k) {
+        const int i = who[k];
+        const int li = (p->h_coords[2 * i] - r0) / half, lj = (p->h_coords[2 * i + 1] - c0) / half;
+        const int q = 2 * (ti - li) + (tj - lj);
+        if (p->direct_ok && chunk_of[i] == owner) {
+          quad_of[(size_t)i * 4 + q] = quad_word(QUAD_DIRECT, (uint32_t)rank++, (uint32_t)tile);
+        } else {
+          quad_of[(size_t)i * 4 + q] = quad_word(QUAD_SIDE, 0, (uint32_t)tile);
+          side |= (uint8_t)(1u << cls[i]);
+        }
+      }
+      tile_info[tile] = (uint8_t)(side | (nwho ? 16 : 0));
+    }
   HIP_TRY(hipMalloc(&p->d_cover, cover.size()));
   HIP_TRY(hipMemcpy(p->d_cover, cover.data(), cover.size(), hipMemcpyHostToDevice));
+  if (p->direct_ok) {
+    std::vector<uint4> quads(n);
+    for (int s2 = 0; s2 < n; ++s2) {
+      const uint32_t* q = &quad_of[(size_t)p->h_order[s2] * 4];
+      quads[s2] = make_uint4(q[0], q[1], q[2], q[3]);
+    }
+    HIP_TRY(hipMalloc(&p->d_quads, sizeof(uint4) * n));
+    HIP_TRY(hipMemcpy(p->d_quads, quads.data(), sizeof(uint4) * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&p->d_tile_info, tile_info.size()));
+    HIP_TRY(hipMemcpy(p->d_tile_info, tile_info.data(), tile_info.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&p->d_chunk_xcc, 8 * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(p->d_chunk_xcc, 0, 8 * sizeof(uint32_t)));
+  }
   return RPSF_OK;
 }
 
@@ -393,9 +445,8 @@ extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int
       return RPSF_OK;
     });
     if (rl != RPSF_OK) return rl;
-    // Tail/sum fusion is opt-in: measured neutral on MI355X (the plane sum is HBM-bound by itself), see DESIGN.md
-    p->split_mode = 1;
-    if (const char* e = std::getenv("RPSF_SPLIT")) p->split_mode = (e[0] && e[0] != '0') ? 0 : 1;
+    if (const char* e = std::getenv("RPSF_DEBUG_ORPHAN")) p->orphan_mod = std::atoi(e);  // testing aid, see direct_store
+    HIP_TRY(hipEventCreateWithFlags(&p->ev_busy, hipEventDisableTiming));
     rl = setup_lattice(p);
     if (rl != RPSF_OK) return rl;
     return dispatch_n(N, [&]<class C>() -> int {
@@ -445,6 +496,12 @@ extern "C" void rpsf_plan_destroy(rpsf_plan* p) {
   (void)hipFree(p->d_win_generic);
   if (p->fft_plan && g_hipfft.destroy) (void)g_hipfft.destroy(p->fft_plan);
   (void)hipFree(p->d_planes);
+  (void)hipFree(p->d_quads);
+  (void)hipFree(p->d_tile_info);
+  (void)hipFree(p->d_flags);
+  (void)hipFree(p->d_dyn);
+  (void)hipFree(p->d_chunk_xcc);
+  if (p->ev_busy) (void)hipEventDestroy(p->ev_busy);
   (void)hipHostFree(p->h_pin_in);
   (void)hipHostFree(p->h_pin_out);
   for (auto& e : p->ev_chunk)
@@ -561,18 +618,20 @@ struct Batch {
   size_t im_stride = 0, out_stride = 0;
 };
 
-// sum_rows > 0: append workgroups that sum colour-plane rows [0, sum_rows) (tail launch only)
-static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const rpsf_geometry& g, bool planes,
-                          int seq_base, int count, hipStream_t st, int sum_rows = 0, Batch b = Batch()) {
+enum OverlapKind { OV_ATOMIC = 0, OV_PLANES = 1, OV_DIRECT = 2 };
+
+static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const rpsf_geometry& g, OverlapKind kind,
+                          hipStream_t st, Batch b = Batch()) {
   return dispatch_n(p->N, [&]<class C>() -> int {
-    PatchParams pp;
+    const int count = p->n_patches;
+    PatchParams pp{};
     pp.im = ImageView{d_img, g.height, g.width, g.ld_image, g.pad_mode, g.pad_value, g.image_row0, g.image_rows};
-    if (planes)
+    if (kind != OV_ATOMIC)
       pp.ov = OutView{p->d_planes, g.height, g.width, g.width, g.out_row0, g.out_rows, p->planes_floats, p->d_sink};
     else
       pp.ov = OutView{d_out, g.height, g.width, g.ld_out, g.out_row0, g.out_rows, 0, p->d_sink};
     pp.origin_row = g.origin_row, pp.origin_col = g.origin_col;
-    pp.desc = p->d_desc, pp.n_patches = count, pp.seq_base = seq_base;
+    pp.desc = p->d_desc, pp.n_patches = count, pp.seq_base = 0;
     pp.tab = p->d_tab, pp.pairtab = p->d_pairtab, pp.tw = p->d_tw, pp.win = p->d_win, pp.g = p->d_g, pp.gs = p->d_gs;
     pp.stamps = p->d_stamps;
     constexpr int TEAMS = Launch<C>::TEAMS;
@@ -580,17 +639,38 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
     pp.stagger_ticks = p->stagger_us * 100;
     pp.stagger_blocks = p->cu_count * std::max(1, 512 / Launch<C>::WG);
     pp.n_frames = b.frames, pp.im_frame_floats = b.im_stride;
-    pp.ov_frame_floats = planes ? 4 * p->planes_floats : b.out_stride;
+    pp.ov_frame_floats = kind != OV_ATOMIC ? 4 * p->planes_floats : b.out_stride;
+    pp.dv = OutView{nullptr, 0, 0, 0, 0, 0, 0, nullptr};
+    if (kind == OV_DIRECT) {
+      pp.dv = OutView{d_out, g.height, g.width, g.ld_out, g.out_row0, g.out_rows, 0, p->d_sink};
+      pp.dv_frame_floats = b.out_stride;
+      pp.quads = p->d_quads, pp.flags = p->d_flags, pp.dyn_side = p->d_dyn, pp.chunk_xcc = p->d_chunk_xcc;
+      pp.flag_epoch = p->epoch, pp.n_tiles = (uint32_t)(p->nti * p->ntj), pp.orphan_mod = p->orphan_mod;
+    }
     const size_t blocks = (size_t)8 * (pp.chunk / TEAMS) * b.frames;
     if (blocks > 0x7fffffffu) return fail(RPSF_E_BADARG, "batch too large for one launch");
-    unsigned grid = (unsigned)blocks;
-    pp.patch_blocks = (int)grid;
-    pp.sum = make_sum_params(p, d_out, g, 0, sum_rows);
-    if (sum_rows > 0) grid += (unsigned)std::max(8, p->round_capacity / TEAMS - (int)grid);  // one per CU left idle by the tail
-    patch_kernel<C><<<dim3(grid), dim3(Launch<C>::WG), Launch<C>::LDS_BYTES, st>>>(pp);
+    patch_kernel<C><<<dim3((unsigned)blocks), dim3(Launch<C>::WG), Launch<C>::LDS_BYTES, st>>>(pp);
     HIP_TRY(hipGetLastError());
     return RPSF_OK;
   });
+}
+
+static int launch_fixup(rpsf_plan* p, float* d_out, const rpsf_geometry& g, hipStream_t st, Batch b) {
+  FixParams fp{};
+  fp.planes = p->d_planes, fp.plane_stride = p->planes_floats, fp.planes_frame_floats = 4 * p->planes_floats, fp.ld_planes = g.width;
+  fp.out = d_out, fp.ld_out = g.ld_out, fp.out_frame_floats = b.out_stride;
+  fp.rows = g.out_rows, fp.W = g.width, fp.row0 = g.out_row0;
+  fp.lat_r0 = p->lat_r0 + g.origin_row, fp.lat_c0 = p->lat_c0 + g.origin_col, fp.half = p->N / 2, fp.ntj = p->ntj;
+  fp.tile_info = p->d_tile_info, fp.flags = p->d_flags, fp.dyn_side = p->d_dyn;
+  fp.epoch = p->epoch, fp.n_tiles = (uint32_t)(p->nti * p->ntj);
+  for (int f0 = 0; f0 < b.frames; f0 += 65535) {  // grid.y limit
+    FixParams q = fp;
+    q.planes += (size_t)f0 * q.planes_frame_floats, q.out += (size_t)f0 * q.out_frame_floats;
+    q.flags += (size_t)f0 * q.n_tiles, q.dyn_side += (size_t)f0 * q.n_tiles;
+    fixup_kernel<<<dim3(fp.n_tiles * FIX_SUB, (unsigned)std::min(65535, b.frames - f0)), dim3(256), 0, st>>>(q);
+  }
+  HIP_TRY(hipGetLastError());
+  return RPSF_OK;
 }
 
 static int launch_sum(rpsf_plan* p, float* d_out, const rpsf_geometry& g, int row_begin, int row_end, hipStream_t st,
@@ -609,7 +689,14 @@ static int launch_sum(rpsf_plan* p, float* d_out, const rpsf_geometry& g, int ro
 }
 
 // One apply.  ev_k0 / ev_k1 (optional) bracket the patch-kernel launches for timing.
-static bool use_planes(const rpsf_plan* p) { return p->overlap_mode == 2 || (p->overlap_mode == 0 && p->lattice); }
+static OverlapKind overlap_kind(const rpsf_plan* p) {
+  switch (p->overlap_mode) {
+    case 1: return OV_ATOMIC;
+    case 2: return OV_PLANES;
+    case 3: return OV_DIRECT;
+    default: return p->lattice ? OV_PLANES : OV_ATOMIC;  // direct stays opt-in until it beats the planes
+  }
+}
 static size_t plane_floats_needed(const rpsf_geometry& g) { return ((size_t)g.out_rows * g.width + 3) & ~(size_t)3; }
 
 static int launch_apply_generic(rpsf_plan* p, const float* d_img, float* d_out, const rpsf_geometry& g, hipStream_t st,
@@ -657,51 +744,67 @@ static int launch_apply_generic(rpsf_plan* p, const float* d_img, float* d_out, 
 static int launch_apply(rpsf_plan* p, const float* d_img, float* d_out, const rpsf_geometry& g, hipStream_t st,
                         hipEvent_t ev_k0, hipEvent_t ev_k1 = nullptr, Batch b = Batch()) {
   if (p->generic) return launch_apply_generic(p, d_img, d_out, g, st, ev_k0, ev_k1, b);
-  const bool planes = use_planes(p);
-  if (planes && !p->lattice) return fail(RPSF_E_STATE, "colour planes need a regular half-overlap lattice of patch corners");
-  if (planes) {
+  const OverlapKind kind = overlap_kind(p);
+  if (kind != OV_ATOMIC && !p->lattice) return fail(RPSF_E_STATE, "colour planes need a regular half-overlap lattice of patch corners");
+  if (kind == OV_DIRECT && !p->direct_ok) return fail(RPSF_E_STATE, "direct overlap-add needs a lattice and a 128- or 256-pixel patch");
+  // The plan's scratch (planes, flags) serves one apply at a time: an apply on another stream waits for the last one.
+  if (p->busy_valid && st != p->last_stream) HIP_TRY(hipStreamWaitEvent(st, p->ev_busy, 0));
+  if (kind != OV_ATOMIC) {
     const size_t need = plane_floats_needed(g);
     if (need > p->planes_floats || (size_t)b.frames > p->planes_frames) {  // four planes per frame in flight
       const size_t per = std::max(need, p->planes_floats), frames = std::max((size_t)b.frames, p->planes_frames);
-      HIP_TRY(hipStreamSynchronize(st));
+      HIP_TRY(hipDeviceSynchronize());  // earlier applies, on whatever stream, may still use the old planes
       (void)hipFree(p->d_planes);
       p->d_planes = nullptr, p->planes_floats = 0, p->planes_frames = 0;
       HIP_TRY(hipMalloc(&p->d_planes, 4 * per * frames * sizeof(float)));
       p->planes_floats = per, p->planes_frames = frames;
     }
-  } else {
+  }
+  bool clear = kind == OV_ATOMIC;
+  if (kind == OV_DIRECT) {
+    const size_t n_tiles = (size_t)p->nti * p->ntj;
+    if ((size_t)b.frames > p->flag_frames) {
+      HIP_TRY(hipDeviceSynchronize());
+      (void)hipFree(p->d_flags);
+      (void)hipFree(p->d_dyn);
+      p->d_flags = p->d_dyn = nullptr, p->flag_frames = 0;
+      HIP_TRY(hipMalloc(&p->d_flags, n_tiles * b.frames * sizeof(uint32_t)));
+      HIP_TRY(hipMalloc(&p->d_dyn, n_tiles * b.frames * sizeof(uint32_t)));
+      HIP_TRY(hipMemset(p->d_flags, 0, n_tiles * b.frames * sizeof(uint32_t)));
+      HIP_TRY(hipMemset(p->d_dyn, 0, n_tiles * b.frames * sizeof(uint32_t)));
+      p->flag_frames = (size_t)b.frames;
+    }
+    if (++p->epoch >= (1u << 24) - 1) {  // the epoch field of the flag words is 24 bits wide
+      HIP_TRY(hipMemsetAsync(p->d_flags, 0, n_tiles * p->flag_frames * sizeof(uint32_t), st));
+      HIP_TRY(hipMemsetAsync(p->d_chunk_xcc, 0, 8 * sizeof(uint32_t), st));
+      p->epoch = 1;
+    }
+    // pixels of the resident window that no lattice tile covers are never written by the kernels below
+    const int half = p->N / 2;
+    const long tr0 = (long)p->lat_r0 + g.origin_row, tc0 = (long)p->lat_c0 + g.origin_col;
+    clear = tr0 > g.out_row0 || tr0 + (long)p->nti * half < (long)g.out_row0 + g.out_rows || tc0 > 0 ||
+            tc0 + (long)p->ntj * half < g.width;
+  }
+  if (clear)
     for (int f = 0; f < b.frames; ++f)
       HIP_TRY(hipMemset2DAsync(d_out + (size_t)f * b.out_stride, (size_t)g.ld_out * sizeof(float), 0,
                                (size_t)g.width * sizeof(float), g.out_rows, st));
-  }
   if (ev_k0) HIP_TRY(hipEventRecord(ev_k0, st));
-  const int n = p->n_patches;
-  // window row (relative to out_row0) from which the tail patches contribute
-  int split_row = p->n_tail > 0 ? std::min(std::max(p->tail_row + g.origin_row - g.out_row0, 0), g.out_rows) : g.out_rows;
-  const bool split = planes && b.frames == 1 && p->n_tail > 0 && split_row > 0 && split_row < g.out_rows;
-  int rc;
-  if (!split) {
-    rc = launch_patches(p, d_img, d_out, g, planes, 0, n, st, 0, b);
-    if (rc != RPSF_OK) return rc;
-    if (ev_k1) HIP_TRY(hipEventRecord(ev_k1, st));
-    if (planes) rc = launch_sum(p, d_out, g, 0, g.out_rows, st, b);
-    return rc;
-  }
-  // main rounds; then ONE launch whose first workgroups are the tail patches (dispatched first, onto empty
-  // CUs) and whose other workgroups sum the colour planes of the rows the tail does not touch; then the
-  // remaining rows.  (Two streams do not work: the sum's small blocks occupy every CU first and the tail
-  // patches, which need a whole CU each, wait for them - measured.)
-  rc = launch_patches(p, d_img, d_out, g, true, 0, n - p->n_tail, st);
-  if (rc != RPSF_OK) return rc;
-  rc = launch_patches(p, d_img, d_out, g, true, n - p->n_tail, p->n_tail, st, split_row);
+  int rc = launch_patches(p, d_img, d_out, g, kind, st, b);
   if (rc != RPSF_OK) return rc;
   if (ev_k1) HIP_TRY(hipEventRecord(ev_k1, st));
-  return launch_sum(p, d_out, g, split_row, g.out_rows, st);
+  if (kind == OV_PLANES) rc = launch_sum(p, d_out, g, 0, g.out_rows, st, b);
+  if (kind == OV_DIRECT) rc = launch_fixup(p, d_out, g, st, b);
+  if (rc != RPSF_OK) return rc;
+  HIP_TRY(hipEventRecord(p->ev_busy, st));
+  p->last_stream = st, p->busy_valid = true;
+  return RPSF_OK;
 }
 
 extern "C" int rpsf_plan_set_overlap_mode(rpsf_plan* p, int mode) {
-  if (!p || mode < 0 || mode > 2) return fail(RPSF_E_BADARG, "mode must be 0 (auto), 1 (atomics) or 2 (colour planes)");
+  if (!p || mode < 0 || mode > 3) return fail(RPSF_E_BADARG, "mode must be 0 (auto), 1 (atomics), 2 (colour planes) or 3 (direct)");
   if (mode == 2 && !p->lattice) return fail(RPSF_E_STATE, "colour planes need a regular half-overlap lattice of patch corners");
+  if (mode == 3 && !p->direct_ok) return fail(RPSF_E_STATE, "direct overlap-add needs a regular half-overlap lattice and a 128- or 256-pixel patch");
   p->overlap_mode = mode;
   return RPSF_OK;
 }
@@ -764,7 +867,7 @@ extern "C" int rpsf_apply(rpsf_plan* p, const float* image_host, int height, int
 // Frames per launch group: the colour planes take 16 bytes per output pixel per frame in flight; keep
 // them under a quarter of the device memory.
 static int batch_group_frames(const rpsf_plan* p, const rpsf_geometry& g, int n_frames) {
-  if (p->generic || !use_planes(p)) return n_frames;
+  if (p->generic || overlap_kind(p) == OV_ATOMIC) return n_frames;
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) total_b = (size_t)64 << 30;
   const size_t per_frame = 16 * plane_floats_needed(g);

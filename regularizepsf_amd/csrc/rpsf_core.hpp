@@ -1040,6 +1040,88 @@ RPSF_HD void store_patch(int t, const cf* v, const OutView& ov, int plane, int p
   });
 }
 
+// ------------------------------------------------------------------------------------------
+// Direct overlap-add (three-stage plans on a regular lattice).  Every lattice tile (N/2 x N/2 pixels) has up to
+// four contributing patches, one per colour class.  The plan cuts the processing order into 8 chunks, one per
+// XCD, and gives every tile to the chunk that holds most of its contributors: those accumulate straight into
+// the output image, in colour order, through that XCD's L2 - the first one stores, the later ones wait for
+// their predecessor's flag, read the running sum (L1-bypassing loads), add and store.  Contributors from other
+// chunks ("side") store into their colour plane as before and a small fix-up kernel adds them afterwards.
+// Quadrant word (one per patch quadrant, plan constant): bits 0-1 mode, 2-4 rank among the tile's direct
+// contributors, 8-31 tile index; bits 5 and 7 are set at run time (accumulate onto what the output holds / sent
+// to the plane although the table said direct).
+// Tile flag word: (epoch << 8) | (output tile initialised << 3) | direct contributors done.
+// ------------------------------------------------------------------------------------------
+enum QuadMode : uint32_t { QUAD_NONE = 0, QUAD_SIDE = 1, QUAD_DIRECT = 2 };
+RPSF_HD uint32_t quad_word(uint32_t mode, uint32_t rank, uint32_t tile) { return mode | (rank << 2) | (tile << 8); }
+RPSF_HD uint32_t quad_mode(uint32_t w) { return w & 3u; }
+RPSF_HD uint32_t quad_rank(uint32_t w) { return (w >> 2) & 7u; }
+RPSF_HD uint32_t quad_tile(uint32_t w) { return w >> 8; }
+constexpr uint32_t QUAD_ACC = 0x20u, QUAD_DEMOTED = 0x80u;
+
+// qw[q], q = 2*(bottom half) + (right half).  LOAD2 / LOAD1: coherent (L1-bypassing) 8- and 4-byte loads of the
+// running sum.  A quadrant whose word says QUAD_NONE lies outside the image and is skipped.
+template <class C, class LOAD2, class LOAD1>
+RPSF_HD void store_patch_direct(int t, const cf* v, const OutView& pv, const OutView& dv, int plane, int pr, int pc,
+                                const float* __restrict__ win, const uint32_t* qw, LOAD2&& load2, LOAD1&& load1) {
+  static_assert(C::S3 && C::A1 >= 1 && C::B1 >= 1, "the top row / column bits must be register digits");
+  ThreadPos<C> tp(t);
+  constexpr int NR = 1 << C::A1, NCOL = 1 << C::B1;
+  float* pbase = pv.out + (size_t)plane * pv.plane_stride;
+  const bool fast = patch_inside<C>(pr, pc, dv.H, dv.W, dv.row0, dv.rows) && pairs_aligned(pbase, pv.ld, pc) &&
+                    pairs_aligned(dv.out, dv.ld, pc);
+  if (fast) {
+    float* prow0 = pbase + (size_t)(pr - pv.row0) * pv.ld + pc;
+    float* drow0 = dv.out + (size_t)(pr - dv.row0) * dv.ld + pc;
+    StaticFor<0, NR>::run([&]<int R1>() RPSF_AI {
+      const int r = (R1 << (C::A2 + C::AL)) + tp.r_rest;
+      const float wr = win[r];
+      cf old[NCOL];
+      StaticFor<0, NCOL>::run([&]<int C1>() RPSF_AI {
+        constexpr int Q = 2 * (R1 >= NR / 2) + (C1 >= NCOL / 2);
+        const int c = (C1 << (C::B2 + C::BL)) + tp.c_rest;
+        old[C1] = cf{0.f, 0.f};
+        if (quad_mode(qw[Q]) == QUAD_DIRECT && (qw[Q] & QUAD_ACC)) old[C1] = load2(drow0 + (size_t)r * dv.ld + 2 * c);
+      });
+      StaticFor<0, NCOL>::run([&]<int C1>() RPSF_AI {
+        constexpr int Q = 2 * (R1 >= NR / 2) + (C1 >= NCOL / 2);
+        const int c = (C1 << (C::B2 + C::BL)) + tp.c_rest;
+        const cf w2 = *reinterpret_cast<const cf*>(win + 2 * c);
+        const cf val = v[R1 * NCOL + C1] * (w2 * wr);
+        if (quad_mode(qw[Q]) == QUAD_DIRECT) *reinterpret_cast<cf*>(drow0 + (size_t)r * dv.ld + 2 * c) = old[C1] + val;
+        else if (quad_mode(qw[Q]) == QUAD_SIDE) store_stream8(prow0 + (size_t)r * pv.ld + 2 * c, val);
+      });
+    });
+    return;
+  }
+  StaticFor<0, NR>::run([&]<int R1>() RPSF_AI {
+    const int r = (R1 << (C::A2 + C::AL)) + tp.r_rest;
+    const float wr = win[r];
+    const int y = pr + r, yl = y - dv.row0;
+    if (y >= 0 && y < dv.H && yl >= 0 && yl < dv.rows) {
+      StaticFor<0, NCOL>::run([&]<int C1>() RPSF_AI {
+        constexpr int Q = 2 * (R1 >= NR / 2) + (C1 >= NCOL / 2);
+        const uint32_t mode = quad_mode(qw[Q]);
+        const bool rmw = (qw[Q] & QUAD_ACC) != 0;
+        const int c = (C1 << (C::B2 + C::BL)) + tp.c_rest;
+        const int x0 = pc + 2 * c;
+        const cf val = v[R1 * NCOL + C1];
+        const float a0 = val.x * (wr * win[2 * c]), a1 = val.y * (wr * win[2 * c + 1]);
+        const bool in0 = x0 >= 0 && x0 < dv.W, in1 = x0 + 1 >= 0 && x0 + 1 < dv.W;
+        if (mode == QUAD_DIRECT) {
+          float* row = dv.out + (size_t)yl * dv.ld;
+          if (in0) row[x0] = (rmw ? load1(row + x0) : 0.f) + a0;
+          if (in1) row[x0 + 1] = (rmw ? load1(row + x0 + 1) : 0.f) + a1;
+        } else if (mode == QUAD_SIDE) {
+          float* row = pbase + (size_t)(y - pv.row0) * pv.ld;
+          if (in0) row[x0] = a0;
+          if (in1) row[x0 + 1] = a1;
+        }
+      });
+    }
+  });
+}
+
 // Sum of the colour planes at one pixel.  cover = 4-bit mask of the classes that have a patch over the
 // pixel's lattice tile (planes are never cleared, so classes without a patch must not be read).
 RPSF_HD float sum_planes_at(const float* planes, size_t plane_stride, size_t offset, int cover) {

@@ -75,50 +75,6 @@ __global__ void sum_planes_kernel(SumParams p) {
   sum_planes_group(p, yl + p.row_begin, xg * 4, sum_vector_ok(p));
 }
 
-// the same work done by `nblocks` co-operating workgroups of a larger launch (grid-stride).  These
-// workgroups are as register-heavy as the patch kernel (one per CU), so each thread keeps eight
-// independent 4-pixel groups (32 loads) in flight to cover the HBM latency.
-__device__ __forceinline__ void sum_planes_worker(const SumParams& p, int block, int nblocks) {
-  const unsigned groups = (unsigned)(p.W + 3) >> 2;
-  const size_t total = (size_t)groups * p.rows;
-  const size_t stride = (size_t)nblocks * blockDim.x;
-  size_t idx = (size_t)block * blockDim.x + threadIdx.x;
-  const bool vector_ok = sum_vector_ok(p) && (p.W & 3) == 0;
-  const bool small = total < ((size_t)1 << 32);
-  constexpr int SU = 8;
-  if (vector_ok) {
-    for (; idx + (SU - 1) * stride < total; idx += SU * stride) {
-      int cov[SU], yl[SU], x[SU];
-      bool uniform = true;
-#pragma unroll
-      for (int u = 0; u < SU; ++u) {
-        size_t i = idx + u * stride;
-        yl[u] = (small ? (int)((unsigned)i / groups) : (int)(i / groups)) + p.row_begin;
-        x[u] = (small ? (int)((unsigned)i % groups) : (int)(i % groups)) * 4;
-        cov[u] = cover_at(p, yl[u] + p.row0, x[u]);
-        uniform = uniform && cov[u] == cover_at(p, yl[u] + p.row0, x[u] + 3);
-      }
-      if (!uniform) {  // a group straddles two lattice tiles: generic path
-#pragma unroll
-        for (int u = 0; u < SU; ++u) sum_planes_group(p, yl[u], x[u], true);
-        continue;
-      }
-      float4 v[SU][4];
-#pragma unroll
-      for (int u = 0; u < SU; ++u)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[u][k] = load_plane4(p, k, (size_t)yl[u] * p.ld_planes + x[u], cov[u]);
-#pragma unroll
-      for (int u = 0; u < SU; ++u)
-        store_out4(p.out + (size_t)yl[u] * p.ld_out + x[u],
-                   make_float4(((v[u][0].x + v[u][1].x) + v[u][2].x) + v[u][3].x, ((v[u][0].y + v[u][1].y) + v[u][2].y) + v[u][3].y,
-                               ((v[u][0].z + v[u][1].z) + v[u][2].z) + v[u][3].z, ((v[u][0].w + v[u][1].w) + v[u][2].w) + v[u][3].w));
-    }
-  }
-  for (; idx < total; idx += stride)
-    sum_planes_group(p, (int)(idx / groups) + p.row_begin, (int)(idx % groups) * 4, vector_ok);
-}
-
 // ------------------------------------------------------------------------------------------------
 // K1
 // ------------------------------------------------------------------------------------------------
@@ -129,9 +85,7 @@ struct PatchParams {
   const int4* desc;         // per processing-order slot: {corner row, corner col, patch index, colour plane}
                             // (one 16-byte load instead of the order -> coords -> plane pointer chase)
   int chunk;                // patches per XCD chunk
-  int seq_base;             // first processing-order slot of this launch (the apply may be split in two launches)
-  int patch_blocks;         // blocks [0, patch_blocks) process patches; blocks beyond it sum colour planes
-  SumParams sum;            // (tail launch: the rows the tail patches do not touch are summed by the idle CUs)
+  int seq_base;             // first processing-order slot of this launch
   unsigned long long* stamps;  // diagnostic builds (RPSF_STAMPS): 16 phase timestamps per patch
   int stagger_ticks;        // start-up stagger of the first resident workgroups, in 10 ns ticks (0 = off)
   int stagger_blocks;       // how many leading blocks are staggered (= resident workgroup capacity)
@@ -145,6 +99,16 @@ struct PatchParams {
   const float* win;
   const cf* g;
   const cf* gs;
+  // direct overlap-add (rpsf_core.hpp, store_patch_direct); dv.out == nullptr: off
+  OutView dv;                 // the output image itself
+  size_t dv_frame_floats;     // batch: frame f accumulates into dv.out + f * dv_frame_floats
+  const uint4* quads;         // per processing-order slot: the four quadrant words
+  uint32_t* flags;            // per (frame, tile): (epoch << 8) | (tile initialised << 3) | direct contributors done
+  uint32_t* dyn_side;         // per (frame, tile): (epoch << 8) | colour bits of contributors demoted to their plane at run time
+  uint32_t* chunk_xcc;        // per chunk: (epoch << 8) | (XCC id + 1) of the first workgroup that registered
+  uint32_t flag_epoch;        // 1 .. 2^24-1, new for every apply
+  uint32_t n_tiles;
+  int orphan_mod;             // testing aid: workgroups with seq % orphan_mod == 1 behave as if they ran on a foreign XCD
 };
 
 template <class C>
@@ -178,18 +142,93 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 #define STAMP(i) ((void)0)
 #endif
 
+// Direct overlap-add epilogue of one workgroup (= one patch; three-stage plans only).  See rpsf_core.hpp,
+// store_patch_direct, for the scheme.  Same-XCD visibility needs no cache maintenance: stores go through to the
+// XCD's L2 (complete once vmcnt has drained) and the successor reads them with L1-bypassing loads.  That the
+// workgroups of one chunk really share an XCD is an observation about the dispatcher, not a guarantee, so it is
+// checked: the first workgroup of a chunk registers its XCC id, and one that finds itself elsewhere ("orphan")
+// sends all four quadrants to its colour plane, marks them in dyn_side for the fix-up kernel and only keeps
+// the flags moving.
+template <class C>
+__device__ __forceinline__ void direct_store(const PatchParams& p, int t, const cf* v, const OutView& ov, int frame, int seq,
+                                             int plane, int pr, int pc, const float* win, uint32_t* scratch) {
+  OutView dv = p.dv;
+  dv.out += (size_t)frame * p.dv_frame_floats;
+  const uint4 q4 = p.quads[p.seq_base + seq];
+  uint32_t qw[4] = {q4.x, q4.y, q4.z, q4.w};
+  uint32_t* flags = p.flags + (size_t)frame * p.n_tiles;
+  const uint32_t epoch = p.flag_epoch;
+  // ---- where am I? ----
+  if (threadIdx.x == 0) {
+    uint32_t xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+    const uint32_t mine = (epoch << 8) | (xcc + 1);
+    uint32_t* reg = p.chunk_xcc + (blockIdx.x & 7);
+    uint32_t seen = __hip_atomic_load(reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while ((seen >> 8) != epoch) {
+      if (__hip_atomic_compare_exchange_strong(reg, &seen, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        seen = mine;
+    }
+    bool orphan = seen != mine;
+    if (p.orphan_mod > 0 && seq % p.orphan_mod == 1) orphan = true;
+    scratch[0] = orphan ? 1u : 0u;
+  }
+  // ---- wait for the predecessors of the quadrants that accumulate into the output ----
+  if (threadIdx.x < 4) {
+    const uint32_t w = qw[threadIdx.x];
+    uint32_t init = 0;
+    if (quad_mode(w) == QUAD_DIRECT && quad_rank(w) > 0) {
+      const uint32_t want = (epoch << 8) | quad_rank(w);
+      uint32_t f;
+      while ((((f = __hip_atomic_load(flags + quad_tile(w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & ~8u)) != want)
+        __builtin_amdgcn_s_sleep(2);
+      init = (f >> 3) & 1u;
+    }
+    scratch[1 + threadIdx.x] = init;
+  }
+  lds_barrier();
+  const bool orphan = scratch[0] != 0;  // workgroup-uniform
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (quad_mode(qw[q]) != QUAD_DIRECT) continue;
+    if (orphan) qw[q] = quad_word(QUAD_SIDE, quad_rank(qw[q]), quad_tile(qw[q])) | QUAD_DEMOTED | (scratch[1 + q] ? QUAD_ACC : 0u);
+    else if (scratch[1 + q]) qw[q] |= QUAD_ACC;
+  }
+  store_patch_direct<C>(
+      t, v, ov, dv, plane, pr, pc, win, qw,
+      [](const float* a) {
+        const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return cf{__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32))};
+      },
+      [](const float* a) { return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); });
+  // ---- publish: every wave drains its stores, then one lane per quadrant moves the tile's flag on ----
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  lds_barrier();
+  if (threadIdx.x < 4) {
+    const uint32_t w = qw[threadIdx.x];
+    const bool demoted = (w & QUAD_DEMOTED) != 0;
+    if (demoted) {  // tell the fix-up kernel that this colour's plane holds a contribution to the tile
+      uint32_t* dyn = p.dyn_side + (size_t)frame * p.n_tiles + quad_tile(w);
+      uint32_t seen = __hip_atomic_load(dyn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), next;
+      do next = ((seen >> 8) == epoch ? seen : (epoch << 8)) | (1u << plane);
+      while (!__hip_atomic_compare_exchange_strong(dyn, &seen, next, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    if (demoted || quad_mode(w) == QUAD_DIRECT) {
+      const uint32_t init = demoted ? ((w & QUAD_ACC) ? 1u : 0u) : 1u;
+      __hip_atomic_store(flags + quad_tile(w), (epoch << 8) | (init << 3) | (quad_rank(w) + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 template <class C>
 __global__ __launch_bounds__(Launch<C>::WG, Launch<C>::WAVES_PER_SIMD) void patch_kernel(PatchParams p) {  // 2 waves per SIMD: 256 registers
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int T = C::T;
-  if ((int)blockIdx.x >= p.patch_blocks) {  // workgroup-uniform
-    sum_planes_worker(p.sum, blockIdx.x - p.patch_blocks, gridDim.x - p.patch_blocks);
-    return;
-  }
   const int team = threadIdx.x / T, t = threadIdx.x % T;
-  // Blocks are dealt round-robin over the 8 XCDs (b and b+8 share one).  `order` lists the patches
-  // along a Z-order curve of the lattice, cut into 8 contiguous chunks: XCD x works through chunk x,
-  // so the four patches that overlap a pixel usually read it through the same L2.  Speed only.
+  // Blocks are dealt round-robin over the 8 XCDs (b and b+8 share one).  The plan's processing order is cut
+  // into 8 contiguous chunks of compact lattice regions: XCD x works through chunk x, so the four patches that
+  // overlap a pixel usually read it through the same L2 (and, with the direct overlap-add, accumulate it there;
+  // that placement is checked at run time, see direct_store).
   // Batch: the n_frames workgroups of one patch slot are consecutive on their XCD, so the slot's packed
   // K comes from HBM once and from that XCD's L2 for the other frames.
   int frame = 0, xrow = blockIdx.x >> 3;
@@ -318,10 +357,88 @@ __global__ __launch_bounds__(Launch<C>::WG, Launch<C>::WAVES_PER_SIMD) void patc
 #elif defined(RPSF_ABL_NOATOMIC)
     store_patch<C>(t, v, ov, plane, pr, pc, win, [](float* a, float val) { *a = val; });
 #else
+    if constexpr (C::S3) {
+      if (p.dv.out) {
+        direct_store<C>(p, t, v, ov, frame, seq, plane, pr, pc, win, reinterpret_cast<uint32_t*>(lds));
+        STAMP(13);
+        return;
+      }
+    }
     store_patch<C>(t, v, ov, plane, pr, pc, win, [](float* a, float val) { unsafeAtomicAdd(a, val); });
 #endif
   }
   STAMP(13);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5': fix-up after a direct overlap-add launch.  FIX_SUB workgroups per lattice tile; most exit at once.
+//   out_tile = (tile initialised by its direct contributors ? out_tile : 0) + sum of the colour planes that hold a
+//   side contribution (static: contributors of another chunk; dynamic: demoted at run time), in colour order.
+// Tiles without any contributor are zeroed (the reference leaves uncovered output at 0, transform.py:167-169).
+// ------------------------------------------------------------------------------------------------
+struct FixParams {
+  const float* planes;
+  size_t plane_stride, planes_frame_floats;
+  int ld_planes;
+  float* out;
+  int ld_out;
+  size_t out_frame_floats;
+  int rows, W, row0;           // resident output window: rows [row0, row0 + rows) of the image, W columns
+  int lat_r0, lat_c0, half;    // full-image coordinates of lattice tile (0, 0); tile edge
+  int ntj;
+  const uint8_t* tile_info;    // bits 0-3 static side mask, bit 4 tile has contributors
+  const uint32_t* flags;
+  const uint32_t* dyn_side;
+  uint32_t epoch, n_tiles;
+};
+constexpr int FIX_SUB = 8;
+
+__global__ __launch_bounds__(256) void fixup_kernel(FixParams p) {
+  const uint32_t tile = blockIdx.x / FIX_SUB, sub = blockIdx.x % FIX_SUB, frame = blockIdx.y;
+  const uint32_t d = p.dyn_side[(size_t)frame * p.n_tiles + tile], f = p.flags[(size_t)frame * p.n_tiles + tile];
+  const uint32_t side = (p.tile_info[tile] & 15u) | ((d >> 8) == p.epoch ? (d & 15u) : 0u);
+  const bool init = (f >> 8) == p.epoch && (f & 8u);
+  if (side == 0 && init) return;
+  const int ti = tile / p.ntj, tj = tile % p.ntj;
+  const int span = (p.half + FIX_SUB - 1) / FIX_SUB;
+  const int ty0 = p.lat_r0 + ti * p.half + (int)sub * span;
+  const int y0 = max(ty0, p.row0), y1 = min(min(ty0 + span, p.lat_r0 + (ti + 1) * p.half), p.row0 + p.rows);
+  const int x0 = max(p.lat_c0 + tj * p.half, 0), x1 = min(p.lat_c0 + (tj + 1) * p.half, p.W);
+  if (y0 >= y1 || x0 >= x1) return;
+  const float* planes = p.planes + (size_t)frame * p.planes_frame_floats;
+  float* out = p.out + (size_t)frame * p.out_frame_floats;
+  const bool vec = ((x0 | x1 | p.ld_planes | p.ld_out) & 3) == 0 && (p.plane_stride & 3) == 0 &&
+                   ((reinterpret_cast<uintptr_t>(planes) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  if (vec) {
+    const int gw = (x1 - x0) >> 2, total = gw * (y1 - y0);
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+      const int yl = y0 + i / gw - p.row0, x = x0 + ((i % gw) << 2);
+      f4* o = reinterpret_cast<f4*>(out + (size_t)yl * p.ld_out + x);
+      const f4* pl = reinterpret_cast<const f4*>(planes + (size_t)yl * p.ld_planes + x);
+      f4 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)  // unconditional loads (redirected to plane 0's line when unused) so they overlap
+        v[k] = __builtin_nontemporal_load(((side >> k) & 1) ? pl + k * (p.plane_stride >> 2) : pl);
+      f4 acc = init ? *o : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if ((side >> k) & 1) acc += v[k];
+      *o = acc;
+    }
+  } else {
+    const int w = x1 - x0, total = w * (y1 - y0);
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+      const int yl = y0 + i / w - p.row0, x = x0 + i % w;
+      float* o = out + (size_t)yl * p.ld_out + x;
+      const float* pl = planes + (size_t)yl * p.ld_planes + x;
+      float acc = init ? *o : 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if ((side >> k) & 1) acc += pl[k * p.plane_stride];
+      *o = acc;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
