@@ -32,10 +32,11 @@
 #include <thread>
 #include <vector>
 
-#include "../../include/rpsf.h"
-#include "rpsf_core.hpp"
+#define RPSF_HOST_TU 1
+#include "rpsf_device.hpp"
 
-using namespace rpsf;
+RPSF_PLANS_V1(RPSF_DECL_V1)
+RPSF_PLANS_V2(RPSF_DECL_V2)
 
 // ------------------------------------------------------------------------------------------------
 // error plumbing
@@ -55,7 +56,6 @@ static int fail(int code, const std::string& msg) {
 
 extern "C" const char* rpsf_last_error(void) { return g_err.c_str(); }
 
-#include "rpsf_kernels.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // plan
@@ -84,6 +84,7 @@ struct rpsf_plan {
   int round_capacity = 0;  // patches the chip holds at once (CUs x resident workgroups x patches per workgroup)
   bool lattice = false;
   bool direct_ok = false;  // lattice and one patch per workgroup
+  bool v2 = false;         // second-generation kernel (rpsf_core2.hpp): N = 128, 256
   uint4* d_quads = nullptr;        // per processing-order slot: quadrant words (rpsf_core.hpp, store_patch_direct)
   uint8_t* d_tile_info = nullptr;  // per lattice tile: static side mask | 16 if any patch covers it
   uint32_t* d_flags = nullptr;     // per (frame, tile)
@@ -270,18 +271,24 @@ static int setup_lattice(rpsf_plan* p) {
 template <class F>
 static int dispatch_n(int N, F&& f) {
   switch (N) {
-#if defined(RPSF_ONLY_N)  // development builds: compile a single plan
-    case RPSF_ONLY_N: return f.template operator()<Cfg<RPSF_ONLY_CFG>>();
-#else
     case 256: return f.template operator()<Cfg256>();
     case 128: return f.template operator()<Cfg128>();
     case 64: return f.template operator()<Cfg64>();
     case 32: return f.template operator()<Cfg32>();
     case 16: return f.template operator()<Cfg16>();
-#endif
     default: return fail(RPSF_E_UNSUPPORTED, "patch size " + std::to_string(N) + " has no compiled plan (16..256, powers of two)");
   }
 }
+
+template <class F>
+static int dispatch_v2(int N, F&& f) {
+  switch (N) {
+    case 256: return f.template operator()<Cfg256v2>();
+    case 128: return f.template operator()<Cfg128v2>();
+    default: return fail(RPSF_E_UNSUPPORTED, "no second-generation plan for this patch size");
+  }
+}
+static bool has_v2(int N) { return (N == 256 || N == 128) && !std::getenv("RPSF_V1"); }
 
 static void host_tables(int N, std::vector<cf>& tw, std::vector<float>& win) {
   tw.resize(N);
@@ -316,6 +323,28 @@ static int upload_tables(int device, uint16_t** d_tab, cf** d_tw, float** d_win,
     HIP_TRY(hipMalloc(d_win, win.size() * sizeof(float)));
     HIP_TRY(hipMemcpy(*d_win, win.data(), win.size() * sizeof(float), hipMemcpyHostToDevice));
   }
+  return RPSF_OK;
+}
+
+template <class C>
+static int upload_tables2(int device, uint16_t** d_tab, cf** d_tw, float** d_win, uint32_t** d_ot) {
+  std::vector<uint16_t> tab((size_t)C::T * C::NSLOT * 2);
+  build_slot_table2<C>(tab.data());
+  std::vector<uint32_t> ot((size_t)C::ORBIT_ROUNDS * 64);
+  if (special_slots2<C>() > 64 || build_orbit_table2<C>(tab.data(), ot.data()) != C::NORBIT)
+    return fail(RPSF_E_STATE, "slot / orbit table inconsistent (internal)");
+  std::vector<cf> tw;
+  std::vector<float> win;
+  host_tables(C::N, tw, win);
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipMalloc(d_ot, ot.size() * sizeof(uint32_t)));
+  HIP_TRY(hipMemcpy(*d_ot, ot.data(), ot.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(d_tab, tab.size() * sizeof(uint16_t)));
+  HIP_TRY(hipMemcpy(*d_tab, tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(d_tw, tw.size() * sizeof(cf)));
+  HIP_TRY(hipMemcpy(*d_tw, tw.data(), tw.size() * sizeof(cf), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(d_win, win.size() * sizeof(float)));
+  HIP_TRY(hipMemcpy(*d_win, win.data(), win.size() * sizeof(float), hipMemcpyHostToDevice));
   return RPSF_OK;
 }
 
@@ -436,7 +465,15 @@ extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int
     HIP_TRY(hipMalloc(&p->d_stamps, sizeof(unsigned long long) * 16 * (size_t)n_patches));
     HIP_TRY(hipMemset(p->d_stamps, 0, sizeof(unsigned long long) * 16 * (size_t)n_patches));
 #endif
-    int rl = dispatch_n(N, [&]<class C>() -> int {
+    p->v2 = has_v2(N);
+    int rl = p->v2 ? dispatch_v2(N, [&]<class C>() -> int {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_kernel2<C>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)Launch2<C>::LDS_BYTES));
+      int per_cu = 0;
+      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, patch_kernel2<C>, Launch2<C>::WG, Launch2<C>::LDS_BYTES));
+      p->round_capacity = p->cu_count * std::max(1, per_cu);
+      return RPSF_OK;
+    }) : dispatch_n(N, [&]<class C>() -> int {
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_kernel<C>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)Launch<C>::LDS_BYTES));
       int per_cu = 0;
@@ -449,6 +486,16 @@ extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int
     HIP_TRY(hipEventCreateWithFlags(&p->ev_busy, hipEventDisableTiming));
     rl = setup_lattice(p);
     if (rl != RPSF_OK) return rl;
+    if (p->v2)
+      return dispatch_v2(N, [&]<class C>() -> int {
+        int r2 = upload_tables2<C>(device, &p->d_tab, &p->d_tw, &p->d_win, &p->d_pairtab);
+        if (r2 != RPSF_OK) return r2;
+        p->g_elems = (size_t)C::G_PER_PATCH * n_patches;
+        p->gs_elems = (size_t)C::GS_PER_PATCH * n_patches;
+        HIP_TRY(hipMalloc(&p->d_g, p->g_elems * sizeof(cf)));
+        HIP_TRY(hipMalloc(&p->d_gs, (p->gs_elems + 1) * sizeof(cf)));
+        return RPSF_OK;
+      });
     return dispatch_n(N, [&]<class C>() -> int {
       int r2 = upload_tables<C>(device, &p->d_tab, &p->d_tw, &p->d_win, &p->d_pairtab);
       if (r2 != RPSF_OK) return r2;
@@ -513,6 +560,15 @@ extern "C" void rpsf_plan_destroy(rpsf_plan* p) {
 }
 
 static int pack_range(rpsf_plan* p, const cf* d_kfull, int first_patch, int count) {
+  if (p->v2)
+    return dispatch_v2(p->N, [&]<class C>() -> int {
+      const size_t total = ((size_t)C::G_PER_PATCH + C::GS_PER_PATCH) * count;
+      pack_kernel2<C><<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, p->stream>>>(
+          d_kfull, count, p->d_tab, p->d_pairtab, p->d_g + (size_t)first_patch * C::G_PER_PATCH,
+          p->d_gs + (size_t)first_patch * C::GS_PER_PATCH);
+      HIP_TRY(hipGetLastError());
+      return RPSF_OK;
+    });
   return dispatch_n(p->N, [&]<class C>() -> int {
     size_t total = (size_t)C::G_PER_PATCH * count;
     int block = 256;
@@ -622,9 +678,8 @@ enum OverlapKind { OV_ATOMIC = 0, OV_PLANES = 1, OV_DIRECT = 2 };
 
 static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const rpsf_geometry& g, OverlapKind kind,
                           hipStream_t st, Batch b = Batch()) {
-  return dispatch_n(p->N, [&]<class C>() -> int {
+  auto fill = [&](PatchParams& pp, int teams) {
     const int count = p->n_patches;
-    PatchParams pp{};
     pp.im = ImageView{d_img, g.height, g.width, g.ld_image, g.pad_mode, g.pad_value, g.image_row0, g.image_rows};
     if (kind != OV_ATOMIC)
       pp.ov = OutView{p->d_planes, g.height, g.width, g.width, g.out_row0, g.out_rows, p->planes_floats, p->d_sink};
@@ -634,10 +689,8 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
     pp.desc = p->d_desc, pp.n_patches = count, pp.seq_base = 0;
     pp.tab = p->d_tab, pp.pairtab = p->d_pairtab, pp.tw = p->d_tw, pp.win = p->d_win, pp.g = p->d_g, pp.gs = p->d_gs;
     pp.stamps = p->d_stamps;
-    constexpr int TEAMS = Launch<C>::TEAMS;
-    pp.chunk = ((count + 7) / 8 + TEAMS - 1) / TEAMS * TEAMS;  // patches per XCD, whole workgroups
+    pp.chunk = ((count + 7) / 8 + teams - 1) / teams * teams;  // patches per XCD, whole workgroups
     pp.stagger_ticks = p->stagger_us * 100;
-    pp.stagger_blocks = p->cu_count * std::max(1, 512 / Launch<C>::WG);
     pp.n_frames = b.frames, pp.im_frame_floats = b.im_stride;
     pp.ov_frame_floats = kind != OV_ATOMIC ? 4 * p->planes_floats : b.out_stride;
     pp.dv = OutView{nullptr, 0, 0, 0, 0, 0, 0, nullptr};
@@ -647,6 +700,23 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
       pp.quads = p->d_quads, pp.flags = p->d_flags, pp.dyn_side = p->d_dyn, pp.chunk_xcc = p->d_chunk_xcc;
       pp.flag_epoch = p->epoch, pp.n_tiles = (uint32_t)(p->nti * p->ntj), pp.orphan_mod = p->orphan_mod;
     }
+  };
+  if (p->v2)
+    return dispatch_v2(p->N, [&]<class C>() -> int {
+      PatchParams pp{};
+      fill(pp, 1);
+      pp.stagger_blocks = p->round_capacity;
+      const size_t blocks = (size_t)8 * pp.chunk * b.frames;
+      if (blocks > 0x7fffffffu) return fail(RPSF_E_BADARG, "batch too large for one launch");
+      patch_kernel2<C><<<dim3((unsigned)blocks), dim3(Launch2<C>::WG), Launch2<C>::LDS_BYTES, st>>>(pp);
+      HIP_TRY(hipGetLastError());
+      return RPSF_OK;
+    });
+  return dispatch_n(p->N, [&]<class C>() -> int {
+    PatchParams pp{};
+    constexpr int TEAMS = Launch<C>::TEAMS;
+    fill(pp, TEAMS);
+    pp.stagger_blocks = p->cu_count * std::max(1, 512 / Launch<C>::WG);
     const size_t blocks = (size_t)8 * (pp.chunk / TEAMS) * b.frames;
     if (blocks > 0x7fffffffu) return fail(RPSF_E_BADARG, "batch too large for one launch");
     patch_kernel<C><<<dim3((unsigned)blocks), dim3(Launch<C>::WG), Launch<C>::LDS_BYTES, st>>>(pp);

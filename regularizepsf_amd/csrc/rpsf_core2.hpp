@@ -1,0 +1,591 @@
+// rpsf_core2.hpp - second-generation per-thread phases of the fused patch kernel for the three-stage plans
+// (N = 128 and N = 256).  Same algorithm as rpsf_core.hpp (packed real 2-D DFT, Hermitian-folded K, overlap-add;
+// regularizepsf/transform.py:151-169), re-laid out around the two widths the memory system likes:
+//   * a thread's unit of global traffic is 16 bytes = four consecutive pixels of one row = the packed columns 2c', 2c'+1.
+//     The low packed-column bit c3 ("half" h) therefore lives in a register digit that is never exchanged: a thread
+//     owns 32 units = 2 halves x 32 complex values, and every stage works on one half (32 values, 5 index bits)
+//     at a time, so the LDS traffic of one half overlaps the butterflies of the other;
+//   * the unit of LDS traffic is one complex value (8 bytes): ds_write_b64 / ds_read_b64 / ds_read_b128, half the
+//     instructions of the re/im passes of the first generation.
+// Digits (most significant first): rows (A1 | A2 | AL), packed columns (B1 | B2 | 1); A1 + B1 = 5, A2 + B2 = 5.
+//   stage 1 owns (r1, c1), stage 2 (r2, c2), the last stage (r3, c3): E = 2^(AL+1) bins per group.
+//   r = r1 2^(A2+AL) + r2 2^AL + r3  ->  kr = k1 + k2 2^A1 + k3 2^(A1+A2) = q + Q k3
+//   c = c1 2^(B2+1) + 2 c2 + c3      ->  kc = l1 + l2 2^B1 + l3 2^(B1+B2) = m + M l3
+// Thread t = 64 wave + 32 hb + l5:  r3 = 2 wave + hb in the stage-1 / stage-2 layouts; l5 = (r2, c2) in the
+// stage-1 layout and (k1, l1) in the stage-2 layout (X1 swaps the five exchanged register bits with l5 inside each
+// half-wave).  Register v[2 j + h] in stages 1-2, v[group E + 2 r3 + c3] in the last stage, so the exchange of half h
+// replaces exactly the registers of parity h.
+// Groups whose partner rule differs (q = 0 or m = 0) are brought to the general rule "bin e <-> bin E-1-e of the
+// partner group" by modulating the partner group before / after its last-stage DFT (a shift by one bin in k3, or a
+// swap in l3); only the four self-paired groups need their own path (two threads park them in LDS and wave 0 walks
+// their bin pairs, one pair per lane).
+#pragma once
+#include <vector>
+
+#include "rpsf_core.hpp"
+
+namespace rpsf {
+
+struct alignas(16) cf2 {
+  cf a, b;
+};
+
+template <int LOGN_, int A1_, int A2_, int AL_, int B1_, int B2_>
+struct Cfg2 {
+  static constexpr int LOGN = LOGN_, N = 1 << LOGN_, NC = N / 2;
+  static constexpr int A1 = A1_, A2 = A2_, AL = AL_, B1 = B1_, B2 = B2_, BL = 1;
+  static_assert(A1_ + B1_ == 5 && A2_ + B2_ == 5, "32 values per thread, half and stage");
+  static_assert(A1_ + A2_ + AL_ == LOGN_ && B1_ + B2_ + 1 == LOGN_ - 1, "digits must cover the index");
+  static_assert(A1_ >= 1 && B1_ >= 1, "the top row / column bits must be stage-1 register digits (quadrants)");
+  static constexpr bool S3 = true;
+  static constexpr int EA = 1 << AL_, EB = 2, E = EA * EB, P = 64 / E, NSLOT = P / 2;
+  static constexpr int T = N * NC / 64, WAVES = T / 64;
+  static_assert(WAVES * 2 == EA, "r3 = 2 wave + hb");
+  static constexpr int LQ = A1_ + A2_, Q = 1 << LQ, M = 1 << (B1_ + B2_), G = Q * M;
+  static_assert(G == 1024, "32 x 32 groups");
+  static constexpr bool SPLIT_ROWS = NSLOT == 1;  // see stage3_rows
+  static constexpr int KCH = 8, NWORDS = NSLOT * E, NCHUNK = NWORDS / KCH;
+  static_assert(NWORDS == 32, "32 pair words per thread");
+  static constexpr int G_PER_PATCH = NWORDS * T * 2;  // complex values
+  // self-paired groups (0,0), (Q/2,0), (0,M/2), (Q/2,M/2): slots 0 of threads 0 and 1; their bin pairs
+  static constexpr int NORBIT = 2 * E + 2;            // E/2 + 2 pairs in group (0,0) (four fixed points), E/2 in the others
+  static constexpr int ORBIT_ROUNDS = (NORBIT + 63) / 64;
+  static constexpr int GS_PER_PATCH = ORBIT_ROUNDS * 64 * 2;  // complex values: one pair word per (round, lane)
+  // LDS, in 8-byte units
+  static constexpr int X1_ROWU = 34;  // 32 + 2: rows stay 16-byte aligned and a 16-lane group of b128 reads covers all banks
+  static constexpr int X1_WAVE_UNITS = 2 * 32 * X1_ROWU;
+  static constexpr int X1_UNITS = WAVES * X1_WAVE_UNITS;
+  static constexpr int X2_UNITS = EA * G;
+  static constexpr int BUF_UNITS = X1_UNITS > X2_UNITS ? X1_UNITS : X2_UNITS;
+  static constexpr int PARK_UNITS = 2 * 2 * E;  // two threads x two groups
+  static constexpr int LDS_UNITS = BUF_UNITS + PARK_UNITS;
+  static constexpr float SCALE = 1.0f / (2.0f * (float)N * (float)N);  // 1/4 (pair algebra) * 1/(N*N/2) (inverse DFT)
+};
+
+// ------------------------------------------------------------------------------------------
+// group ids: gid = (j'' << 5) + l5',  j'' = (k2, l2) register digit of the stage-2 layout, l5' = (k1, l1)
+// ------------------------------------------------------------------------------------------
+template <class C>
+RPSF_HD void gid_to_qm2(int gid, int& q, int& m) {
+  const int l5 = gid & 31, j = gid >> 5;
+  const int k1 = l5 >> C::B1, l1 = l5 & ((1 << C::B1) - 1);
+  const int k2 = j >> C::B2, l2 = j & ((1 << C::B2) - 1);
+  q = k1 + (k2 << C::A1);
+  m = l1 + (l2 << C::B1);
+}
+template <class C>
+RPSF_HD int qm_to_gid2(int q, int m) {
+  const int k1 = q & ((1 << C::A1) - 1), k2 = q >> C::A1;
+  const int l1 = m & ((1 << C::B1) - 1), l2 = m >> C::B1;
+  return (((k2 << C::B2) + l2) << 5) + (k1 << C::B1) + l1;
+}
+template <class C>
+RPSF_HD int partner_gid2(int gid) {
+  int q, m;
+  gid_to_qm2<C>(gid, q, m);
+  return qm_to_gid2<C>((C::Q - q) & (C::Q - 1), (C::M - m) & (C::M - 1));
+}
+enum SlotKind : int { SLOT_GENERAL = 0, SLOT_Q0 = 1, SLOT_M0 = 2, SLOT_SELF = 3 };
+template <class C>
+RPSF_HD int slot_kind2(int gid_a) {
+  int q, m;
+  gid_to_qm2<C>(gid_a, q, m);
+  if (partner_gid2<C>(gid_a) == gid_a) return SLOT_SELF;
+  if (q == 0) return SLOT_Q0;
+  if (m == 0) return SLOT_M0;
+  return SLOT_GENERAL;
+}
+
+// Slot table: tab[(t*NSLOT + s)*2 + member] = gid.  Slot sigma = s*T + t.  The two self-paired slots come first
+// (threads 0 and 1 of slot 0: (0,0)+(Q/2,0) and (0,M/2)+(Q/2,M/2)), then the q = 0 / m = 0 pairs (all inside wave 0's
+// slot 0), then the rest in ascending gid.  Host only.
+template <class C>
+inline void build_slot_table2(uint16_t* tab) {
+  const int G = C::G;
+  std::vector<char> seen(G, 0);
+  std::vector<int> slots;
+  auto push = [&](int a, int b) {
+    slots.push_back(a), slots.push_back(b);
+    seen[a] = seen[b] = 1;
+  };
+  push(qm_to_gid2<C>(0, 0), qm_to_gid2<C>(C::Q / 2, 0));
+  push(qm_to_gid2<C>(0, C::M / 2), qm_to_gid2<C>(C::Q / 2, C::M / 2));
+  for (int pass = 0; pass < 2; ++pass)
+    for (int g = 0; g < G; ++g) {
+      if (seen[g]) continue;
+      int q, m;
+      gid_to_qm2<C>(g, q, m);
+      if (pass == 0 && q != 0 && m != 0) continue;
+      push(g, partner_gid2<C>(g));
+    }
+  const int ns = (int)slots.size() / 2;
+  for (int sigma = 0; sigma < ns; ++sigma) {
+    const int s = sigma / C::T, t = sigma % C::T;
+    tab[(t * C::NSLOT + s) * 2 + 0] = (uint16_t)slots[2 * sigma];
+    tab[(t * C::NSLOT + s) * 2 + 1] = (uint16_t)slots[2 * sigma + 1];
+  }
+}
+template <class C>
+inline int special_slots2() { return 2 + (C::Q / 2 - 1) + (C::M / 2 - 1); }  // all must sit in slot 0 of wave 0
+
+// Bin pairs of the four self-paired groups.  Entry: bits 0-7 x1, 8-15 x2 (positions among the 4E parked values:
+// thread*2E + member*E + e), 16-23 twiddle index kc of the first bin, bit 31 valid.  Host only; NORBIT entries used.
+template <class C>
+inline int build_orbit_table2(const uint16_t* tab, uint32_t* ot) {
+  int n = 0;
+  for (int i = 0; i < C::ORBIT_ROUNDS * 64; ++i) ot[i] = 0;
+  for (int t = 0; t < 2; ++t)
+    for (int member = 0; member < 2; ++member) {
+      int q, m;
+      gid_to_qm2<C>(tab[(t * C::NSLOT + 0) * 2 + member], q, m);
+      for (int e = 0; e < C::E; ++e) {
+        const int k3 = e >> 1, l3 = e & 1;
+        const int pk = q == 0 ? (C::EA - k3) % C::EA : C::EA - 1 - k3;
+        const int pl = m == 0 ? l3 : 1 - l3;
+        const int pe = pk * 2 + pl;
+        if (e > pe) continue;
+        if (n < C::ORBIT_ROUNDS * 64)
+          ot[n] = pair_entry(t * 2 * C::E + member * C::E + e, t * 2 * C::E + member * C::E + pe, m + C::M * l3);
+        ++n;
+      }
+    }
+  return n;
+}
+
+// ------------------------------------------------------------------------------------------
+// Thread coordinates
+// ------------------------------------------------------------------------------------------
+template <class C>
+struct ThreadPos2 {
+  int wave, hb, l5, r3;
+  int r_low, c2;  // stage-1 layout: r = (r1 << (A2+AL)) + r_low; unit column c' = (c1 << B2) + c2 (pixels 4c' .. 4c'+3)
+  RPSF_HD explicit ThreadPos2(int t) {
+    wave = t >> 6, hb = (t >> 5) & 1, l5 = t & 31;
+    r3 = 2 * wave + hb;
+    const int r2 = l5 >> C::B2;
+    c2 = l5 & ((1 << C::B2) - 1);
+    r_low = (r2 << C::AL) + r3;
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// Stages.  v[2 j + H] in stages 1 and 2; tw[k] = exp(-2 pi i k / N)
+// ------------------------------------------------------------------------------------------
+template <class C, int H, bool INV>
+RPSF_HD void stage1h(int t, cf* v, const cf* __restrict__ tw) {
+  constexpr int NR = 1 << C::A1, NCOL = 1 << C::B1;
+  ThreadPos2<C> tp(t);
+  const int c_low = 2 * tp.c2 + H;
+  auto row_tw = [&]() RPSF_AI {
+    StaticFor<1, NR>::run([&]<int K1>() RPSF_AI {
+      const cf w = tw[(K1 * tp.r_low) & (C::N - 1)];
+      StaticFor<0, NCOL>::run([&]<int C1>() RPSF_AI {
+        cf& x = v[2 * (K1 * NCOL + C1) + H];
+        x = INV ? cmulc(x, w) : cmul(x, w);
+      });
+    });
+  };
+  auto col_tw = [&]() RPSF_AI {
+    StaticFor<1, NCOL>::run([&]<int L1>() RPSF_AI {
+      const cf w = tw[(2 * L1 * c_low) & (C::N - 1)];
+      StaticFor<0, NR>::run([&]<int K1>() RPSF_AI {
+        cf& x = v[2 * (K1 * NCOL + L1) + H];
+        x = INV ? cmulc(x, w) : cmul(x, w);
+      });
+    });
+  };
+  if constexpr (!INV) {
+    fft_axis<C::A1, 2 * NCOL, NCOL, 2, false, H>(v);
+    row_tw();
+    fft_axis<C::B1, 2, NR, 2 * NCOL, false, H>(v);
+    col_tw();
+  } else {
+    col_tw();
+    fft_axis<C::B1, 2, NR, 2 * NCOL, true, H>(v);
+    row_tw();
+    fft_axis<C::A1, 2 * NCOL, NCOL, 2, true, H>(v);
+  }
+}
+
+template <class C, int H, bool INV>
+RPSF_HD void stage2h(int t, cf* v, const cf* __restrict__ tw) {
+  constexpr int NR = 1 << C::A2, NCOL = 1 << C::B2;
+  ThreadPos2<C> tp(t);
+  auto row_tw = [&]() RPSF_AI {  // W_{2^(A2+AL)}^(k2 r3)
+    StaticFor<1, NR>::run([&]<int K2>() RPSF_AI {
+      const cf w = tw[((K2 * tp.r3) << C::A1) & (C::N - 1)];
+      StaticFor<0, NCOL>::run([&]<int C2>() RPSF_AI {
+        cf& x = v[2 * (K2 * NCOL + C2) + H];
+        x = INV ? cmulc(x, w) : cmul(x, w);
+      });
+    });
+  };
+  auto col_tw = [&]() RPSF_AI {  // W_{2^(B2+1)}^(l2 c3): compile-time, only for c3 = 1
+    if constexpr (H == 1) {
+      StaticFor<1, NCOL>::run([&]<int L2>() RPSF_AI {
+        constexpr int k64 = L2 * (64 >> (C::B2 + 1));  // on the 64-point circle
+        constexpr float c = cos64(k64), s = -sin64(k64);
+        StaticFor<0, NR>::run([&]<int K2>() RPSF_AI {
+          cf& x = v[2 * (K2 * NCOL + L2) + H];
+          x = INV ? cmulc(x, cf{c, s}) : cmul(x, cf{c, s});
+        });
+      });
+    }
+  };
+  if constexpr (!INV) {
+    fft_axis<C::A2, 2 * NCOL, NCOL, 2, false, H>(v);
+    row_tw();
+    fft_axis<C::B2, 2, NR, 2 * NCOL, false, H>(v);
+    col_tw();
+  } else {
+    col_tw();
+    fft_axis<C::B2, 2, NR, 2 * NCOL, true, H>(v);
+    row_tw();
+    fft_axis<C::A2, 2 * NCOL, NCOL, 2, true, H>(v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// LDS exchanges of half H (lds in 8-byte units)
+// ------------------------------------------------------------------------------------------
+template <class C, int H>
+RPSF_HD void x1_write2(int t, const cf* v, cf* lds) {
+  ThreadPos2<C> tp(t);
+  cf* base = lds + tp.wave * C::X1_WAVE_UNITS + tp.hb * (32 * C::X1_ROWU) + tp.l5;
+  StaticFor<0, 32>::run([&]<int J>() RPSF_AI { base[J * C::X1_ROWU] = v[2 * J + H]; });
+}
+template <class C, int H>
+RPSF_HD void x1_read2(int t, cf* v, const cf* lds) {
+  ThreadPos2<C> tp(t);
+  const cf2* row = reinterpret_cast<const cf2*>(lds + tp.wave * C::X1_WAVE_UNITS + tp.hb * (32 * C::X1_ROWU) + tp.l5 * C::X1_ROWU);
+  StaticFor<0, 16>::run([&]<int K>() RPSF_AI {
+    const cf2 u = row[K];
+    v[2 * (2 * K) + H] = u.a;
+    v[2 * (2 * K + 1) + H] = u.b;
+  });
+}
+template <class C, int H>
+RPSF_HD void x2_mid_write2(int t, const cf* v, cf* lds) {
+  ThreadPos2<C> tp(t);
+  cf* base = lds + tp.r3 * C::G + tp.l5;
+  StaticFor<0, 32>::run([&]<int J>() RPSF_AI { base[J * 32] = v[2 * J + H]; });
+}
+template <class C, int H>
+RPSF_HD void x2_mid_read2(int t, cf* v, const cf* lds) {
+  ThreadPos2<C> tp(t);
+  const cf* base = lds + tp.r3 * C::G + tp.l5;
+  StaticFor<0, 32>::run([&]<int J>() RPSF_AI { v[2 * J + H] = base[J * 32]; });
+}
+template <class C, int H>
+RPSF_HD void x2_last_read2(const GroupIds<C>& gids, cf* v, const cf* lds) {
+  StaticFor<0, C::P>::run([&]<int GI>() RPSF_AI {
+    const cf* base = lds + gids[GI];
+    StaticFor<0, C::EA>::run([&]<int R3>() RPSF_AI { v[GI * C::E + 2 * R3 + H] = base[R3 * C::G]; });
+  });
+}
+template <class C, int H>
+RPSF_HD void x2_last_write2(const GroupIds<C>& gids, const cf* v, cf* lds) {
+  StaticFor<0, C::P>::run([&]<int GI>() RPSF_AI {
+    cf* base = lds + gids[GI];
+    StaticFor<0, C::EA>::run([&]<int R3>() RPSF_AI { base[R3 * C::G] = v[GI * C::E + 2 * R3 + H]; });
+  });
+}
+
+// ------------------------------------------------------------------------------------------
+// Frequency step
+// ------------------------------------------------------------------------------------------
+// Modulation of the partner group (member B) of a q = 0 / m = 0 slot, in the (r3, c3) domain: b[r3] *= W_EA^(+-r3)
+// shifts its k3 bins by one, negating the c3 = 1 values swaps its l3 bins.  kind is per lane; the select is on values.
+// Done per column parity C3, next to the row DFTs of that parity.
+template <class C, int S, bool POST, int C3>
+RPSF_HD void modulate_partner(int kind, cf* v) {
+  cf* zb = v + (2 * S + 1) * C::E;
+  const bool q0 = kind == SLOT_Q0, m0 = kind == SLOT_M0;
+  StaticFor<0, C::EA>::run([&]<int R3>() RPSF_AI {
+    cf& x = zb[2 * R3 + C3];
+    if constexpr (R3 > 0) {
+      constexpr int k64 = R3 * (64 / C::EA);
+      constexpr float c = cos64(k64), s = POST ? sin64(k64) : -sin64(k64);  // W_EA^r3 before, its conjugate after
+      x = sel(q0, cmul(x, cf{c, s}), x);
+    }
+    if constexpr (C3 == 1) x = sel(m0, -x, x);
+  });
+}
+
+// Last stage in two steps: the DFTs along r3 of the values of one column parity of a slot, and the 2-point DFT along
+// c3.  With one slot per thread (N = 256) the row DFTs of a parity need only that half of the exchange, so they run
+// while the other half is still moving through LDS (Cfg2::SPLIT_ROWS); with several slots they stay next to the slot's
+// pair words.
+template <class C, bool INV, int C3, int S>
+RPSF_HD void stage3_rows(int t, const GroupIds<C>& gids, cf* v) {
+  if constexpr (!INV && S == 0) {
+    if (t < 64) modulate_partner<C, 0, false, C3>(slot_kind2<C>(gids[0]), v);  // wave-uniform branch
+  }
+  fft_axis<C::AL, 2, 1, 1, INV, (2 * S) * C::E + C3>(v);
+  fft_axis<C::AL, 2, 1, 1, INV, (2 * S + 1) * C::E + C3>(v);
+  if constexpr (INV && S == 0) {
+    if (t < 64) modulate_partner<C, 0, true, C3>(slot_kind2<C>(gids[0]), v);
+  }
+}
+template <class C, bool INV, int S>
+RPSF_HD void stage3_cols(cf* v) {
+  fft_axis<1, 1, C::EA, 2, INV, (2 * S) * C::E>(v);
+  fft_axis<1, 1, C::EA, 2, INV, (2 * S + 1) * C::E>(v);
+}
+
+// K words: word w of thread t at cf index (w*T + t)*2 - (K'_h(p), K'_h(p + (0,N/2))) for p = bin e of member A of slot
+// w / E, e = w % E (every slot, the modulated ones included).
+template <class C, int CI>
+RPSF_HD void load_k_chunk2(int t, cf* k, const cf* __restrict__ g) {
+  StaticFor<0, C::KCH>::run([&]<int I>() RPSF_AI {
+    load_stream16(g + ((size_t)(CI * C::KCH + I) * C::T + t) * 2, k[2 * I], k[2 * I + 1]);
+  });
+}
+
+// Self-paired groups: threads 0 and 1 park their slot 0 (after its forward DFT) ...
+template <class C>
+RPSF_HD void self_park(int t, const cf* v, cf* park) {
+  if (t < 2) StaticFor<0, 2 * C::E>::run([&]<int I>() RPSF_AI { park[t * 2 * C::E + I] = v[I]; });
+}
+// ... lane `lane` of wave 0 handles pair `round*64 + lane` ...
+template <class C>
+RPSF_HD void self_orbit(int lane, int round, const uint32_t* __restrict__ ot, cf ka, cf kb, const cf* __restrict__ tw, cf* park) {
+  const uint32_t ent = ot[round * 64 + lane];
+  const int x1 = ent & 0xff, x2 = (ent >> 8) & 0xff, kc = (ent >> 16) & 0xff;
+  const cf z1 = park[x1], z2 = park[x2];
+  const PairOut o = pair_op(z1, z2, ka, kb, tw[kc]);
+  if (ent >> 31) {
+    park[x1] = o.a;
+    if (x2 != x1) park[x2] = o.b;
+  }
+}
+// ... and the two threads take the results back before the inverse DFT.
+template <class C>
+RPSF_HD void self_unpark(int t, cf* v, const cf* park) {
+  if (t < 2) StaticFor<0, 2 * C::E>::run([&]<int I>() RPSF_AI { v[I] = park[t * 2 * C::E + I]; });
+}
+
+// pair words of slot S held in k[0 .. 2*COUNT): bins E0 .. E0+COUNT-1
+template <class C, int S, int E0, int COUNT>
+RPSF_HD void pair_words(const GroupIds<C>& gids, cf* v, const cf* k, const cf* __restrict__ tw) {
+  cf* za = v + (2 * S) * C::E;
+  cf* zb = za + C::E;
+  int qa, ma;
+  gid_to_qm2<C>(gids[2 * S], qa, ma);
+  const cf w0 = tw[ma], w1 = tw[ma + C::M];
+  StaticFor<0, COUNT>::run([&]<int I>() RPSF_AI {
+    constexpr int EE = E0 + I;
+    const PairOut o = pair_op(za[EE], zb[C::E - 1 - EE], k[2 * I], k[2 * I + 1], (EE & 1) ? w1 : w0);
+    za[EE] = o.a;
+    zb[C::E - 1 - EE] = o.b;
+  });
+}
+
+// The frequency step of one thread in three calls (the kernel puts wave-level LDS ordering between them; with
+// SPLIT_ROWS it also runs the row DFTs of slot 0 itself, around the exchanges):
+//   freq_a: (row DFTs and) column DFT of slot 0, self-paired slots parked;
+//   self_orbit (wave 0 only, one call per round);
+//   freq_b: pair words chunk by chunk (k holds chunk 0 on entry; each later chunk is requested as soon as the
+//           buffer is free), the other slots' DFTs around their words, results of the self-paired slots taken back.
+template <class C>
+RPSF_HD void freq_a(int t, const GroupIds<C>& gids, cf* v, cf* park) {
+  if constexpr (!C::SPLIT_ROWS) {
+    stage3_rows<C, false, 0, 0>(t, gids, v);
+    stage3_rows<C, false, 1, 0>(t, gids, v);
+  }
+  stage3_cols<C, false, 0>(v);
+  if (t < 64) self_park<C>(t, v, park);
+}
+template <class C>
+RPSF_HD void freq_b(int t, const GroupIds<C>& gids, cf* v, cf* k, const cf* __restrict__ g, const cf* __restrict__ tw,
+                    const cf* park) {
+  StaticFor<0, C::NCHUNK>::run([&]<int CI>() RPSF_AI {
+    constexpr int S = CI * C::KCH / C::E, E0 = CI * C::KCH % C::E;
+    if constexpr (E0 == 0 && S > 0) {
+      stage3_rows<C, false, 0, S>(t, gids, v);
+      stage3_rows<C, false, 1, S>(t, gids, v);
+      stage3_cols<C, false, S>(v);
+    }
+    pair_words<C, S, E0, C::KCH>(gids, v, k, tw);
+    if constexpr (CI + 1 < C::NCHUNK) load_k_chunk2<C, CI + 1>(t, k, g);
+    if constexpr (E0 + C::KCH == C::E) {
+      if constexpr (S == 0) {
+        if (t < 64) self_unpark<C>(t, v, park);
+      }
+      stage3_cols<C, true, S>(v);
+      if constexpr (!(C::SPLIT_ROWS && S == 0)) {
+        stage3_rows<C, true, 0, S>(t, gids, v);
+        stage3_rows<C, true, 1, S>(t, gids, v);
+      }
+    }
+  });
+}
+
+// Value of the packed K stream at (thread t, word w, side b)
+template <class C>
+RPSF_HD cf pack_value2(const cf* __restrict__ kfull, const uint16_t* __restrict__ tab, int t, int w, int b) {
+  const int s = w / C::E, e = w % C::E;
+  int q, m;
+  gid_to_qm2<C>(tab[(t * C::NSLOT + s) * 2], q, m);
+  const int kr = q + C::Q * (e >> 1), kc = m + C::M * (e & 1);
+  return kh_at<C>(kfull, kr, b ? kc + C::NC : kc);
+}
+// ... and of the side array of the self-paired bin pairs (entry i of the orbit table)
+template <class C>
+RPSF_HD cf pack_orbit2(const cf* __restrict__ kfull, const uint16_t* __restrict__ tab, const uint32_t* __restrict__ ot, int i, int b) {
+  const uint32_t ent = ot[i];
+  if (!(ent >> 31)) return cf{0.f, 0.f};
+  const int x1 = ent & 0xff, t = x1 / (2 * C::E), member = (x1 / C::E) & 1, e = x1 % C::E;
+  int q, m;
+  gid_to_qm2<C>(tab[(t * C::NSLOT + 0) * 2 + member], q, m);
+  const int kr = q + C::Q * (e >> 1), kc = m + C::M * (e & 1);
+  return kh_at<C>(kfull, kr, b ? kc + C::NC : kc);
+}
+
+// ------------------------------------------------------------------------------------------
+// Image side.  Unit (R1, C1) of a thread: row r = (R1 << (A2+AL)) + r_low, pixels 4c' .. 4c'+3, c' = (C1 << B2) + c2.
+// ------------------------------------------------------------------------------------------
+RPSF_HD bool quads_aligned(const void* base, int ld, int pc) { return ((ld | pc) & 3) == 0 && (reinterpret_cast<uintptr_t>(base) & 15) == 0; }
+
+// Gather in two steps so that a persistent workgroup can request the next patch's pixels while the stores of the
+// current one drain: load_raw2 issues the loads (np.pad index maps from LDS for patches that hang over the edge),
+// window_patch2 applies the sine window (transform.py:151-155,163) once the values are needed.
+template <class C>
+RPSF_HD void load_raw2(int t, cf* v, const ImageView& im, int pr, int pc, bool fast, const int* maps) {
+  ThreadPos2<C> tp(t);
+  constexpr int NR = 1 << C::A1, NCOL = 1 << C::B1;
+  if (fast) {
+    const float* base = im.img + (size_t)(pr - im.row0) * im.ld + pc;
+    StaticFor<0, NR>::run([&]<int R1>() RPSF_AI {
+      const int r = (R1 << (C::A2 + C::AL)) + tp.r_low;
+      StaticFor<0, NCOL>::run([&]<int C1>() RPSF_AI {
+        const int cp = (C1 << C::B2) + tp.c2;
+        const f32x4 q = *reinterpret_cast<const f32x4*>(base + (size_t)r * im.ld + 4 * cp);
+        v[2 * (R1 * NCOL + C1)] = cf{q.x, q.y};
+        v[2 * (R1 * NCOL + C1) + 1] = cf{q.z, q.w};
+      });
+    });
+  } else {
+    StaticFor<0, NR>::run([&]<int R1>() RPSF_AI {
+      const int r = (R1 << (C::A2 + C::AL)) + tp.r_low;
+      const int yl = maps[r];
+      const float* row = im.img + (size_t)(yl < 0 ? 0 : yl) * im.ld;
+      StaticFor<0, NCOL>::run([&]<int C1>() RPSF_AI {
+        const int cp = (C1 << C::B2) + tp.c2;
+        float px[4];
+        StaticFor<0, 4>::run([&]<int I>() RPSF_AI {
+          const int x = maps[C::N + 4 * cp + I];
+          const float raw = row[x < 0 ? 0 : x];  // always in bounds; select afterwards
+          px[I] = (yl < 0 || x < 0) ? im.pad_value : raw;
+        });
+        v[2 * (R1 * NCOL + C1)] = cf{px[0], px[1]};
+        v[2 * (R1 * NCOL + C1) + 1] = cf{px[2], px[3]};
+      });
+    });
+  }
+}
+template <class C>
+RPSF_HD void window_patch2(int t, cf* v, const float* __restrict__ win) {
+  ThreadPos2<C> tp(t);
+  constexpr int NR = 1 << C::A1, NCOL = 1 << C::B1;
+  StaticFor<0, NR>::run([&]<int R1>() RPSF_AI {
+    const float wr = win[(R1 << (C::A2 + C::AL)) + tp.r_low];
+    StaticFor<0, NCOL>::run([&]<int C1>() RPSF_AI {
+      const int cp = (C1 << C::B2) + tp.c2;
+      const f32x4 w4 = *reinterpret_cast<const f32x4*>(win + 4 * cp);
+      cf& a = v[2 * (R1 * NCOL + C1)];
+      cf& b = v[2 * (R1 * NCOL + C1) + 1];
+      a = cf{a.x * (w4.x * wr), a.y * (w4.y * wr)};
+      b = cf{b.x * (w4.z * wr), b.y * (w4.w * wr)};
+    });
+  });
+}
+template <class C>
+RPSF_HD void load_patch2(int t, cf* v, const ImageView& im, int pr, int pc, const float* __restrict__ win, bool fast, const int* maps) {
+  load_raw2<C>(t, v, im, pr, pc, fast, maps);
+  window_patch2<C>(t, v, win);
+}
+
+// Overlap-add of the finished patch.  qw: the four quadrant words of rpsf_core.hpp (store_patch_direct) or nullptr:
+//   nullptr + pv.plane_stride != 0: every pixel into colour plane `plane` (streaming stores);
+//   nullptr + pv.plane_stride == 0: float atomics into pv.out (ADD);
+//   else: QUAD_DIRECT quadrants into dv.out (accumulating onto what is there when QUAD_ACC is set, read with LOAD4 /
+//   LOAD1 = L1-bypassing loads), QUAD_SIDE quadrants into the colour plane.
+template <class C, class ADD, class LOAD4, class LOAD1>
+RPSF_HD void store_patch2(int t, const cf* v, const OutView& pv, const OutView& dv, int plane, int pr, int pc,
+                          const float* __restrict__ win, const uint32_t* qw, ADD&& add, LOAD4&& load4, LOAD1&& load1) {
+  ThreadPos2<C> tp(t);
+  constexpr int NR = 1 << C::A1, NCOL = 1 << C::B1;
+  const bool planes = pv.plane_stride != 0;
+  float* pbase = pv.out + (size_t)plane * pv.plane_stride;
+  const bool fast = patch_inside<C>(pr, pc, pv.H, pv.W, pv.row0, pv.rows) && quads_aligned(pbase, pv.ld, pc) &&
+                    (planes || qw) && (!qw || quads_aligned(dv.out, dv.ld, pc));
+  if (fast) {
+    float* prow0 = pbase + (size_t)(pr - pv.row0) * pv.ld + pc;
+    float* drow0 = qw ? dv.out + (size_t)(pr - dv.row0) * dv.ld + pc : nullptr;
+    constexpr int BATCH = 4;  // rows of units whose running sums are in flight together
+    StaticFor<0, NR / BATCH>::run([&]<int RB>() RPSF_AI {
+      f32x4 old[BATCH * NCOL];
+      StaticFor<0, BATCH * NCOL>::run([&]<int U>() RPSF_AI {
+        constexpr int R1 = RB * BATCH + U / NCOL, C1 = U % NCOL, QD = 2 * (R1 >= NR / 2) + (C1 >= NCOL / 2);
+        old[U] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (qw && quad_mode(qw[QD]) == QUAD_DIRECT && (qw[QD] & QUAD_ACC)) {
+          const int r = (R1 << (C::A2 + C::AL)) + tp.r_low, cp = (C1 << C::B2) + tp.c2;
+          old[U] = load4(drow0 + (size_t)r * dv.ld + 4 * cp);
+        }
+      });
+      StaticFor<0, BATCH * NCOL>::run([&]<int U>() RPSF_AI {
+        constexpr int R1 = RB * BATCH + U / NCOL, C1 = U % NCOL, QD = 2 * (R1 >= NR / 2) + (C1 >= NCOL / 2);
+        const int r = (R1 << (C::A2 + C::AL)) + tp.r_low, cp = (C1 << C::B2) + tp.c2;
+        const float wr = win[r];
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(win + 4 * cp);
+        const cf a = v[2 * (R1 * NCOL + C1)], b = v[2 * (R1 * NCOL + C1) + 1];
+        f32x4 val = {a.x * (w4.x * wr), a.y * (w4.y * wr), b.x * (w4.z * wr), b.y * (w4.w * wr)};
+        if (!qw || quad_mode(qw[QD]) == QUAD_SIDE) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RPSF_NO_NT)
+          __builtin_nontemporal_store(val, reinterpret_cast<f32x4*>(prow0 + (size_t)r * pv.ld + 4 * cp));
+#else
+          *reinterpret_cast<f32x4*>(prow0 + (size_t)r * pv.ld + 4 * cp) = val;
+#endif
+        } else if (quad_mode(qw[QD]) == QUAD_DIRECT) {
+          val += old[U];
+          *reinterpret_cast<f32x4*>(drow0 + (size_t)r * dv.ld + 4 * cp) = val;
+        }
+      });
+    });
+    return;
+  }
+  StaticFor<0, NR>::run([&]<int R1>() RPSF_AI {
+    const int r = (R1 << (C::A2 + C::AL)) + tp.r_low;
+    const float wr = win[r];
+    const int y = pr + r, yl = y - pv.row0;
+    if (y >= 0 && y < pv.H && yl >= 0 && yl < pv.rows) {
+      StaticFor<0, NCOL>::run([&]<int C1>() RPSF_AI {
+        constexpr int QD = 2 * (R1 >= NR / 2) + (C1 >= NCOL / 2);
+        const int cp = (C1 << C::B2) + tp.c2;
+        const cf a = v[2 * (R1 * NCOL + C1)], b = v[2 * (R1 * NCOL + C1) + 1];
+        const float px[4] = {a.x, a.y, b.x, b.y};
+        StaticFor<0, 4>::run([&]<int I>() RPSF_AI {
+          const int x = pc + 4 * cp + I;
+          if (x < 0 || x >= pv.W) return;
+          const float val = px[I] * (wr * win[4 * cp + I]);
+          if (!qw) {
+            float* dst = pbase + (size_t)yl * pv.ld + x;
+            if (planes) *dst = val; else add(dst, val);
+          } else if (quad_mode(qw[QD]) == QUAD_DIRECT) {
+            float* dst = dv.out + (size_t)(y - dv.row0) * dv.ld + x;
+            *dst = ((qw[QD] & QUAD_ACC) ? load1(dst) : 0.f) + val;
+          } else if (quad_mode(qw[QD]) == QUAD_SIDE) {
+            pbase[(size_t)yl * pv.ld + x] = val;
+          }
+        });
+      });
+    }
+  });
+}
+
+// Plans compiled into the library
+using Cfg256v2 = Cfg2<8, 4, 0, 4, 1, 5>;
+using Cfg128v2 = Cfg2<7, 4, 1, 2, 1, 4>;
+
+}  // namespace rpsf

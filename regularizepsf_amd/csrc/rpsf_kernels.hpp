@@ -1,79 +1,10 @@
-// rpsf_kernels.hpp - the device code of librpsf_hip.so: K5 (colour-plane sum), K1 (patch kernel), the K
-// pack kernel, K2 (transfer-kernel build), K3 (PSF spectra), K4 (seam add) and the three small kernels of
-// the hipFFT fallback.  Included by rpsf.hip only (one translation unit); the per-thread phase functions the
-// kernels are made of live in rpsf_core.hpp, which the CPU emulator (tests/emu) compiles as well.
+// rpsf_kernels.hpp - the device code of librpsf_hip.so: K1 (patch kernel), its K pack kernel and K3 (PSF spectra) as
+// templates over the plan geometry - instantiated in the k1_*.hip translation units, one group of plans each, so
+// that the library builds in parallel - and, for the host translation unit only (RPSF_HOST_TU), the plan-independent
+// kernels: K5 (colour-plane sum), K5' (fix-up of the direct overlap-add), K2 (transfer-kernel build), K4 (seam add)
+// and the three small kernels of the hipFFT fallback.  The per-thread phase functions the kernels are made of live
+// in rpsf_core.hpp / rpsf_core2.hpp, which the CPU emulators (tests/emu) compile as well.
 #pragma once
-
-// ------------------------------------------------------------------------------------------------
-// K5: out = sum of the colour planes that have a patch over the pixel (fixed order: deterministic)
-// ------------------------------------------------------------------------------------------------
-struct SumParams {
-  const float* planes;
-  size_t plane_stride;
-  float* out;
-  int rows, W, ld_planes, ld_out;
-  int row_begin;       // first window row this launch sums
-  int row0;            // full-image row of window row 0
-  int lat_r0, lat_c0;  // full-image coordinates of lattice tile (0, 0)
-  int half_shift;      // log2(N/2)
-  int nti, ntj;
-  const uint8_t* cover;  // nti x ntj, 4-bit class masks
-  size_t planes_frame_floats, out_frame_floats;  // batch: frame f (= blockIdx.y) at planes + f*..., out + f*...
-};
-
-__device__ __forceinline__ int cover_at(const SumParams& p, int y, int x) {
-  int ty = (y - p.lat_r0) >> p.half_shift, tx = (x - p.lat_c0) >> p.half_shift;
-  if (y < p.lat_r0 || x < p.lat_c0 || ty >= p.nti || tx >= p.ntj) return 0;
-  return p.cover[ty * p.ntj + tx];
-}
-
-__device__ __forceinline__ bool sum_vector_ok(const SumParams& p) {
-  return ((p.ld_planes | p.ld_out) & 3) == 0 &&
-         ((reinterpret_cast<uintptr_t>(p.planes) | reinterpret_cast<uintptr_t>(p.out) | (p.plane_stride * 4)) & 15) == 0;
-}
-// Branch-free 16-byte read of plane k: a plane without a patch over the tile is never read (its content is
-// stale) - the load is redirected to one always-valid line and its result discarded.  Keeping the loads
-// unconditional matters: a load under a branch is waited for at the join, which serialises the four planes.
-__device__ __forceinline__ float4 load_plane4(const SumParams& p, int k, size_t off, int cov) {
-  const bool on = (cov >> k) & 1;
-  const float* src = on ? p.planes + k * p.plane_stride + off : p.planes;
-  typedef float f4 __attribute__((ext_vector_type(4)));
-  f4 a = __builtin_nontemporal_load(reinterpret_cast<const f4*>(src));
-  return make_float4(on ? a.x : 0.f, on ? a.y : 0.f, on ? a.z : 0.f, on ? a.w : 0.f);
-}
-__device__ __forceinline__ void store_out4(float* o, float4 v) {
-  typedef float f4 __attribute__((ext_vector_type(4)));
-  f4 w = {v.x, v.y, v.z, v.w};
-  __builtin_nontemporal_store(w, reinterpret_cast<f4*>(o));
-}
-
-// four consecutive pixels (x .. x+3) of window row yl
-__device__ __forceinline__ void sum_planes_group(const SumParams& p, int yl, int x, bool vector_ok) {
-  int y = yl + p.row0;
-  size_t off = (size_t)yl * p.ld_planes + x;
-  float* o = p.out + (size_t)yl * p.ld_out + x;
-  int c0 = cover_at(p, y, x), c3 = cover_at(p, y, x + 3);
-  if (vector_ok && x + 3 < p.W && c0 == c3) {  // one tile, aligned: four 16-byte loads, one 16-byte store
-    float4 a0 = load_plane4(p, 0, off, c0), a1 = load_plane4(p, 1, off, c0), a2 = load_plane4(p, 2, off, c0),
-           a3 = load_plane4(p, 3, off, c0);
-    store_out4(o, make_float4(((a0.x + a1.x) + a2.x) + a3.x, ((a0.y + a1.y) + a2.y) + a3.y,
-                              ((a0.z + a1.z) + a2.z) + a3.z, ((a0.w + a1.w) + a2.w) + a3.w));
-  } else {
-    for (int i = 0; i < 4 && x + i < p.W; ++i) o[i] = sum_planes_at(p.planes, p.plane_stride, off + i, cover_at(p, y, x + i));
-  }
-}
-
-__global__ void sum_planes_kernel(SumParams p) {
-  p.planes += (size_t)blockIdx.y * p.planes_frame_floats;
-  p.out += (size_t)blockIdx.y * p.out_frame_floats;
-  const unsigned groups = (unsigned)(p.W + 3) >> 2;
-  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (size_t)groups * p.rows) return;
-  const bool small = (size_t)groups * p.rows < ((size_t)1 << 32);
-  const int yl = small ? (int)((unsigned)idx / groups) : (int)(idx / groups);
-  const int xg = small ? (int)((unsigned)idx % groups) : (int)(idx % groups);
-  sum_planes_group(p, yl + p.row_begin, xg * 4, sum_vector_ok(p));
-}
 
 // ------------------------------------------------------------------------------------------------
 // K1
@@ -142,23 +73,20 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 #define STAMP(i) ((void)0)
 #endif
 
-// Direct overlap-add epilogue of one workgroup (= one patch; three-stage plans only).  See rpsf_core.hpp,
+// Direct overlap-add protocol of one workgroup (= one patch; three-stage plans only).  See rpsf_core.hpp,
 // store_patch_direct, for the scheme.  Same-XCD visibility needs no cache maintenance: stores go through to the
 // XCD's L2 (complete once vmcnt has drained) and the successor reads them with L1-bypassing loads.  That the
 // workgroups of one chunk really share an XCD is an observation about the dispatcher, not a guarantee, so it is
 // checked: the first workgroup of a chunk registers its XCC id, and one that finds itself elsewhere ("orphan")
 // sends all four quadrants to its colour plane, marks them in dyn_side for the fix-up kernel and only keeps
 // the flags moving.
-template <class C>
-__device__ __forceinline__ void direct_store(const PatchParams& p, int t, const cf* v, const OutView& ov, int frame, int seq,
-                                             int plane, int pr, int pc, const float* win, uint32_t* scratch) {
-  OutView dv = p.dv;
-  dv.out += (size_t)frame * p.dv_frame_floats;
+// direct_begin: registers / checks the XCD, waits for the predecessors of the quadrants that accumulate into the
+// output and returns the run-time quadrant words.  scratch: 8 words of LDS no other wave is using.
+__device__ __forceinline__ void direct_begin(const PatchParams& p, int frame, int seq, uint32_t (&qw)[4], uint32_t* scratch) {
   const uint4 q4 = p.quads[p.seq_base + seq];
-  uint32_t qw[4] = {q4.x, q4.y, q4.z, q4.w};
+  qw[0] = q4.x, qw[1] = q4.y, qw[2] = q4.z, qw[3] = q4.w;
   uint32_t* flags = p.flags + (size_t)frame * p.n_tiles;
   const uint32_t epoch = p.flag_epoch;
-  // ---- where am I? ----
   if (threadIdx.x == 0) {
     uint32_t xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
@@ -173,7 +101,6 @@ __device__ __forceinline__ void direct_store(const PatchParams& p, int t, const 
     if (p.orphan_mod > 0 && seq % p.orphan_mod == 1) orphan = true;
     scratch[0] = orphan ? 1u : 0u;
   }
-  // ---- wait for the predecessors of the quadrants that accumulate into the output ----
   if (threadIdx.x < 4) {
     const uint32_t w = qw[threadIdx.x];
     uint32_t init = 0;
@@ -194,14 +121,11 @@ __device__ __forceinline__ void direct_store(const PatchParams& p, int t, const 
     if (orphan) qw[q] = quad_word(QUAD_SIDE, quad_rank(qw[q]), quad_tile(qw[q])) | QUAD_DEMOTED | (scratch[1 + q] ? QUAD_ACC : 0u);
     else if (scratch[1 + q]) qw[q] |= QUAD_ACC;
   }
-  store_patch_direct<C>(
-      t, v, ov, dv, plane, pr, pc, win, qw,
-      [](const float* a) {
-        const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return cf{__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32))};
-      },
-      [](const float* a) { return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); });
-  // ---- publish: every wave drains its stores, then one lane per quadrant moves the tile's flag on ----
+}
+// direct_end: every wave drains its stores, then one lane per quadrant moves the tile's flag on
+__device__ __forceinline__ void direct_end(const PatchParams& p, int frame, int plane, const uint32_t (&qw)[4]) {
+  const uint32_t epoch = p.flag_epoch;
+  uint32_t* flags = p.flags + (size_t)frame * p.n_tiles;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   lds_barrier();
   if (threadIdx.x < 4) {
@@ -218,6 +142,23 @@ __device__ __forceinline__ void direct_store(const PatchParams& p, int t, const 
       __hip_atomic_store(flags + quad_tile(w), (epoch << 8) | (init << 3) | (quad_rank(w) + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+}
+
+template <class C>
+__device__ __forceinline__ void direct_store(const PatchParams& p, int t, const cf* v, const OutView& ov, int frame, int seq,
+                                             int plane, int pr, int pc, const float* win, uint32_t* scratch) {
+  OutView dv = p.dv;
+  dv.out += (size_t)frame * p.dv_frame_floats;
+  uint32_t qw[4];
+  direct_begin(p, frame, seq, qw, scratch);
+  store_patch_direct<C>(
+      t, v, ov, dv, plane, pr, pc, win, qw,
+      [](const float* a) {
+        const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return cf{__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32))};
+      },
+      [](const float* a) { return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); });
+  direct_end(p, frame, plane, qw);
 }
 
 template <class C>
@@ -371,77 +312,6 @@ __global__ __launch_bounds__(Launch<C>::WG, Launch<C>::WAVES_PER_SIMD) void patc
 }
 
 // ------------------------------------------------------------------------------------------------
-// K5': fix-up after a direct overlap-add launch.  FIX_SUB workgroups per lattice tile; most exit at once.
-//   out_tile = (tile initialised by its direct contributors ? out_tile : 0) + sum of the colour planes that hold a
-//   side contribution (static: contributors of another chunk; dynamic: demoted at run time), in colour order.
-// Tiles without any contributor are zeroed (the reference leaves uncovered output at 0, transform.py:167-169).
-// ------------------------------------------------------------------------------------------------
-struct FixParams {
-  const float* planes;
-  size_t plane_stride, planes_frame_floats;
-  int ld_planes;
-  float* out;
-  int ld_out;
-  size_t out_frame_floats;
-  int rows, W, row0;           // resident output window: rows [row0, row0 + rows) of the image, W columns
-  int lat_r0, lat_c0, half;    // full-image coordinates of lattice tile (0, 0); tile edge
-  int ntj;
-  const uint8_t* tile_info;    // bits 0-3 static side mask, bit 4 tile has contributors
-  const uint32_t* flags;
-  const uint32_t* dyn_side;
-  uint32_t epoch, n_tiles;
-};
-constexpr int FIX_SUB = 8;
-
-__global__ __launch_bounds__(256) void fixup_kernel(FixParams p) {
-  const uint32_t tile = blockIdx.x / FIX_SUB, sub = blockIdx.x % FIX_SUB, frame = blockIdx.y;
-  const uint32_t d = p.dyn_side[(size_t)frame * p.n_tiles + tile], f = p.flags[(size_t)frame * p.n_tiles + tile];
-  const uint32_t side = (p.tile_info[tile] & 15u) | ((d >> 8) == p.epoch ? (d & 15u) : 0u);
-  const bool init = (f >> 8) == p.epoch && (f & 8u);
-  if (side == 0 && init) return;
-  const int ti = tile / p.ntj, tj = tile % p.ntj;
-  const int span = (p.half + FIX_SUB - 1) / FIX_SUB;
-  const int ty0 = p.lat_r0 + ti * p.half + (int)sub * span;
-  const int y0 = max(ty0, p.row0), y1 = min(min(ty0 + span, p.lat_r0 + (ti + 1) * p.half), p.row0 + p.rows);
-  const int x0 = max(p.lat_c0 + tj * p.half, 0), x1 = min(p.lat_c0 + (tj + 1) * p.half, p.W);
-  if (y0 >= y1 || x0 >= x1) return;
-  const float* planes = p.planes + (size_t)frame * p.planes_frame_floats;
-  float* out = p.out + (size_t)frame * p.out_frame_floats;
-  const bool vec = ((x0 | x1 | p.ld_planes | p.ld_out) & 3) == 0 && (p.plane_stride & 3) == 0 &&
-                   ((reinterpret_cast<uintptr_t>(planes) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
-  typedef float f4 __attribute__((ext_vector_type(4)));
-  if (vec) {
-    const int gw = (x1 - x0) >> 2, total = gw * (y1 - y0);
-    for (int i = threadIdx.x; i < total; i += blockDim.x) {
-      const int yl = y0 + i / gw - p.row0, x = x0 + ((i % gw) << 2);
-      f4* o = reinterpret_cast<f4*>(out + (size_t)yl * p.ld_out + x);
-      const f4* pl = reinterpret_cast<const f4*>(planes + (size_t)yl * p.ld_planes + x);
-      f4 v[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k)  // unconditional loads (redirected to plane 0's line when unused) so they overlap
-        v[k] = __builtin_nontemporal_load(((side >> k) & 1) ? pl + k * (p.plane_stride >> 2) : pl);
-      f4 acc = init ? *o : f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if ((side >> k) & 1) acc += v[k];
-      *o = acc;
-    }
-  } else {
-    const int w = x1 - x0, total = w * (y1 - y0);
-    for (int i = threadIdx.x; i < total; i += blockDim.x) {
-      const int yl = y0 + i / w - p.row0, x = x0 + i % w;
-      float* o = out + (size_t)yl * p.ld_out + x;
-      const float* pl = planes + (size_t)yl * p.ld_planes + x;
-      float acc = init ? *o : 0.f;
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if ((side >> k) & 1) acc += pl[k * p.plane_stride];
-      *o = acc;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // K-pack
 // ------------------------------------------------------------------------------------------------
 template <class C>
@@ -462,48 +332,6 @@ __global__ void pack_kernel(const cf* __restrict__ kfull, int n_patches, const u
       gs[(size_t)patch * C::GS_PER_PATCH + (size_t)C::spec_prefix(s) * 2 * C::E + ((size_t)e * C::spec_t(s) + t) * 2 + b] =
           pack_value<C>(kf, tab, pt, t, rho, 1);
   }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K2: transform.py:78-82.  Mirrors NumPy's evaluation order: |.| by hypot, scalar powers with
-// NumPy's fast paths (0, 1, 2, 0.5, -1), complex * real as a full complex product with (r, 0),
-// complex / real as NumPy's scaled division, then a plain complex product with T.
-// ------------------------------------------------------------------------------------------------
-template <class R>
-__device__ __forceinline__ R np_pow(R x, R e) {
-  if (e == R(0)) return R(1);
-  if (e == R(1)) return x;
-  if (e == R(2)) return x * x;
-  if (e == R(0.5)) return sqrt(x);
-  if (e == R(-1)) return R(1) / x;
-  return pow(x, e);
-}
-
-template <class R>
-__global__ void build_transfer_kernel(const R* __restrict__ s, const R* __restrict__ t, R* __restrict__ k,
-                                      size_t count, R alpha, R eps) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  R sr = s[2 * i], si = s[2 * i + 1], tr = t[2 * i], ti = t[2 * i + 1];
-  R sabs = hypot(sr, si), tabs = hypot(tr, ti);
-  R pw = np_pow(sabs, alpha - R(1));
-  // conj(S) * (pw + 0i)
-  R cr = sr, ci = -si;
-  R nr = cr * pw - ci * R(0), ni = cr * R(0) + ci * pw;
-  R den = np_pow(sabs, alpha + R(1)) + np_pow(eps * tabs, alpha + R(1));
-  // (nr + i ni) / (den + 0i), NumPy's algorithm for |re| >= |im|
-  R qr, qi;
-  if (fabs(den) == R(0)) {
-    qr = nr / fabs(den);
-    qi = ni / fabs(den);
-  } else {
-    R rat = R(0) / den;
-    R scl = R(1) / (den + R(0) * rat);
-    qr = (nr + ni * rat) * scl;
-    qi = (ni - nr * rat) * scl;
-  }
-  k[2 * i] = qr * tr - qi * ti;
-  k[2 * i + 1] = qr * ti + qi * tr;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -595,6 +423,192 @@ __global__ __launch_bounds__(Launch<C>::WG) void psf_fft_kernel(const float* __r
   });
 }
 
+
+#if defined(RPSF_HOST_TU)
+// ------------------------------------------------------------------------------------------------
+// K5: out = sum of the colour planes that have a patch over the pixel (fixed order: deterministic)
+// ------------------------------------------------------------------------------------------------
+struct SumParams {
+  const float* planes;
+  size_t plane_stride;
+  float* out;
+  int rows, W, ld_planes, ld_out;
+  int row_begin;       // first window row this launch sums
+  int row0;            // full-image row of window row 0
+  int lat_r0, lat_c0;  // full-image coordinates of lattice tile (0, 0)
+  int half_shift;      // log2(N/2)
+  int nti, ntj;
+  const uint8_t* cover;  // nti x ntj, 4-bit class masks
+  size_t planes_frame_floats, out_frame_floats;  // batch: frame f (= blockIdx.y) at planes + f*..., out + f*...
+};
+
+__device__ __forceinline__ int cover_at(const SumParams& p, int y, int x) {
+  int ty = (y - p.lat_r0) >> p.half_shift, tx = (x - p.lat_c0) >> p.half_shift;
+  if (y < p.lat_r0 || x < p.lat_c0 || ty >= p.nti || tx >= p.ntj) return 0;
+  return p.cover[ty * p.ntj + tx];
+}
+
+__device__ __forceinline__ bool sum_vector_ok(const SumParams& p) {
+  return ((p.ld_planes | p.ld_out) & 3) == 0 &&
+         ((reinterpret_cast<uintptr_t>(p.planes) | reinterpret_cast<uintptr_t>(p.out) | (p.plane_stride * 4)) & 15) == 0;
+}
+// Branch-free 16-byte read of plane k: a plane without a patch over the tile is never read (its content is
+// stale) - the load is redirected to one always-valid line and its result discarded.  Keeping the loads
+// unconditional matters: a load under a branch is waited for at the join, which serialises the four planes.
+__device__ __forceinline__ float4 load_plane4(const SumParams& p, int k, size_t off, int cov) {
+  const bool on = (cov >> k) & 1;
+  const float* src = on ? p.planes + k * p.plane_stride + off : p.planes;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  f4 a = __builtin_nontemporal_load(reinterpret_cast<const f4*>(src));
+  return make_float4(on ? a.x : 0.f, on ? a.y : 0.f, on ? a.z : 0.f, on ? a.w : 0.f);
+}
+__device__ __forceinline__ void store_out4(float* o, float4 v) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  f4 w = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(w, reinterpret_cast<f4*>(o));
+}
+
+// four consecutive pixels (x .. x+3) of window row yl
+__device__ __forceinline__ void sum_planes_group(const SumParams& p, int yl, int x, bool vector_ok) {
+  int y = yl + p.row0;
+  size_t off = (size_t)yl * p.ld_planes + x;
+  float* o = p.out + (size_t)yl * p.ld_out + x;
+  int c0 = cover_at(p, y, x), c3 = cover_at(p, y, x + 3);
+  if (vector_ok && x + 3 < p.W && c0 == c3) {  // one tile, aligned: four 16-byte loads, one 16-byte store
+    float4 a0 = load_plane4(p, 0, off, c0), a1 = load_plane4(p, 1, off, c0), a2 = load_plane4(p, 2, off, c0),
+           a3 = load_plane4(p, 3, off, c0);
+    store_out4(o, make_float4(((a0.x + a1.x) + a2.x) + a3.x, ((a0.y + a1.y) + a2.y) + a3.y,
+                              ((a0.z + a1.z) + a2.z) + a3.z, ((a0.w + a1.w) + a2.w) + a3.w));
+  } else {
+    for (int i = 0; i < 4 && x + i < p.W; ++i) o[i] = sum_planes_at(p.planes, p.plane_stride, off + i, cover_at(p, y, x + i));
+  }
+}
+
+__global__ void sum_planes_kernel(SumParams p) {
+  p.planes += (size_t)blockIdx.y * p.planes_frame_floats;
+  p.out += (size_t)blockIdx.y * p.out_frame_floats;
+  const unsigned groups = (unsigned)(p.W + 3) >> 2;
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)groups * p.rows) return;
+  const bool small = (size_t)groups * p.rows < ((size_t)1 << 32);
+  const int yl = small ? (int)((unsigned)idx / groups) : (int)(idx / groups);
+  const int xg = small ? (int)((unsigned)idx % groups) : (int)(idx % groups);
+  sum_planes_group(p, yl + p.row_begin, xg * 4, sum_vector_ok(p));
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5': fix-up after a direct overlap-add launch.  FIX_SUB workgroups per lattice tile; most exit at once.
+//   out_tile = (tile initialised by its direct contributors ? out_tile : 0) + sum of the colour planes that hold a
+//   side contribution (static: contributors of another chunk; dynamic: demoted at run time), in colour order.
+// Tiles without any contributor are zeroed (the reference leaves uncovered output at 0, transform.py:167-169).
+// ------------------------------------------------------------------------------------------------
+struct FixParams {
+  const float* planes;
+  size_t plane_stride, planes_frame_floats;
+  int ld_planes;
+  float* out;
+  int ld_out;
+  size_t out_frame_floats;
+  int rows, W, row0;           // resident output window: rows [row0, row0 + rows) of the image, W columns
+  int lat_r0, lat_c0, half;    // full-image coordinates of lattice tile (0, 0); tile edge
+  int ntj;
+  const uint8_t* tile_info;    // bits 0-3 static side mask, bit 4 tile has contributors
+  const uint32_t* flags;
+  const uint32_t* dyn_side;
+  uint32_t epoch, n_tiles;
+};
+constexpr int FIX_SUB = 8;
+
+__global__ __launch_bounds__(256) void fixup_kernel(FixParams p) {
+  const uint32_t tile = blockIdx.x / FIX_SUB, sub = blockIdx.x % FIX_SUB, frame = blockIdx.y;
+  const uint32_t d = p.dyn_side[(size_t)frame * p.n_tiles + tile], f = p.flags[(size_t)frame * p.n_tiles + tile];
+  const uint32_t side = (p.tile_info[tile] & 15u) | ((d >> 8) == p.epoch ? (d & 15u) : 0u);
+  const bool init = (f >> 8) == p.epoch && (f & 8u);
+  if (side == 0 && init) return;
+  const int ti = tile / p.ntj, tj = tile % p.ntj;
+  const int span = (p.half + FIX_SUB - 1) / FIX_SUB;
+  const int ty0 = p.lat_r0 + ti * p.half + (int)sub * span;
+  const int y0 = max(ty0, p.row0), y1 = min(min(ty0 + span, p.lat_r0 + (ti + 1) * p.half), p.row0 + p.rows);
+  const int x0 = max(p.lat_c0 + tj * p.half, 0), x1 = min(p.lat_c0 + (tj + 1) * p.half, p.W);
+  if (y0 >= y1 || x0 >= x1) return;
+  const float* planes = p.planes + (size_t)frame * p.planes_frame_floats;
+  float* out = p.out + (size_t)frame * p.out_frame_floats;
+  const bool vec = ((x0 | x1 | p.ld_planes | p.ld_out) & 3) == 0 && (p.plane_stride & 3) == 0 &&
+                   ((reinterpret_cast<uintptr_t>(planes) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  if (vec) {
+    const int gw = (x1 - x0) >> 2, total = gw * (y1 - y0);
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+      const int yl = y0 + i / gw - p.row0, x = x0 + ((i % gw) << 2);
+      f4* o = reinterpret_cast<f4*>(out + (size_t)yl * p.ld_out + x);
+      const f4* pl = reinterpret_cast<const f4*>(planes + (size_t)yl * p.ld_planes + x);
+      f4 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)  // unconditional loads (redirected to plane 0's line when unused) so they overlap
+        v[k] = __builtin_nontemporal_load(((side >> k) & 1) ? pl + k * (p.plane_stride >> 2) : pl);
+      f4 acc = init ? *o : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if ((side >> k) & 1) acc += v[k];
+      *o = acc;
+    }
+  } else {
+    const int w = x1 - x0, total = w * (y1 - y0);
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+      const int yl = y0 + i / w - p.row0, x = x0 + i % w;
+      float* o = out + (size_t)yl * p.ld_out + x;
+      const float* pl = planes + (size_t)yl * p.ld_planes + x;
+      float acc = init ? *o : 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if ((side >> k) & 1) acc += pl[k * p.plane_stride];
+      *o = acc;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: transform.py:78-82.  Mirrors NumPy's evaluation order: |.| by hypot, scalar powers with
+// NumPy's fast paths (0, 1, 2, 0.5, -1), complex * real as a full complex product with (r, 0),
+// complex / real as NumPy's scaled division, then a plain complex product with T.
+// ------------------------------------------------------------------------------------------------
+template <class R>
+__device__ __forceinline__ R np_pow(R x, R e) {
+  if (e == R(0)) return R(1);
+  if (e == R(1)) return x;
+  if (e == R(2)) return x * x;
+  if (e == R(0.5)) return sqrt(x);
+  if (e == R(-1)) return R(1) / x;
+  return pow(x, e);
+}
+
+template <class R>
+__global__ void build_transfer_kernel(const R* __restrict__ s, const R* __restrict__ t, R* __restrict__ k,
+                                      size_t count, R alpha, R eps) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  R sr = s[2 * i], si = s[2 * i + 1], tr = t[2 * i], ti = t[2 * i + 1];
+  R sabs = hypot(sr, si), tabs = hypot(tr, ti);
+  R pw = np_pow(sabs, alpha - R(1));
+  // conj(S) * (pw + 0i)
+  R cr = sr, ci = -si;
+  R nr = cr * pw - ci * R(0), ni = cr * R(0) + ci * pw;
+  R den = np_pow(sabs, alpha + R(1)) + np_pow(eps * tabs, alpha + R(1));
+  // (nr + i ni) / (den + 0i), NumPy's algorithm for |re| >= |im|
+  R qr, qi;
+  if (fabs(den) == R(0)) {
+    qr = nr / fabs(den);
+    qi = ni / fabs(den);
+  } else {
+    R rat = R(0) / den;
+    R scl = R(1) / (den + R(0) * rat);
+    qr = (nr + ni * rat) * scl;
+    qi = (ni - nr * rat) * scl;
+  }
+  k[2 * i] = qr * tr - qi * ti;
+  k[2 * i + 1] = qr * ti + qi * tr;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K4: accum[i] += src[i]
 // ------------------------------------------------------------------------------------------------
@@ -647,3 +661,5 @@ __global__ void generic_scatter_kernel(GenericGeom gg, const int32_t* __restrict
   unsafeAtomicAdd(gg.ov.out + (size_t)(y - gg.ov.row0) * gg.ov.ld + x, buf[idx].x * (win[r] * win[c]));
 }
 
+
+#endif  // RPSF_HOST_TU

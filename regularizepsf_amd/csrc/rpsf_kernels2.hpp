@@ -1,0 +1,187 @@
+// rpsf_kernels2.hpp - K1 of the three-stage plans (N = 128, 256), second generation: 16-byte global units, 8-byte
+// LDS units, the two column-parity halves of the patch pipelined through the stages (rpsf_core2.hpp), and its K pack
+// kernel.  Included by rpsf.hip after rpsf_kernels.hpp (PatchParams, barriers, STAMP, the direct-mode protocol).
+#pragma once
+
+template <class C>
+struct Launch2 {
+  static constexpr int WG = C::T;
+  static constexpr int OT_WORDS = C::ORBIT_ROUNDS * 64;
+  static constexpr int TABLE_FLOATS = 3 * C::N + OT_WORDS;  // twiddles (N complex) + window (N) + bin pairs of the self-paired groups
+  static constexpr size_t LDS_BYTES = (size_t)TABLE_FLOATS * sizeof(float) + (size_t)C::LDS_UNITS * sizeof(cf);
+  static_assert(TABLE_FLOATS % 4 == 0, "the exchange buffer must stay 16-byte aligned");
+};
+
+// 16-byte load that bypasses this CU's L1 (agent scope), through a raw buffer descriptor so that the compiler tracks it
+__device__ __forceinline__ f32x4 load16_sc1(const float* base, size_t span_bytes, const float* p) {
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)span_bytes, 0x00020000);
+  const i32x4 q = __builtin_amdgcn_raw_buffer_load_b128(r, (int)((p - base) * sizeof(float)), 0, /*sc1*/ 16);
+  return f32x4{__int_as_float(q.x), __int_as_float(q.y), __int_as_float(q.z), __int_as_float(q.w)};
+}
+
+template <class C>
+__global__ __launch_bounds__(Launch2<C>::WG, 2) void patch_kernel2(PatchParams p) {  // 2 waves per SIMD: 256 registers
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int T = C::T, N = C::N;
+  const int t = threadIdx.x;
+  int frame = 0, xrow = blockIdx.x >> 3;
+  if (p.n_frames > 1) {
+    frame = xrow % p.n_frames;
+    xrow /= p.n_frames;
+  }
+  const int seq = (blockIdx.x & 7) * p.chunk + xrow;
+  if (xrow >= p.chunk || seq >= p.n_patches) return;  // workgroup-uniform
+  ImageView im = p.im;
+  OutView ov = p.ov;
+  im.img += (size_t)frame * p.im_frame_floats;
+  ov.out += (size_t)frame * p.ov_frame_floats;
+  const int4 dsc = p.desc[p.seq_base + seq];
+  const int patch = dsc.z;
+  // Start-up stagger.  The workgroups of one round move in lock step otherwise - all CUs stream K at one moment, store at
+  // another, and the memory system alternates between idle and saturated.  The first resident workgroup of each CU is
+  // held back by a different fraction of stagger_ticks (later workgroups inherit the offset of the one they replace).
+  if (p.stagger_ticks > 0 && (int)blockIdx.x < p.stagger_blocks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long wait = (unsigned long long)(((blockIdx.x >> 3) * 0x9E3779B1u >> 22) & 1023) * p.stagger_ticks >> 10;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+  }
+  STAMP(0);
+  const int pr = dsc.x + p.origin_row, pc = dsc.y + p.origin_col;
+  const cf* g = p.g + (size_t)patch * C::G_PER_PATCH;
+  cf* tw = reinterpret_cast<cf*>(smem);
+  float* win = smem + 2 * N;
+  uint32_t* ot = reinterpret_cast<uint32_t*>(smem + 3 * N);
+  cf* lds = reinterpret_cast<cf*>(smem + Launch2<C>::TABLE_FLOATS);
+  cf* park = lds + C::BUF_UNITS;
+  // Table values first (VMEM returns in order: they arrive ahead of the pixels requested right behind them and are
+  // put into LDS while the gather is in flight).
+  static_assert(N <= 2 * T && Launch2<C>::OT_WORDS <= T, "one or two table entries per thread");
+  const cf tw0 = p.tw[t < N ? t : 0], tw1 = p.tw[t + T < N ? t + T : 0];
+  const float wn0 = p.win[t < N ? t : 0], wn1 = p.win[t + T < N ? t + T : 0];
+  const uint32_t ot0 = p.pairtab[t < Launch2<C>::OT_WORDS ? t : 0];
+  GroupIds<C> gids;
+  gids.load(p.tab, t);
+  cf v[64];
+  const bool fast = patch_inside<C>(pr, pc, im.H, im.W, im.row0, im.rows) && quads_aligned(im.img, im.ld, pc);
+  int* maps = reinterpret_cast<int*>(lds);
+  if (!fast) {
+    build_pad_maps<C>(t, maps, im, pr, pc);
+    lds_barrier();
+  }
+  load_raw2<C>(t, v, im, pr, pc, fast, maps);
+  if (t < N) tw[t] = tw0, win[t] = wn0;
+  if (t + T < N) tw[t + T] = tw1, win[t + T] = wn1;
+  if (t < Launch2<C>::OT_WORDS) ot[t] = ot0;
+  lds_barrier();  // tables staged; the maps (which share LDS with the exchange buffer) are no longer needed
+  window_patch2<C>(t, v, win);
+  STAMP(1);
+  // ---- forward: the halves leapfrog through stage 1, X1 (wave-local) and stage 2 ----
+  stage1h<C, 0, false>(t, v, tw);
+  x1_write2<C, 0>(t, v, lds);
+  stage1h<C, 1, false>(t, v, tw);
+  wave_lds_sync();
+  x1_read2<C, 0>(t, v, lds);
+  x1_write2<C, 1>(t, v, lds);  // (a wave's DS operations complete in order: these writes cannot overtake the reads)
+  STAMP(2);
+  stage2h<C, 0, false>(t, v, tw);
+  wave_lds_sync();
+  x1_read2<C, 1>(t, v, lds);
+  STAMP(3);
+  cf k[2 * C::KCH];
+  load_k_chunk2<C, 0>(t, k, g);  // in flight across the exchange below (raw barriers do not drain VMEM)
+  cf ko[2 * C::ORBIT_ROUNDS];
+  if (t < 64) {
+    const cf* gs = p.gs + (size_t)patch * C::GS_PER_PATCH;
+    StaticFor<0, C::ORBIT_ROUNDS>::run([&]<int R>() RPSF_AI { load_stream16(gs + (size_t)(R * 64 + t) * 2, ko[2 * R], ko[2 * R + 1]); });
+  }
+  lds_barrier();  // every wave has left its X1 region (X2 uses the whole buffer)
+  x2_mid_write2<C, 0>(t, v, lds);
+  stage2h<C, 1, false>(t, v, tw);
+  lds_barrier();
+  x2_last_read2<C, 0>(gids, v, lds);
+  lds_barrier();
+  x2_mid_write2<C, 1>(t, v, lds);
+  if constexpr (C::SPLIT_ROWS) stage3_rows<C, false, 0, 0>(t, gids, v);  // the row DFTs of the half that has arrived, under the exchange of the other
+  lds_barrier();
+  x2_last_read2<C, 1>(gids, v, lds);
+  // no barrier: every X2 unit is read by exactly one thread, the same one that rewrites it below
+  STAMP(4);
+  // ---- frequency step ----
+  if constexpr (C::SPLIT_ROWS) stage3_rows<C, false, 1, 0>(t, gids, v);
+  freq_a<C>(t, gids, v, park);
+  if (t < 64) {  // wave 0: the bin pairs of the four self-paired groups, one pair per lane
+    wave_lds_sync();
+    StaticFor<0, C::ORBIT_ROUNDS>::run([&]<int R>() RPSF_AI { self_orbit<C>(t, R, ot, ko[2 * R], ko[2 * R + 1], tw, park); });
+    wave_lds_sync();
+  }
+  STAMP(5);
+  freq_b<C>(t, gids, v, k, g, tw, park);
+  if constexpr (C::SPLIT_ROWS) stage3_rows<C, true, 0, 0>(t, gids, v);
+  STAMP(6);
+  // ---- inverse ----
+  x2_last_write2<C, 0>(gids, v, lds);
+  if constexpr (C::SPLIT_ROWS) stage3_rows<C, true, 1, 0>(t, gids, v);
+  lds_barrier();
+  x2_mid_read2<C, 0>(t, v, lds);
+  lds_barrier();
+  x2_last_write2<C, 1>(gids, v, lds);
+  stage2h<C, 0, true>(t, v, tw);
+  lds_barrier();
+  x2_mid_read2<C, 1>(t, v, lds);
+  lds_barrier();  // X1 regions alias the X2 image
+  STAMP(7);
+  x1_write2<C, 0>(t, v, lds);
+  stage2h<C, 1, true>(t, v, tw);
+  wave_lds_sync();
+  x1_read2<C, 0>(t, v, lds);
+  x1_write2<C, 1>(t, v, lds);
+  STAMP(8);
+  stage1h<C, 0, true>(t, v, tw);
+  wave_lds_sync();
+  x1_read2<C, 1>(t, v, lds);
+  stage1h<C, 1, true>(t, v, tw);
+  STAMP(9);
+  // ---- overlap-add ----
+  const int plane = ov.plane_stride ? dsc.w : 0;
+  auto add = [](float* a, float val) { unsafeAtomicAdd(a, val); };
+  if (p.dv.out) {
+    OutView dv = p.dv;
+    dv.out += (size_t)frame * p.dv_frame_floats;
+    uint32_t qw[4];
+    direct_begin(p, frame, seq, qw, reinterpret_cast<uint32_t*>(park));
+    STAMP(10);
+    const float* dbase = dv.out;
+    const size_t dspan = ((size_t)(dv.rows - 1) * dv.ld + dv.W) * sizeof(float);
+    store_patch2<C>(
+        t, v, ov, dv, plane, pr, pc, win, qw, add, [=](const float* a) { return load16_sc1(dbase, dspan, a); },
+        [](const float* a) { return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); });
+    STAMP(11);
+    direct_end(p, frame, plane, qw);
+    STAMP(12);
+  } else {
+    store_patch2<C>(t, v, ov, ov, plane, pr, pc, win, nullptr, add, [](const float* a) { return *reinterpret_cast<const f32x4*>(a); },
+                    [](const float* a) { return *a; });
+  }
+  STAMP(13);
+}
+
+// K pack: the caller's full complex64 K (n, N, N) -> folded pair words in the stream layout [word][thread], plus the
+// side array of the self-paired bin pairs
+template <class C>
+__global__ void pack_kernel2(const cf* __restrict__ kfull, int n_patches, const uint16_t* __restrict__ tab,
+                             const uint32_t* __restrict__ ot, cf* __restrict__ g, cf* __restrict__ gs) {
+  const size_t per = (size_t)C::G_PER_PATCH + C::GS_PER_PATCH;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= per * n_patches) return;
+  const int patch = (int)(idx / per);
+  const int rem = (int)(idx % per);
+  const cf* kf = kfull + (size_t)patch * C::N * C::N;
+  if (rem < C::G_PER_PATCH) {
+    const int b = rem & 1, t = (rem >> 1) % C::T, w = (rem >> 1) / C::T;
+    g[(size_t)patch * C::G_PER_PATCH + rem] = pack_value2<C>(kf, tab, t, w, b);
+  } else {
+    const int r2 = rem - C::G_PER_PATCH;
+    gs[(size_t)patch * C::GS_PER_PATCH + r2] = pack_orbit2<C>(kf, tab, ot, r2 >> 1, r2 & 1);
+  }
+}

@@ -1,5 +1,5 @@
-"""Drive the kernel's per-thread phases (regularizepsf_amd/csrc/rpsf_core.hpp) on the CPU, thread by thread,
-and check the result against the reference goldens.  This pins the index algebra shared with the HIP
+"""Drive the kernel's per-thread phases (regularizepsf_amd/csrc/rpsf_core.hpp, and rpsf_core2.hpp for the
+second-generation 128/256-pixel plans) on the CPU, thread by thread, and check the result against the reference goldens.  This pins the index algebra shared with the HIP
 kernel (digit layouts, LDS addressing, slot table, packed-K format) without needing a GPU."""
 
 import ctypes
@@ -42,6 +42,42 @@ def test_emulated_kernel_matches_reference_golden(emu, case):
     vp = ctypes.c_void_p
     rc = emu.emu_apply(k.shape[1], len(coords), c.ctypes.data_as(vp), h, w, MODES[str(fx["pad_mode"])],
                        ctypes.c_float(0.0), image.ctypes.data_as(vp), kk.ctypes.data_as(vp), out.ctypes.data_as(vp))
+    assert rc == 0
+    rel_max, rel_l2 = rel_errors(out, fx["expected"])
+    assert rel_max <= 1e-5 and rel_l2 <= 1e-5, (rel_max, rel_l2)
+
+
+EMU2_SRC = ROOT / "tests" / "emu" / "emu2.cpp"
+EMU2_LIB = ROOT / "tests" / "emu" / "libemu2.so"
+CORE2 = ROOT / "regularizepsf_amd" / "csrc" / "rpsf_core2.hpp"
+
+
+@pytest.fixture(scope="module")
+def emu2():
+    if not EMU2_LIB.exists() or EMU2_LIB.stat().st_mtime < max(EMU2_SRC.stat().st_mtime, CORE.stat().st_mtime, CORE2.stat().st_mtime):
+        clang = "/opt/rocm/lib/llvm/bin/clang++"
+        if not pathlib.Path(clang).exists():
+            clang = shutil.which("clang++")
+        if clang is None:
+            pytest.skip("no clang++ to build the emulator")
+        subprocess.run([clang, "-std=c++20", "-O1", "-shared", "-fPIC", "-o", str(EMU2_LIB), str(EMU2_SRC)], check=True)
+    return ctypes.CDLL(str(EMU2_LIB))
+
+
+@pytest.mark.parametrize("direct", [0, 1])
+@pytest.mark.parametrize("case", [c[0] for c in APPLY_CASES if c[7] in MODES and c[3] >= 128])
+def test_emulated_second_generation_kernel_matches_reference_golden(emu2, case, direct):
+    """direct = 1: quadrant by quadrant, the first patch over a lattice tile stores and the later ones accumulate
+    (what the tile flags arrange on the GPU); direct = 0: plain adds into a cleared image."""
+    fx, coords, k = load_apply_case(case)
+    image = np.ascontiguousarray(fx["image"], np.float32)
+    h, w = image.shape
+    c = np.ascontiguousarray(np.array(coords, np.int32))
+    kk = np.ascontiguousarray(k, np.complex64)
+    out = np.zeros((h, w), np.float32)
+    vp = ctypes.c_void_p
+    rc = emu2.emu2_apply(k.shape[1], len(coords), c.ctypes.data_as(vp), h, w, MODES[str(fx["pad_mode"])],
+                         ctypes.c_float(0.0), image.ctypes.data_as(vp), kk.ctypes.data_as(vp), out.ctypes.data_as(vp), direct)
     assert rc == 0
     rel_max, rel_l2 = rel_errors(out, fx["expected"])
     assert rel_max <= 1e-5 and rel_l2 <= 1e-5, (rel_max, rel_l2)
