@@ -2,21 +2,22 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config 3] [--no-cpu]
 
-One "step" = one full apply (output clear + fused patch kernel) of the headline workload
-(BASELINE.json configs[2]: 4096x4096 image, 256x256 patches, 1089-patch lattice, coma PSF grid ->
-Gaussian target, alpha=3, eps=0.1) with image, output and packed transfer kernel resident in HBM.
-For N > 1 (launched by torch.distributed.run, one process per GPU) the image grows to (4096*N) x 4096
-and is split into N row bands of the patch lattice (weak scaling: per-GPU work is fixed).  The seam between
-two bands is handled without a data-path collective by default (`--seam recompute`: a band also runs the one
-lattice row above it that reaches into its rows, +3 % patches); `--seam exchange` sends the spill rows to the
-next rank with RCCL send/recv instead.  torch is used here only for the launcher's rendezvous: a gloo group
-broadcasts the 128-byte RCCL unique id; the compute path, the barrier/max-reduction around the timed region
-and the optional seam exchange are ctypes -> librpsf_hip.so (RCCL is loaded by the library itself).
+One "step" = one full device-resident apply (fused patch kernel + overlap-add) with image, output and packed transfer
+kernel resident in HBM.
+  N = 1: the headline workload, BASELINE.json configs[2]: 4096x4096 image, 256x256 patches, 1089-patch lattice, coma PSF
+         grid -> Gaussian target, alpha=3, eps=0.1.
+  N > 1 (launched by torch.distributed.run, one process per GPU): BASELINE.json configs[3], ONE 8192x8192 frame cut into
+         N row bands of the patch lattice (strong scaling); the rows a band's last lattice row spills into the next band are
+         sent to that rank with RCCL send/recv and added there, inside the timed region (`--seam exchange`, the default;
+         `--seam recompute` lets both neighbours compute the seam lattice row instead: no data-path collective).
+         `--weak` keeps the per-GPU work fixed instead (a (4096 N) x 4096 image of config 3's recipe).
+torch is used here only for the launcher's rendezvous: a gloo group broadcasts the 128-byte RCCL unique id; the compute
+path, the barrier/max-reduction around the timed region and the seam exchange are ctypes -> librpsf_hip.so (RCCL is loaded
+by the library itself).
 
 Before the W warm-up steps every rank keeps its GPU busy for `--prewarm-ms` (default 100 ms, untimed, local applies
-only): a freshly woken MI355X spends its first millisecond of work below steady clocks, which at K = 50 inflates the
-mean step by 6 % (0.274 vs 0.257 ms; with K = 500 both give 0.257 ms).  The timed region is unchanged: barrier +
-synchronise, exactly K steps, barrier + synchronise, maximum over ranks.
+only): a freshly woken MI355X spends its first millisecond of work below steady clocks.  The timed region is unchanged:
+barrier + synchronise, exactly K steps, barrier + synchronise, maximum over ranks.
 
 Prints ONE JSON line on rank 0 (see the "Measurement" section of DESIGN.md for every field).
 """
@@ -69,52 +70,67 @@ def emit_json(line: dict) -> None:
         os.write(_REAL_STDOUT, data)
 
 
-def cpu_baseline(image, coords, k, budget_s: float = 20.0):
-    """Time the CPU oracle (bit-identical restatement of the reference) on a bounded sample.
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
 
-    The sample is a top band of the SAME workload: the first lattice rows of patches, enough for
-    roughly `budget_s` seconds of work, applied to the image rows they cover, using every host core.
+    return platform.processor() or "unknown"
+
+
+def cpu_baseline(image, coords, k, budget_s: float = 25.0):
+    """Time the CPU oracle (bit-identical restatement of the reference) on the GPU box's host cores.
+
+    Two legs, each best of 3 after one warm-up run, on the same inputs as the GPU step:
+      * `workers = os.cpu_count()`: scipy.fft on every core; the sample is the whole frame if a probe says it fits the
+        budget, otherwise a top band of lattice rows (the first lattice rows of patches and the image rows they cover);
+      * `workers = None`, the reference's default (single-threaded FFTs), same rule.
     """
+    import numpy
+    import scipy
+
     from oracle import regpsf_oracle as orc
 
     n = k.shape[1]
     cores = os.cpu_count() or 1
     rows = sorted({r for r, _ in coords})
-    # probe one lattice row to size the sample
-    def band(last_row):
+
+    def band(n_rows):
+        last_row = rows[n_rows - 1]
         sel = [i for i, (r, _) in enumerate(coords) if r <= last_row]
         h = min(image.shape[0], last_row + n)
-        return sel, h
+        done_rows = h if n_rows == len(rows) else last_row + n // 2  # rows fully covered by the sampled lattice rows
+        return sel, h, done_rows
 
-    sel, h = band(rows[1])
-    t0 = time.perf_counter()
-    orc.apply_transfer(image[:h], [coords[i] for i in sel], k[sel], workers=cores)
-    probe = time.perf_counter() - t0
-    per_row = probe / 2
-    n_rows = int(max(2, min(len(rows), budget_s / max(per_row, 1e-3))))
-    sel, h = band(rows[n_rows - 1])
-    best = None
-    for _ in range(2):
+    def leg(workers):
+        sel, h, _ = band(2)
         t0 = time.perf_counter()
-        orc.apply_transfer(image[:h], [coords[i] for i in sel], k[sel], workers=cores)
-        dt = time.perf_counter() - t0
-        best = dt if best is None else min(best, dt)
-    # pixels corrected = rows fully covered by the sampled lattice rows
-    done_rows = h if n_rows == len(rows) else rows[n_rows - 1] + n // 2
-    mpix = done_rows * image.shape[1] / 1e6
-    # the reference's default (workers=None: single-threaded FFTs) on the two-lattice-row probe sample
-    sel1, h1 = band(rows[1])
-    t0 = time.perf_counter()
-    orc.apply_transfer(image[:h1], [coords[i] for i in sel1], k[sel1], workers=None)
-    single = time.perf_counter() - t0
-    single_rows = h1 if len(rows) == 2 else rows[1] + n // 2
+        orc.apply_transfer(image[:h], [coords[i] for i in sel], k[sel], workers=workers)
+        per_row = (time.perf_counter() - t0) / 2
+        n_rows = int(max(2, min(len(rows), (budget_s / 4) / max(per_row, 1e-3))))  # 1 warm-up + 3 timed runs in the budget
+        sel, h, done_rows = band(n_rows)
+        times = []
+        for _ in range(4):
+            t0 = time.perf_counter()
+            orc.apply_transfer(image[:h], [coords[i] for i in sel], k[sel], workers=workers)
+            times.append(time.perf_counter() - t0)
+        best = min(times[1:])
+        return done_rows * image.shape[1] / 1e6 / best, best, done_rows, len(sel)
+
+    v_all, t_all, rows_all, n_all = leg(cores)
+    v_one, t_one, rows_one, n_one = leg(None)
     return {
-        "value": round(mpix / best, 3), "unit": "Mpixels/s", "cores": cores, "kind": "port",
-        "sample": f"top {done_rows} of {image.shape[0]} image rows ({len(sel)} of {len(coords)} patches), "
-                  f"float64 NumPy/SciPy oracle, scipy.fft workers={cores}, best of 2, {best:.2f} s",
-        "single_thread_value": round(single_rows * image.shape[1] / 1e6 / single, 3),
-        "single_thread_sample": f"workers=None (the reference's default) on the top {single_rows} rows "
-                                f"({len(sel1)} patches), one run, {single:.2f} s",
+        "value": round(v_all, 3), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+        "sample": f"top {rows_all} of {image.shape[0]} image rows ({n_all} of {len(coords)} patches), float64 NumPy/SciPy oracle, "
+                  f"scipy.fft workers={cores}, best of 3 after 1 warm-up, {t_all:.2f} s",
+        "single_thread_value": round(v_one, 3),
+        "single_thread_sample": f"workers=None (the reference's default) on the top {rows_one} rows ({n_one} patches), "
+                                f"best of 3 after 1 warm-up, {t_one:.2f} s",
+        "cpu_model": cpu_model(), "numpy": numpy.__version__, "scipy": scipy.__version__,
     }
 
 
@@ -273,7 +289,9 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS))
+    ap.add_argument("--config", type=int, default=None, choices=sorted(CONFIGS),
+                    help="default: 3 (BASELINE headline) on one GPU, 4 (one 8192^2 frame, row bands, strong scaling) on several")
+    ap.add_argument("--weak", action="store_true", help="N > 1: grow the image with the ranks instead of cutting one frame")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--prewarm-ms", type=float, default=100.0,
                     help="untimed device activity before the W warm-up steps (clock ramp); 0 = off")
@@ -282,10 +300,10 @@ def main() -> None:
                          "multi-rank flow on a box with fewer GPUs than ranks")
     ap.add_argument("--verify", action="store_true", help="check every rank's owned rows against the CPU oracle")
     ap.add_argument("--frames", type=int, default=8, help="config 5: frames per GPU in one batch")
-    ap.add_argument("--seam", choices=["recompute", "exchange"], default="recompute",
-                    help="N > 1: 'recompute' - every band also runs the lattice row above it that reaches into its rows "
-                         "(no data-path collective, +3 %% patches); 'exchange' - the spill rows of a band are sent to the "
-                         "next rank with RCCL send/recv and added there")
+    ap.add_argument("--seam", choices=["recompute", "exchange"], default="exchange",
+                    help="N > 1: 'exchange' - the spill rows of a band are sent to the next rank with RCCL send/recv and added "
+                         "there (BASELINE's halo reduce); 'recompute' - every band also runs the lattice row above it that "
+                         "reaches into its rows (no data-path collective, more patches)")
     args = ap.parse_args()
     quiet_stdout()
 
@@ -294,13 +312,15 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         args.gpus = world
+    if args.config is None:
+        args.config = 3 if world == 1 or args.weak else 4
 
     from oracle import regpsf_oracle as orc  # synthetic inputs + cpu_baseline only
     from regularizepsf_amd import _native
     from regularizepsf_amd.sharding import ShardedApply
 
     h1, w, n, seed = CONFIGS[args.config]
-    strong = args.config == 4  # fixed 8192^2 frame cut into `world` bands; every other config grows with the ranks
+    strong = args.config == 4 or not args.weak  # one frame cut into `world` bands; --weak: the image grows with the ranks
     height = h1 if strong else h1 * world
     device = local_rank % max(1, _native.device_count()) if args.comm == "gloo" else local_rank
     pad = "symmetric"
@@ -394,13 +414,18 @@ def main() -> None:
         elapsed = comm.allreduce_max(elapsed)  # whole-job time = slowest rank
     ms_per_step = 1e3 * elapsed / args.steps
 
-    # ---------------- dominant-kernel roofline: HIP events on the plan's stream, live ----------------
+    # ---------------- roofline: HIP events on the plan's stream, live ----------------
+    # Algorithmic bytes: folded K read once (n N (N/2+1) complex64) + image read once + output written
+    # once, over the whole device-resident apply of this rank (patch kernel + everything the overlap-add needs).  With
+    # the plane sum fused into the patch launch (N = 256) the apply IS one launch of the dominant kernel.
     iters = max(20, min(args.steps, 200))
     total_ms, kernel_ms = plan.apply_device_timed(d_img.ptr, d_out.ptr, geom, iters)
-    kern_avg_ms = float(np.mean(kernel_ms))
+    kern_avg_ms, apply_avg_ms = float(np.mean(kernel_ms)), float(np.mean(total_ms))
     my_patches = plan.n_patches
-    alg_bytes = plan.transfer_bytes + band.image_rows * w * 4 + band.out_rows * w * 4  # K + image + output, once each
-    achieved = alg_bytes / (kern_avg_ms * 1e-3) / 1e9
+    alg_bytes = my_patches * n * (n // 2 + 1) * 8 + band.image_rows * w * 4 + band.out_rows * w * 4
+    step_ms = ms_per_step if world == 1 else apply_avg_ms  # one rank's apply; at N = 1 the wall-clock step itself
+    achieved = alg_bytes / (step_ms * 1e-3) / 1e9
+    achieved_kernel = alg_bytes / (kern_avg_ms * 1e-3) / 1e9
 
     if args.verify:  # every rank checks the rows it owns against the float64 oracle on the same inputs
         run_step()
@@ -442,10 +467,13 @@ def main() -> None:
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
             "frac_of_measured_copy_ceiling": round(achieved / MEASURED_COPY_GBS, 4),
-            "kernel": "patch_kernel", "kernel_avg_ms": round(kern_avg_ms, 4), "kernel_launches": iters,
-            "algorithmic_bytes": int(alg_bytes),
-            "bytes_model": "packed folded K read once + image read once + output written once (rank 0's band)",
-            "apply_avg_ms_events": round(float(np.mean(total_ms)), 4), "patches_this_rank": my_patches,
+            "kernel": "patch_kernel2" if n in (128, 256) else "patch_kernel",
+            "whole_apply_ms": round(step_ms, 4), "kernel_avg_ms": round(kern_avg_ms, 4), "kernel_launches": iters,
+            "frac_patch_kernel_only": round(achieved_kernel / HBM_PEAK_GBS, 4),
+            "algorithmic_bytes": int(alg_bytes), "packed_k_bytes": int(plan.transfer_bytes),
+            "bytes_model": "SURVEY 8d: folded K (n N (N/2+1) complex64) read once + image read once + output written once "
+                           "(rank 0's band), divided by the whole device-resident apply",
+            "apply_avg_ms_events": round(apply_avg_ms, 4), "patches_this_rank": my_patches,
         },
     }
     traffic_file = ROOT / "profiles" / "traffic_latest.json"

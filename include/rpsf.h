@@ -63,9 +63,13 @@ int rpsf_plan_set_transfer(rpsf_plan* plan, const float* k_c64_host);
 int rpsf_plan_set_transfer_device(rpsf_plan* plan, const void* k_c64_device);
 /* Overlap-add strategy (transform.py:167-169).  0 = automatic: on a regular half-overlap lattice of
  * corners (calculate_covering output) patches of equal lattice parity never overlap, so each patch
- * stores into one of four colour planes with plain coalesced stores and a small kernel sums the
- * planes in a fixed order (deterministic); any other corner list falls back to float atomics.
- * 1 = force atomics, 2 = force planes (error if the corners are not a lattice). */
+ * stores into one of four colour planes with plain coalesced stores and the planes are summed in a
+ * fixed order (deterministic) - inside the same launch for 256-pixel patches, by a small kernel
+ * otherwise; any other corner list falls back to float atomics.
+ * 1 = force atomics, 2 = force planes (error if the corners are not a lattice), 3 = direct: every
+ * lattice tile is accumulated in the output image itself, through the L2 of the XCD that runs most of
+ * its patches, in processing order (deterministic; 128- and 256-pixel patches on a lattice only;
+ * measured slower than the planes, kept for comparison). */
 int rpsf_plan_set_overlap_mode(rpsf_plan* plan, int mode);
 /* Start-up stagger of the patch kernel's first resident workgroups (microseconds, 0 = off): spreads
  * the gather / K-stream / store phases of different CUs in time so that HBM traffic overlaps compute. */
@@ -103,7 +107,11 @@ int rpsf_apply(rpsf_plan* plan, const float* image_host, int height, int width, 
 int rpsf_apply_host(rpsf_plan* plan, const void* image_host, int image_is_f64, int height, int width, int pad_mode,
                     float pad_value, void* out_host, int out_is_f64);
 /* Same with image and output already resident on the plan's device; asynchronous on `stream`
- * (a hipStream_t, or NULL for the plan's own stream).  The output rows are cleared first. */
+ * (a hipStream_t, or NULL for the plan's own stream).  Every pixel of the resident output rows is written
+ * (uncovered ones with 0).  image_dev / out_dev must be ordinary device memory of the plan's device
+ * (hipMalloc: coarse-grained) - the atomic overlap-add mode uses hardware float atomics, which
+ * fine-grained or host-mapped memory does not support.  A plan serves one apply at a time: a call on a
+ * different stream than the previous one waits for that one (the plan's scratch is shared). */
 int rpsf_apply_device(rpsf_plan* plan, const void* image_dev, void* out_dev, const rpsf_geometry* geom, void* stream);
 /* Run `iters` back-to-back device-resident applies on the plan's stream, timing each with HIP
  * events: total_ms[i] covers the whole apply (output clear + patch kernel), kernel_ms[i] the patch
@@ -169,6 +177,9 @@ void rpsf_comm_destroy(rpsf_comm* comm);
  * rank-1 (if any) into recv_dev, then add recv_dev[0:recv_count] into accum_dev.  Any count may be 0. */
 int rpsf_comm_seam_exchange_add(rpsf_comm* comm, const void* send_dev, size_t send_count, void* recv_dev,
                                 size_t recv_count, void* accum_dev, void* stream);
+/* accum_dev[0:count] += src_dev[0:count] (float32, on `device`, asynchronous on stream): the add of the seam
+ * exchange by itself, for callers that move the seam rows with their own transport. */
+int rpsf_add_rows(int device, void* accum_dev, const void* src_dev, size_t count, void* stream);
 int rpsf_comm_barrier(rpsf_comm* comm, void* stream);
 /* max over ranks of one double (used for whole-job timing) */
 int rpsf_comm_allreduce_max(rpsf_comm* comm, double* value);

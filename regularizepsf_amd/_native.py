@@ -83,6 +83,7 @@ _PROTOTYPES = {
     "rpsf_comm_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_void_p]),
     "rpsf_comm_destroy": (None, [c_void_p]),
     "rpsf_comm_seam_exchange_add": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "rpsf_add_rows": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rpsf_comm_barrier": (c_int, [c_void_p, c_void_p]),
     "rpsf_comm_allreduce_max": (c_int, [c_void_p, POINTER(c_double)]),
 }
@@ -331,6 +332,11 @@ def saturation_fill(padded: np.ndarray, mask: np.ndarray, neighborhood_width: in
         raise ValueError(msg)
     m = np.ascontiguousarray(mask, dtype=np.uint8)
     check(lib().rpsf_saturation_fill(_ptr(padded), padded.shape[0], padded.shape[1], _ptr(m), int(neighborhood_width)))
+
+
+def add_rows(accum_ptr: c_void_p, src_ptr: c_void_p, count: int, device: int = 0, stream: c_void_p | None = None) -> None:
+    """accum[0:count] += src[0:count] on the device (kernel K4: the add of the seam exchange)."""
+    check(lib().rpsf_add_rows(device, accum_ptr, src_ptr, count, stream))
 
 
 class Comm:

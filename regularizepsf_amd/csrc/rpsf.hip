@@ -56,6 +56,20 @@ static int fail(int code, const std::string& msg) {
 
 extern "C" const char* rpsf_last_error(void) { return g_err.c_str(); }
 
+// Device allocation that is freed on every exit path of the entry points that make temporaries
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() { (void)hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+  template <class T>
+  T* as() const { return static_cast<T*>(p); }
+  void* release() {
+    void* q = p;
+    p = nullptr;
+    return q;
+  }
+};
+
 
 // ------------------------------------------------------------------------------------------------
 // plan
@@ -85,6 +99,16 @@ struct rpsf_plan {
   bool lattice = false;
   bool direct_ok = false;  // lattice and one patch per workgroup
   bool v2 = false;         // second-generation kernel (rpsf_core2.hpp): N = 128, 256
+  // Fused plane sum (second-generation kernels, one frame, aligned geometry): the workgroups behind the patches in the
+  // grid sum a lattice tile as soon as all its contributors have published their (write-through) plane stores, so
+  // the sum runs on the CUs the partial last round leaves idle and no second kernel is needed.
+  uint32_t* d_tile_done = nullptr;   // per tile: contributors done, never reset (epoch * contributors after every apply)
+  uint32_t* d_sum_order = nullptr;   // all tiles, the ones whose contributors run first first
+  uint32_t done_epoch = 0;
+  uint32_t* d_sum_queue = nullptr;   // position in d_sum_order, never reset
+  uint32_t sum_queue_base = 0;
+  bool no_fuse = false;
+  bool fuse_pays = false;            // one workgroup per CU (N = 256): measured -5..6 % per apply; with four small ones per CU (N = 128) +3 %
   uint4* d_quads = nullptr;        // per processing-order slot: quadrant words (rpsf_core.hpp, store_patch_direct)
   uint8_t* d_tile_info = nullptr;  // per lattice tile: static side mask | 16 if any patch covers it
   uint32_t* d_flags = nullptr;     // per (frame, tile)
@@ -185,7 +209,8 @@ static int setup_lattice(rpsf_plan* p) {
     // four colours reach their store phase one after the other: a CU that ran a colour-0 patch frees first and is
     // handed the next run's colour-0 patch, so after the first run the colours stay staggered by one store phase
     // and a patch finds its overlapping predecessors (earlier in this order) already done.
-    const int run = std::max(4, p->round_capacity / 8);
+    int run = std::max(4, p->round_capacity / 8);
+    if (const char* e = std::getenv("RPSF_ORDER_RUN")) run = std::max(1, std::atoi(e));  // development: 1 = plain strips, large = colour by colour
     if (!std::getenv("RPSF_NO_COLOUR_RUNS"))
       for (int x = 0; x < 8; ++x) {
         const int lo = std::min(n, x * chunk), hi = std::min(n, lo + chunk);
@@ -252,6 +277,30 @@ static int setup_lattice(rpsf_plan* p) {
     }
   HIP_TRY(hipMalloc(&p->d_cover, cover.size()));
   HIP_TRY(hipMemcpy(p->d_cover, cover.data(), cover.size(), hipMemcpyHostToDevice));
+  if (p->v2) {  // fused plane sum: tile order (by the slot of the last contributor: the dispatch order inside a chunk) and counters
+    std::vector<std::pair<int, uint32_t>> keyed;
+    for (int ti = 0; ti < nti; ++ti)
+      for (int tj = 0; tj < ntj; ++tj) {
+        int last = -1;
+        for (int a2 = 0; a2 < 2; ++a2)
+          for (int b2 = 0; b2 < 2; ++b2) {
+            const int li = ti - a2, lj = tj - b2;
+            if (li < 0 || lj < 0 || li >= nli || lj >= nlj) continue;
+            const int i = cell[(size_t)li * nlj + lj];
+            if (i >= 0) last = std::max(last, seq_of[i] % chunk);
+          }
+        keyed.push_back({last, (uint32_t)(ti * ntj + tj)});
+      }
+    std::stable_sort(keyed.begin(), keyed.end(), [](const auto& a2, const auto& b2) { return a2.first < b2.first; });
+    std::vector<uint32_t> order(keyed.size());
+    for (size_t i = 0; i < keyed.size(); ++i) order[i] = keyed[i].second;
+    HIP_TRY(hipMalloc(&p->d_sum_order, order.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpy(p->d_sum_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&p->d_tile_done, order.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(p->d_tile_done, 0, order.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&p->d_sum_queue, sizeof(uint32_t)));
+    HIP_TRY(hipMemset(p->d_sum_queue, 0, sizeof(uint32_t)));
+  }
   if (p->direct_ok) {
     std::vector<uint4> quads(n);
     for (int s2 = 0; s2 < n; ++s2) {
@@ -304,25 +353,29 @@ template <class C>
 static int upload_tables(int device, uint16_t** d_tab, cf** d_tw, float** d_win, uint32_t** d_pairtab = nullptr) {
   std::vector<uint16_t> tab((size_t)C::T * C::NSLOT * 2);
   build_slot_table<C>(tab.data());
-  if (d_pairtab) {
-    std::vector<uint32_t> pt((size_t)C::PT_WORDS + 1);
-    if (build_pair_table<C>(tab.data(), pt.data()) > C::NP) return fail(RPSF_E_STATE, "pair table overflow (internal)");
-    HIP_TRY(hipSetDevice(device));
-    HIP_TRY(hipMalloc(d_pairtab, pt.size() * sizeof(uint32_t)));
-    HIP_TRY(hipMemcpy(*d_pairtab, pt.data(), pt.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-  }
+  std::vector<uint32_t> pt((size_t)C::PT_WORDS + 1);
+  if (d_pairtab && build_pair_table<C>(tab.data(), pt.data()) > C::NP) return fail(RPSF_E_STATE, "pair table overflow (internal)");
   std::vector<cf> tw;
   std::vector<float> win;
   host_tables(C::N, tw, win);
   HIP_TRY(hipSetDevice(device));
-  HIP_TRY(hipMalloc(d_tab, tab.size() * sizeof(uint16_t)));
-  HIP_TRY(hipMemcpy(*d_tab, tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-  HIP_TRY(hipMalloc(d_tw, tw.size() * sizeof(cf)));
-  HIP_TRY(hipMemcpy(*d_tw, tw.data(), tw.size() * sizeof(cf), hipMemcpyHostToDevice));
-  if (d_win) {
-    HIP_TRY(hipMalloc(d_win, win.size() * sizeof(float)));
-    HIP_TRY(hipMemcpy(*d_win, win.data(), win.size() * sizeof(float), hipMemcpyHostToDevice));
+  DevBuf b_pt, b_tab, b_tw, b_win;  // handed over only when everything has been uploaded: nothing leaks on an error
+  if (d_pairtab) {
+    HIP_TRY(b_pt.alloc(pt.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpy(b_pt.p, pt.data(), pt.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   }
+  HIP_TRY(b_tab.alloc(tab.size() * sizeof(uint16_t)));
+  HIP_TRY(hipMemcpy(b_tab.p, tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  HIP_TRY(b_tw.alloc(tw.size() * sizeof(cf)));
+  HIP_TRY(hipMemcpy(b_tw.p, tw.data(), tw.size() * sizeof(cf), hipMemcpyHostToDevice));
+  if (d_win) {
+    HIP_TRY(b_win.alloc(win.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(b_win.p, win.data(), win.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  if (d_pairtab) *d_pairtab = static_cast<uint32_t*>(b_pt.release());
+  *d_tab = static_cast<uint16_t*>(b_tab.release());
+  *d_tw = static_cast<cf*>(b_tw.release());
+  if (d_win) *d_win = static_cast<float*>(b_win.release());
   return RPSF_OK;
 }
 
@@ -337,14 +390,19 @@ static int upload_tables2(int device, uint16_t** d_tab, cf** d_tw, float** d_win
   std::vector<float> win;
   host_tables(C::N, tw, win);
   HIP_TRY(hipSetDevice(device));
-  HIP_TRY(hipMalloc(d_ot, ot.size() * sizeof(uint32_t)));
-  HIP_TRY(hipMemcpy(*d_ot, ot.data(), ot.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-  HIP_TRY(hipMalloc(d_tab, tab.size() * sizeof(uint16_t)));
-  HIP_TRY(hipMemcpy(*d_tab, tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-  HIP_TRY(hipMalloc(d_tw, tw.size() * sizeof(cf)));
-  HIP_TRY(hipMemcpy(*d_tw, tw.data(), tw.size() * sizeof(cf), hipMemcpyHostToDevice));
-  HIP_TRY(hipMalloc(d_win, win.size() * sizeof(float)));
-  HIP_TRY(hipMemcpy(*d_win, win.data(), win.size() * sizeof(float), hipMemcpyHostToDevice));
+  DevBuf b_ot, b_tab, b_tw, b_win;
+  HIP_TRY(b_ot.alloc(ot.size() * sizeof(uint32_t)));
+  HIP_TRY(hipMemcpy(b_ot.p, ot.data(), ot.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  HIP_TRY(b_tab.alloc(tab.size() * sizeof(uint16_t)));
+  HIP_TRY(hipMemcpy(b_tab.p, tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  HIP_TRY(b_tw.alloc(tw.size() * sizeof(cf)));
+  HIP_TRY(hipMemcpy(b_tw.p, tw.data(), tw.size() * sizeof(cf), hipMemcpyHostToDevice));
+  HIP_TRY(b_win.alloc(win.size() * sizeof(float)));
+  HIP_TRY(hipMemcpy(b_win.p, win.data(), win.size() * sizeof(float), hipMemcpyHostToDevice));
+  *d_ot = static_cast<uint32_t*>(b_ot.release());
+  *d_tab = static_cast<uint16_t*>(b_tab.release());
+  *d_tw = static_cast<cf*>(b_tw.release());
+  *d_win = static_cast<float*>(b_win.release());
   return RPSF_OK;
 }
 
@@ -466,6 +524,8 @@ extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int
     HIP_TRY(hipMemset(p->d_stamps, 0, sizeof(unsigned long long) * 16 * (size_t)n_patches));
 #endif
     p->v2 = has_v2(N);
+    p->no_fuse = std::getenv("RPSF_NO_FUSE") != nullptr;
+    p->fuse_pays = N >= 256 || std::getenv("RPSF_FUSE_ALWAYS") != nullptr;
     int rl = p->v2 ? dispatch_v2(N, [&]<class C>() -> int {
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_kernel2<C>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)Launch2<C>::LDS_BYTES));
@@ -548,6 +608,9 @@ extern "C" void rpsf_plan_destroy(rpsf_plan* p) {
   (void)hipFree(p->d_flags);
   (void)hipFree(p->d_dyn);
   (void)hipFree(p->d_chunk_xcc);
+  (void)hipFree(p->d_tile_done);
+  (void)hipFree(p->d_sum_order);
+  (void)hipFree(p->d_sum_queue);
   if (p->ev_busy) (void)hipEventDestroy(p->ev_busy);
   (void)hipHostFree(p->h_pin_in);
   (void)hipHostFree(p->h_pin_out);
@@ -592,8 +655,9 @@ extern "C" int rpsf_plan_set_transfer(rpsf_plan* p, const float* k_host) {
   }
   int chunk = (int)std::max<size_t>(1, (size_t)(64u << 20) / (per * sizeof(cf)));
   if (chunk > p->n_patches) chunk = p->n_patches;
-  cf* d_tmp = nullptr;
-  HIP_TRY(hipMalloc(&d_tmp, per * sizeof(cf) * chunk));
+  DevBuf b_tmp;
+  HIP_TRY(b_tmp.alloc(per * sizeof(cf) * chunk));
+  cf* d_tmp = b_tmp.as<cf>();
   int rc = RPSF_OK;
   for (int first = 0; first < p->n_patches && rc == RPSF_OK; first += chunk) {
     int cnt = std::min(chunk, p->n_patches - first);
@@ -606,7 +670,6 @@ extern "C" int rpsf_plan_set_transfer(rpsf_plan* p, const float* k_host) {
       if (e != hipSuccess) rc = fail(RPSF_E_HIP, hipGetErrorString(e));
     }
   }
-  (void)hipFree(d_tmp);
   if (rc == RPSF_OK) p->have_k = true;
   return rc;
 }
@@ -676,8 +739,9 @@ struct Batch {
 
 enum OverlapKind { OV_ATOMIC = 0, OV_PLANES = 1, OV_DIRECT = 2 };
 
+// fused: the plane sum runs in this launch (see rpsf_plan::d_tile_done)
 static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const rpsf_geometry& g, OverlapKind kind,
-                          hipStream_t st, Batch b = Batch()) {
+                          hipStream_t st, Batch b = Batch(), bool fused = false) {
   auto fill = [&](PatchParams& pp, int teams) {
     const int count = p->n_patches;
     pp.im = ImageView{d_img, g.height, g.width, g.ld_image, g.pad_mode, g.pad_value, g.image_row0, g.image_rows};
@@ -706,8 +770,24 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
       PatchParams pp{};
       fill(pp, 1);
       pp.stagger_blocks = p->round_capacity;
-      const size_t blocks = (size_t)8 * pp.chunk * b.frames;
+      size_t blocks = (size_t)8 * pp.chunk * b.frames;
       if (blocks > 0x7fffffffu) return fail(RPSF_E_BADARG, "batch too large for one launch");
+      pp.slot0 = 0, pp.patch_blocks = (int)blocks;
+      if (fused) {
+        const int n_tiles = p->nti * p->ntj;
+        pp.tile_done = p->d_tile_done, pp.quads = p->d_quads, pp.n_tiles = (uint32_t)n_tiles;
+        TileSum& ts = pp.ts;
+        ts.planes = p->d_planes, ts.plane_stride = p->planes_floats, ts.ld_planes = g.width;
+        ts.out = d_out, ts.ld_out = g.ld_out;
+        ts.rows = g.out_rows, ts.W = g.width, ts.row0 = g.out_row0;
+        ts.lat_r0 = p->lat_r0 + g.origin_row, ts.lat_c0 = p->lat_c0 + g.origin_col, ts.half = p->N / 2, ts.ntj = p->ntj;
+        ts.cover = p->d_cover, ts.tiles = p->d_sum_order, ts.count = n_tiles;
+        ts.done = p->d_tile_done, ts.epoch = p->done_epoch;
+        const int nsum = std::max(8, std::min(n_tiles, p->round_capacity));  // as many summing workgroups as the chip holds
+        ts.queue = p->d_sum_queue, ts.queue_base = p->sum_queue_base;
+        p->sum_queue_base += (uint32_t)(n_tiles + nsum);  // every workgroup draws one position past the end
+        blocks += (size_t)nsum;
+      }
       patch_kernel2<C><<<dim3((unsigned)blocks), dim3(Launch2<C>::WG), Launch2<C>::LDS_BYTES, st>>>(pp);
       HIP_TRY(hipGetLastError());
       return RPSF_OK;
@@ -859,11 +939,26 @@ static int launch_apply(rpsf_plan* p, const float* d_img, float* d_out, const rp
     for (int f = 0; f < b.frames; ++f)
       HIP_TRY(hipMemset2DAsync(d_out + (size_t)f * b.out_stride, (size_t)g.ld_out * sizeof(float), 0,
                                (size_t)g.width * sizeof(float), g.out_rows, st));
+  // Fused plane sum: one frame, every plane line written whole by one store instruction (see sum_tile)
+  const long tile_r0 = (long)p->lat_r0 + g.origin_row, tile_c0 = (long)p->lat_c0 + g.origin_col;
+  const bool fused = kind == OV_PLANES && p->v2 && p->fuse_pays && p->d_tile_done && !p->no_fuse && b.frames == 1 && g.width % 32 == 0 &&
+                     g.ld_out % 4 == 0 && tile_c0 % 32 == 0 && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0;
+  if (fused) {
+    if (++p->done_epoch >= (1u << 29)) {  // the counters hold epoch * contributors
+      HIP_TRY(hipMemsetAsync(p->d_tile_done, 0, (size_t)p->nti * p->ntj * sizeof(uint32_t), st));
+      p->done_epoch = 1;
+    }
+    // the tile sums write lattice tiles only: pixels of the window outside the tile grid are cleared here
+    const int half = p->N / 2;
+    if (tile_r0 > g.out_row0 || tile_r0 + (long)p->nti * half < (long)g.out_row0 + g.out_rows || tile_c0 > 0 ||
+        tile_c0 + (long)p->ntj * half < g.width)
+      HIP_TRY(hipMemset2DAsync(d_out, (size_t)g.ld_out * sizeof(float), 0, (size_t)g.width * sizeof(float), g.out_rows, st));
+  }
   if (ev_k0) HIP_TRY(hipEventRecord(ev_k0, st));
-  int rc = launch_patches(p, d_img, d_out, g, kind, st, b);
+  int rc = launch_patches(p, d_img, d_out, g, kind, st, b, fused);
   if (rc != RPSF_OK) return rc;
   if (ev_k1) HIP_TRY(hipEventRecord(ev_k1, st));
-  if (kind == OV_PLANES) rc = launch_sum(p, d_out, g, 0, g.out_rows, st, b);
+  if (kind == OV_PLANES && !fused) rc = launch_sum(p, d_out, g, 0, g.out_rows, st, b);
   if (kind == OV_DIRECT) rc = launch_fixup(p, d_out, g, st, b);
   if (rc != RPSF_OK) return rc;
   HIP_TRY(hipEventRecord(p->ev_busy, st));
@@ -1181,10 +1276,11 @@ extern "C" int rpsf_build_transfer(int device, size_t count, const void* s_host,
   HIP_TRY(hipSetDevice(device));
   const size_t esz = is_f64 ? 16 : 8;
   const size_t chunk = std::min<size_t>(count, (size_t)8 << 20);  // 8 Mi elements per round
-  char *ds = nullptr, *dt = nullptr, *dk = nullptr;
-  HIP_TRY(hipMalloc(&ds, chunk * esz));
-  HIP_TRY(hipMalloc(&dt, chunk * esz));
-  HIP_TRY(hipMalloc(&dk, chunk * esz));
+  DevBuf bs, bt, bk;
+  HIP_TRY(bs.alloc(chunk * esz));
+  HIP_TRY(bt.alloc(chunk * esz));
+  HIP_TRY(bk.alloc(chunk * esz));
+  char *ds = bs.as<char>(), *dt = bt.as<char>(), *dk = bk.as<char>();
   int rc = RPSF_OK;
   for (size_t first = 0; first < count && rc == RPSF_OK; first += chunk) {
     size_t cnt = std::min(chunk, count - first);
@@ -1196,9 +1292,6 @@ extern "C" int rpsf_build_transfer(int device, size_t count, const void* s_host,
     e = hipMemcpy((char*)k_host + first * esz, dk, cnt * esz, hipMemcpyDeviceToHost);
     if (e != hipSuccess) rc = fail(RPSF_E_HIP, hipGetErrorString(e));
   }
-  (void)hipFree(ds);
-  (void)hipFree(dt);
-  (void)hipFree(dk);
   return rc;
 }
 
@@ -1214,13 +1307,15 @@ extern "C" int rpsf_psf_fft(int device, int patch_size, int count, const float* 
     cf* d_tw = nullptr;
     int rc = upload_tables<C>(device, &d_tab, &d_tw, nullptr);
     if (rc != RPSF_OK) return rc;
+    DevBuf keep_tab, keep_tw, b_in, b_out;
+    keep_tab.p = d_tab, keep_tw.p = d_tw;
     const size_t per = (size_t)C::N * C::N;
     int chunk = (int)std::max<size_t>(1, (size_t)(64u << 20) / (per * sizeof(cf)));
     if (chunk > count) chunk = count;
-    float* d_in = nullptr;
-    cf* d_out = nullptr;
-    HIP_TRY(hipMalloc(&d_in, per * sizeof(float) * chunk));
-    HIP_TRY(hipMalloc(&d_out, per * sizeof(cf) * chunk));
+    HIP_TRY(b_in.alloc(per * sizeof(float) * chunk));
+    HIP_TRY(b_out.alloc(per * sizeof(cf) * chunk));
+    float* d_in = b_in.as<float>();
+    cf* d_out = b_out.as<cf>();
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&psf_fft_kernel<C>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)Launch<C>::LDS_BYTES));
     for (int first = 0; first < count && rc == RPSF_OK; first += chunk) {
@@ -1235,10 +1330,6 @@ extern "C" int rpsf_psf_fft(int device, int patch_size, int count, const float* 
         e = hipMemcpy(reinterpret_cast<cf*>(fft_host) + (size_t)first * per, d_out, per * sizeof(cf) * cnt, hipMemcpyDeviceToHost);
       if (e != hipSuccess) rc = fail(RPSF_E_HIP, hipGetErrorString(e));
     }
-    (void)hipFree(d_in);
-    (void)hipFree(d_out);
-    (void)hipFree(d_tab);
-    (void)hipFree(d_tw);
     return rc;
   });
 }
@@ -1428,14 +1519,21 @@ extern "C" int rpsf_comm_seam_exchange_add(rpsf_comm* c, const void* send_dev, s
     if (do_recv) NCCL_TRY(g_rccl.recv(recv_dev, recv_count, 7, c->rank - 1, c->comm, st));
     NCCL_TRY(g_rccl.group_end());
   }
-  if (do_recv) {
-    if (!accum_dev) return fail(RPSF_E_BADARG, "accum_dev is null");
-    int block = 256;
-    size_t grid = ((recv_count + 3) / 4 + block - 1) / block;
-    add_rows_kernel<<<dim3((unsigned)grid), dim3(block), 0, st>>>(reinterpret_cast<float*>(accum_dev),
-                                                                 reinterpret_cast<const float*>(recv_dev), recv_count);
-    HIP_TRY(hipGetLastError());
-  }
+  if (do_recv) return rpsf_add_rows(c->device, accum_dev, recv_dev, recv_count, st);
+  return RPSF_OK;
+}
+
+// accum[0:count] += src[0:count] on `device` (kernel K4; the add of the seam exchange, exported for callers that move
+// the seam rows themselves)
+extern "C" int rpsf_add_rows(int device, void* accum_dev, const void* src_dev, size_t count, void* stream) {
+  if (!accum_dev || !src_dev) return fail(RPSF_E_BADARG, "null argument");
+  if (count == 0) return RPSF_OK;
+  HIP_TRY(hipSetDevice(device));
+  const int block = 256;
+  const size_t grid = ((count + 3) / 4 + block - 1) / block;
+  add_rows_kernel<<<dim3((unsigned)grid), dim3(block), 0, reinterpret_cast<hipStream_t>(stream)>>>(
+      reinterpret_cast<float*>(accum_dev), reinterpret_cast<const float*>(src_dev), count);
+  HIP_TRY(hipGetLastError());
   return RPSF_OK;
 }
 

@@ -338,6 +338,11 @@ RPSF_HD void stage3_cols(cf* v) {
 template <class C, int CI>
 RPSF_HD void load_k_chunk2(int t, cf* k, const cf* __restrict__ g) {
   StaticFor<0, C::KCH>::run([&]<int I>() RPSF_AI {
+#if defined(RPSF2_ABL_NOK)
+    k[2 * I] = cf{1.0f + (float)I, 0.5f};
+    k[2 * I + 1] = cf{0.25f, (float)t};
+    return;
+#endif
     load_stream16(g + ((size_t)(CI * C::KCH + I) * C::T + t) * 2, k[2 * I], k[2 * I + 1]);
   });
 }
@@ -509,11 +514,15 @@ RPSF_HD void load_patch2(int t, cf* v, const ImageView& im, int pr, int pc, cons
 // Overlap-add of the finished patch.  qw: the four quadrant words of rpsf_core.hpp (store_patch_direct) or nullptr:
 //   nullptr + pv.plane_stride != 0: every pixel into colour plane `plane` (streaming stores);
 //   nullptr + pv.plane_stride == 0: float atomics into pv.out (ADD);
-//   else: QUAD_DIRECT quadrants into dv.out (accumulating onto what is there when QUAD_ACC is set, read with LOAD4 /
+//   else: QUAD_DIRECT quadrants into dv.out (accumulating onto what is there when QUAD_ACC is set, read with LOAD4
+//   - called as load4<R1, C1>(address) for unit (R1, C1), so that a caller may have prefetched the values - /
 //   LOAD1 = L1-bypassing loads), QUAD_SIDE quadrants into the colour plane.
-template <class C, class ADD, class LOAD4, class LOAD1>
+// PSTORE4 / PSTORE1: 16- and 4-byte stores into the colour plane (streaming, or write-through when the plane sum runs
+// in the same launch).
+template <class C, class ADD, class LOAD4, class LOAD1, class PSTORE4, class PSTORE1>
 RPSF_HD void store_patch2(int t, const cf* v, const OutView& pv, const OutView& dv, int plane, int pr, int pc,
-                          const float* __restrict__ win, const uint32_t* qw, ADD&& add, LOAD4&& load4, LOAD1&& load1) {
+                          const float* __restrict__ win, const uint32_t* qw, ADD&& add, LOAD4&& load4, LOAD1&& load1,
+                          PSTORE4&& pstore4, PSTORE1&& pstore1) {
   ThreadPos2<C> tp(t);
   constexpr int NR = 1 << C::A1, NCOL = 1 << C::B1;
   const bool planes = pv.plane_stride != 0;
@@ -531,7 +540,7 @@ RPSF_HD void store_patch2(int t, const cf* v, const OutView& pv, const OutView& 
         old[U] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (qw && quad_mode(qw[QD]) == QUAD_DIRECT && (qw[QD] & QUAD_ACC)) {
           const int r = (R1 << (C::A2 + C::AL)) + tp.r_low, cp = (C1 << C::B2) + tp.c2;
-          old[U] = load4(drow0 + (size_t)r * dv.ld + 4 * cp);
+          old[U] = load4.template operator()<R1, C1>(drow0 + (size_t)r * dv.ld + 4 * cp);
         }
       });
       StaticFor<0, BATCH * NCOL>::run([&]<int U>() RPSF_AI {
@@ -542,11 +551,7 @@ RPSF_HD void store_patch2(int t, const cf* v, const OutView& pv, const OutView& 
         const cf a = v[2 * (R1 * NCOL + C1)], b = v[2 * (R1 * NCOL + C1) + 1];
         f32x4 val = {a.x * (w4.x * wr), a.y * (w4.y * wr), b.x * (w4.z * wr), b.y * (w4.w * wr)};
         if (!qw || quad_mode(qw[QD]) == QUAD_SIDE) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(RPSF_NO_NT)
-          __builtin_nontemporal_store(val, reinterpret_cast<f32x4*>(prow0 + (size_t)r * pv.ld + 4 * cp));
-#else
-          *reinterpret_cast<f32x4*>(prow0 + (size_t)r * pv.ld + 4 * cp) = val;
-#endif
+          pstore4(prow0 + (size_t)r * pv.ld + 4 * cp, val);
         } else if (quad_mode(qw[QD]) == QUAD_DIRECT) {
           val += old[U];
           *reinterpret_cast<f32x4*>(drow0 + (size_t)r * dv.ld + 4 * cp) = val;
@@ -571,12 +576,12 @@ RPSF_HD void store_patch2(int t, const cf* v, const OutView& pv, const OutView& 
           const float val = px[I] * (wr * win[4 * cp + I]);
           if (!qw) {
             float* dst = pbase + (size_t)yl * pv.ld + x;
-            if (planes) *dst = val; else add(dst, val);
+            if (planes) pstore1(dst, val); else add(dst, val);
           } else if (quad_mode(qw[QD]) == QUAD_DIRECT) {
             float* dst = dv.out + (size_t)(y - dv.row0) * dv.ld + x;
             *dst = ((qw[QD] & QUAD_ACC) ? load1(dst) : 0.f) + val;
           } else if (quad_mode(qw[QD]) == QUAD_SIDE) {
-            pbase[(size_t)yl * pv.ld + x] = val;
+            pstore1(pbase + (size_t)yl * pv.ld + x, val);
           }
         });
       });

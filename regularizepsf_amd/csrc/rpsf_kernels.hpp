@@ -7,6 +7,127 @@
 #pragma once
 
 // ------------------------------------------------------------------------------------------------
+// Colour-plane sum by lattice tile.  out_tile = sum of the planes that have a patch over the tile (4-bit cover mask,
+// fixed colour order: deterministic); a tile nobody covers is zeroed.  Used tile-list by tile-list: the tiles whose
+// contributors have all finished are summed by the CUs the partial last round of patches leaves idle (same launch as
+// those patches), the remaining ones by a small kernel afterwards.
+// ------------------------------------------------------------------------------------------------
+struct TileSum {
+  const float* planes;
+  size_t plane_stride;
+  int ld_planes;
+  float* out;
+  int ld_out;
+  int rows, W, row0;         // resident output window
+  int lat_r0, lat_c0, half;  // full-image coordinates of lattice tile (0, 0); tile edge
+  int ntj;
+  const uint8_t* cover;      // per tile: 4-bit colour mask
+  const uint32_t* tiles;     // the list
+  int count;
+  // fused with the patch launch: a tile is summed once its done counter has reached epoch * (number of contributors);
+  // done == nullptr: the planes are complete (separate launch)
+  const uint32_t* done;
+  uint32_t epoch;
+  uint32_t* queue;           // fused: next position in the list (never reset: this launch owns [queue_base, queue_base + count))
+  uint32_t queue_base;
+};
+
+// 16-byte plane accesses of the fused mode: write-through stores and L1-bypassing loads (agent scope), so that a
+// workgroup on another XCD reads what the patch workgroups wrote (MI355X_MICROARCH.md, inter-workgroup visibility).
+// Raw buffer accesses, so that the compiler tracks them; a descriptor spans up to 4 GiB from `base`.
+typedef float rpsf_f4 __attribute__((ext_vector_type(4)));
+typedef int rpsf_i4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const float* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, -1, 0x00020000);
+}
+__device__ __forceinline__ rpsf_f4 plane_load16_wt(__amdgpu_buffer_rsrc_t r, size_t float_offset) {
+  const rpsf_i4 q = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(float_offset * sizeof(float)), 0, /*sc1 | nt*/ 16 | 2);
+  return rpsf_f4{__int_as_float(q.x), __int_as_float(q.y), __int_as_float(q.z), __int_as_float(q.w)};
+}
+__device__ __forceinline__ void plane_store16_wt(__amdgpu_buffer_rsrc_t r, size_t float_offset, rpsf_f4 v) {
+  const rpsf_i4 q = {__float_as_int(v.x), __float_as_int(v.y), __float_as_int(v.z), __float_as_int(v.w)};
+  __builtin_amdgcn_raw_buffer_store_b128(q, r, (int)(float_offset * sizeof(float)), 0, /*sc1 | nt*/ 16 | 2);
+}
+
+__device__ __forceinline__ void sum_tile(const TileSum& p, uint32_t tile, int tid, int nthreads) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int ti = tile / p.ntj, tj = tile % p.ntj;
+  const int cov = p.cover[tile];
+  const bool fused = p.done != nullptr;
+  if (fused) {  // wait until every contributor of the tile has published its stores
+    if (tid == 0) {
+      const uint32_t want = p.epoch * (uint32_t)__builtin_popcount(cov & 15);
+      while (__hip_atomic_load(p.done + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) __builtin_amdgcn_s_sleep(4);
+    }
+    __syncthreads();
+  }
+  const int y0 = max(p.lat_r0 + ti * p.half, p.row0), y1 = min(p.lat_r0 + (ti + 1) * p.half, p.row0 + p.rows);
+  const int x0 = max(p.lat_c0 + tj * p.half, 0), x1 = min(p.lat_c0 + (tj + 1) * p.half, p.W);
+  if (y0 >= y1 || x0 >= x1) return;
+  const bool vec = ((x0 | x1 | p.ld_planes | p.ld_out) & 3) == 0 && (p.plane_stride & 3) == 0 &&
+                   ((reinterpret_cast<uintptr_t>(p.planes) | reinterpret_cast<uintptr_t>(p.out)) & 15) == 0;
+  if (vec) {
+    const __amdgpu_buffer_rsrc_t rsrc = plane_rsrc(p.planes);
+    const int gw = (x1 - x0) >> 2, total = gw * (y1 - y0);
+    constexpr int UN = 4;  // groups in flight per thread: 16 sixteen-byte loads
+    for (int i0 = tid; i0 < total; i0 += UN * nthreads) {
+      f4 v[UN][4];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int i = min(i0 + u * nthreads, total - 1);
+        const size_t off = (size_t)(y0 + i / gw - p.row0) * p.ld_planes + x0 + ((i % gw) << 2);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {  // unconditional loads (redirected to plane 0's line when unused) so that they overlap
+          const size_t o = ((cov >> k) & 1) ? off + k * p.plane_stride : off;
+          v[u][k] = fused ? plane_load16_wt(rsrc, o) : __builtin_nontemporal_load(reinterpret_cast<const f4*>(p.planes + o));
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int i = i0 + u * nthreads;
+        if (i >= total) break;
+        f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if ((cov >> k) & 1) acc += v[u][k];
+        __builtin_nontemporal_store(acc, reinterpret_cast<f4*>(p.out + (size_t)(y0 + i / gw - p.row0) * p.ld_out + x0 + ((i % gw) << 2)));
+      }
+    }
+  } else {
+    const int w = x1 - x0, total = w * (y1 - y0);
+    for (int i = tid; i < total; i += nthreads) {
+      const size_t yl = (size_t)(y0 + i / w - p.row0);
+      const int x = x0 + i % w;
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if ((cov >> k) & 1) {
+          const float* src = p.planes + k * p.plane_stride + yl * p.ld_planes + x;
+          acc += fused ? __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(src), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : *src;
+        }
+      p.out[yl * p.ld_out + x] = acc;
+    }
+  }
+}
+// workgroup `block` of `nblocks` co-operating ones works through the list: in fixed strides, or - fused mode, where the
+// workgroups start at different times (most while the last patches still run, the rest after them) - from a queue
+__device__ __forceinline__ void sum_tiles_worker(const TileSum& p, int block, int nblocks) {
+  if (!p.queue) {
+    for (int i = block; i < p.count; i += nblocks) sum_tile(p, p.tiles[i], threadIdx.x, blockDim.x);
+    return;
+  }
+  __shared__ uint32_t next;
+  for (;;) {
+    if (threadIdx.x == 0) next = __hip_atomic_fetch_add(p.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.queue_base;
+    __syncthreads();
+    const uint32_t i = next;
+    __syncthreads();
+    if (i >= (uint32_t)p.count) return;
+    sum_tile(p, p.tiles[i], threadIdx.x, blockDim.x);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K1
 // ------------------------------------------------------------------------------------------------
 struct PatchParams {
@@ -17,6 +138,10 @@ struct PatchParams {
                             // (one 16-byte load instead of the order -> coords -> plane pointer chase)
   int chunk;                // patches per XCD chunk
   int seq_base;             // first processing-order slot of this launch
+  int slot0;                // first slot of every chunk this launch covers (the apply may be cut into a main and a tail launch)
+  int patch_blocks;         // workgroups [0, patch_blocks) process patches; the ones beyond sum colour-plane tiles
+  TileSum ts;               // ... of this list
+  uint32_t* tile_done;      // fused plane sum: per (frame, tile) count of contributors whose plane stores are complete (nullptr: off)
   unsigned long long* stamps;  // diagnostic builds (RPSF_STAMPS): 16 phase timestamps per patch
   int stagger_ticks;        // start-up stagger of the first resident workgroups, in 10 ns ticks (0 = off)
   int stagger_blocks;       // how many leading blocks are staggered (= resident workgroup capacity)
@@ -425,6 +550,8 @@ __global__ __launch_bounds__(Launch<C>::WG) void psf_fft_kernel(const float* __r
 
 
 #if defined(RPSF_HOST_TU)
+__global__ __launch_bounds__(256) void sum_tiles_kernel(TileSum p) { sum_tiles_worker(p, blockIdx.x, gridDim.x); }
+
 // ------------------------------------------------------------------------------------------------
 // K5: out = sum of the colour planes that have a patch over the pixel (fixed order: deterministic)
 // ------------------------------------------------------------------------------------------------

@@ -20,12 +20,36 @@ __device__ __forceinline__ f32x4 load16_sc1(const float* base, size_t span_bytes
   return f32x4{__int_as_float(q.x), __int_as_float(q.y), __int_as_float(q.z), __int_as_float(q.w)};
 }
 
+// Development-only timing ablations (results are wrong; never set by regularizepsf_amd/build.py):
+//   RPSF2_ABL_NOGATHER / _NOK / _NOSTORE: no pixel loads / no K loads / no output stores;
+//   RPSF2_ABL_NOLDS: no LDS exchanges (barriers stay); RPSF2_ABL_NOBAR: no workgroup barriers either;
+//   RPSF2_ABL_NOVALU: no butterflies and no pair operations.
+#if defined(RPSF2_ABL_NOLDS)
+#define ABL_LDS(...) ((void)0)
+#else
+#define ABL_LDS(...) __VA_ARGS__
+#endif
+#if defined(RPSF2_ABL_NOVALU)
+#define ABL_VALU(...) ((void)0)
+#else
+#define ABL_VALU(...) __VA_ARGS__
+#endif
+#if defined(RPSF2_ABL_NOBAR)
+#define ABL_BAR() ((void)0)
+#else
+#define ABL_BAR() lds_barrier()
+#endif
+
 template <class C>
 __global__ __launch_bounds__(Launch2<C>::WG, 2) void patch_kernel2(PatchParams p) {  // 2 waves per SIMD: 256 registers
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int T = C::T, N = C::N;
   const int t = threadIdx.x;
-  int frame = 0, xrow = blockIdx.x >> 3;
+  if ((int)blockIdx.x >= p.patch_blocks) {  // workgroup-uniform: a CU the partial last round leaves idle sums finished tiles
+    sum_tiles_worker(p.ts, blockIdx.x - p.patch_blocks, gridDim.x - p.patch_blocks);
+    return;
+  }
+  int frame = 0, xrow = p.slot0 + (blockIdx.x >> 3);
   if (p.n_frames > 1) {
     frame = xrow % p.n_frames;
     xrow /= p.n_frames;
@@ -69,7 +93,12 @@ __global__ __launch_bounds__(Launch2<C>::WG, 2) void patch_kernel2(PatchParams p
     build_pad_maps<C>(t, maps, im, pr, pc);
     lds_barrier();
   }
+#if defined(RPSF2_ABL_NOGATHER)
+#pragma unroll
+  for (int j = 0; j < 64; ++j) v[j] = cf{(float)(t + j), (float)(t - j)};
+#else
   load_raw2<C>(t, v, im, pr, pc, fast, maps);
+#endif
   if (t < N) tw[t] = tw0, win[t] = wn0;
   if (t + T < N) tw[t + T] = tw1, win[t + T] = wn1;
   if (t < Launch2<C>::OT_WORDS) ot[t] = ot0;
@@ -77,75 +106,101 @@ __global__ __launch_bounds__(Launch2<C>::WG, 2) void patch_kernel2(PatchParams p
   window_patch2<C>(t, v, win);
   STAMP(1);
   // ---- forward: the halves leapfrog through stage 1, X1 (wave-local) and stage 2 ----
-  stage1h<C, 0, false>(t, v, tw);
-  x1_write2<C, 0>(t, v, lds);
-  stage1h<C, 1, false>(t, v, tw);
+  ABL_VALU(stage1h<C, 0, false>(t, v, tw));
+  ABL_LDS(x1_write2<C, 0>(t, v, lds));
+  ABL_VALU(stage1h<C, 1, false>(t, v, tw));
   wave_lds_sync();
-  x1_read2<C, 0>(t, v, lds);
-  x1_write2<C, 1>(t, v, lds);  // (a wave's DS operations complete in order: these writes cannot overtake the reads)
+  ABL_LDS(x1_read2<C, 0>(t, v, lds));
+  ABL_LDS(x1_write2<C, 1>(t, v, lds));  // (a wave's DS operations complete in order: these writes cannot overtake the reads)
   STAMP(2);
-  stage2h<C, 0, false>(t, v, tw);
+  ABL_VALU(stage2h<C, 0, false>(t, v, tw));
   wave_lds_sync();
-  x1_read2<C, 1>(t, v, lds);
+  ABL_LDS(x1_read2<C, 1>(t, v, lds));
   STAMP(3);
   cf k[2 * C::KCH];
+#if defined(RPSF2_ABL_NOK)
+#pragma unroll
+  for (int j = 0; j < 2 * C::KCH; ++j) k[j] = cf{1.0f + j, 0.5f * t};
+#else
   load_k_chunk2<C, 0>(t, k, g);  // in flight across the exchange below (raw barriers do not drain VMEM)
+#endif
   cf ko[2 * C::ORBIT_ROUNDS];
   if (t < 64) {
     const cf* gs = p.gs + (size_t)patch * C::GS_PER_PATCH;
     StaticFor<0, C::ORBIT_ROUNDS>::run([&]<int R>() RPSF_AI { load_stream16(gs + (size_t)(R * 64 + t) * 2, ko[2 * R], ko[2 * R + 1]); });
   }
-  lds_barrier();  // every wave has left its X1 region (X2 uses the whole buffer)
-  x2_mid_write2<C, 0>(t, v, lds);
-  stage2h<C, 1, false>(t, v, tw);
-  lds_barrier();
-  x2_last_read2<C, 0>(gids, v, lds);
-  lds_barrier();
-  x2_mid_write2<C, 1>(t, v, lds);
-  if constexpr (C::SPLIT_ROWS) stage3_rows<C, false, 0, 0>(t, gids, v);  // the row DFTs of the half that has arrived, under the exchange of the other
-  lds_barrier();
-  x2_last_read2<C, 1>(gids, v, lds);
+  ABL_BAR();  // every wave has left its X1 region (X2 uses the whole buffer)
+  ABL_LDS(x2_mid_write2<C, 0>(t, v, lds));
+  ABL_VALU(stage2h<C, 1, false>(t, v, tw));
+  ABL_BAR();
+  ABL_LDS(x2_last_read2<C, 0>(gids, v, lds));
+  ABL_BAR();
+  ABL_LDS(x2_mid_write2<C, 1>(t, v, lds));
+  if constexpr (C::SPLIT_ROWS) ABL_VALU(stage3_rows<C, false, 0, 0>(t, gids, v));  // the row DFTs of the half that has arrived, under the exchange of the other
+  ABL_BAR();
+  ABL_LDS(x2_last_read2<C, 1>(gids, v, lds));
   // no barrier: every X2 unit is read by exactly one thread, the same one that rewrites it below
   STAMP(4);
   // ---- frequency step ----
-  if constexpr (C::SPLIT_ROWS) stage3_rows<C, false, 1, 0>(t, gids, v);
-  freq_a<C>(t, gids, v, park);
+  if constexpr (C::SPLIT_ROWS) ABL_VALU(stage3_rows<C, false, 1, 0>(t, gids, v));
+  ABL_VALU(freq_a<C>(t, gids, v, park));
   if (t < 64) {  // wave 0: the bin pairs of the four self-paired groups, one pair per lane
     wave_lds_sync();
     StaticFor<0, C::ORBIT_ROUNDS>::run([&]<int R>() RPSF_AI { self_orbit<C>(t, R, ot, ko[2 * R], ko[2 * R + 1], tw, park); });
     wave_lds_sync();
   }
   STAMP(5);
+#if defined(RPSF2_ABL_NOVALU)
+  StaticFor<1, C::NCHUNK>::run([&]<int CI>() RPSF_AI {  // keep the K stream: every chunk is requested and consumed
+    cf acc = k[0];
+    StaticFor<1, 2 * C::KCH>::run([&]<int I>() RPSF_AI { acc = acc + k[I]; });
+    v[CI] = v[CI] + acc;
+    load_k_chunk2<C, CI>(t, k, g);
+  });
+  v[0] = v[0] + k[0] + k[15];
+#else
   freq_b<C>(t, gids, v, k, g, tw, park);
-  if constexpr (C::SPLIT_ROWS) stage3_rows<C, true, 0, 0>(t, gids, v);
+#endif
+  if constexpr (C::SPLIT_ROWS) ABL_VALU(stage3_rows<C, true, 0, 0>(t, gids, v));
   STAMP(6);
   // ---- inverse ----
-  x2_last_write2<C, 0>(gids, v, lds);
-  if constexpr (C::SPLIT_ROWS) stage3_rows<C, true, 1, 0>(t, gids, v);
-  lds_barrier();
-  x2_mid_read2<C, 0>(t, v, lds);
-  lds_barrier();
-  x2_last_write2<C, 1>(gids, v, lds);
-  stage2h<C, 0, true>(t, v, tw);
-  lds_barrier();
-  x2_mid_read2<C, 1>(t, v, lds);
-  lds_barrier();  // X1 regions alias the X2 image
+  ABL_LDS(x2_last_write2<C, 0>(gids, v, lds));
+  if constexpr (C::SPLIT_ROWS) ABL_VALU(stage3_rows<C, true, 1, 0>(t, gids, v));
+  ABL_BAR();
+  ABL_LDS(x2_mid_read2<C, 0>(t, v, lds));
+  ABL_BAR();
+  ABL_LDS(x2_last_write2<C, 1>(gids, v, lds));
+  ABL_VALU(stage2h<C, 0, true>(t, v, tw));
+  ABL_BAR();
+  ABL_LDS(x2_mid_read2<C, 1>(t, v, lds));
+  ABL_BAR();  // X1 regions alias the X2 image
   STAMP(7);
-  x1_write2<C, 0>(t, v, lds);
-  stage2h<C, 1, true>(t, v, tw);
+  ABL_LDS(x1_write2<C, 0>(t, v, lds));
+  ABL_VALU(stage2h<C, 1, true>(t, v, tw));
   wave_lds_sync();
-  x1_read2<C, 0>(t, v, lds);
-  x1_write2<C, 1>(t, v, lds);
+  ABL_LDS(x1_read2<C, 0>(t, v, lds));
+  ABL_LDS(x1_write2<C, 1>(t, v, lds));
   STAMP(8);
-  stage1h<C, 0, true>(t, v, tw);
+  ABL_VALU(stage1h<C, 0, true>(t, v, tw));
   wave_lds_sync();
-  x1_read2<C, 1>(t, v, lds);
-  stage1h<C, 1, true>(t, v, tw);
+  ABL_LDS(x1_read2<C, 1>(t, v, lds));
+  ABL_VALU(stage1h<C, 1, true>(t, v, tw));
   STAMP(9);
   // ---- overlap-add ----
+#if defined(RPSF2_ABL_NOSTORE)
+  {  // keep every value live but store (almost) nothing
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) acc += v[j].x * v[j].y;
+    if (acc == 123456.789f) ov.out[threadIdx.x] = acc;
+    return;
+  }
+#endif
   const int plane = ov.plane_stride ? dsc.w : 0;
   auto add = [](float* a, float val) { unsafeAtomicAdd(a, val); };
-  if (p.dv.out) {
+  auto pstore4 = [](float* a, f32x4 val) RPSF_AI { __builtin_nontemporal_store(val, reinterpret_cast<f32x4*>(a)); };
+  auto pstore1 = [](float* a, float val) RPSF_AI { *a = val; };
+  if (p.dv.out) {  // direct overlap-add (opt-in; moves as many bytes as the planes do and waits on top - DESIGN.md)
     OutView dv = p.dv;
     dv.out += (size_t)frame * p.dv_frame_floats;
     uint32_t qw[4];
@@ -154,14 +209,33 @@ __global__ __launch_bounds__(Launch2<C>::WG, 2) void patch_kernel2(PatchParams p
     const float* dbase = dv.out;
     const size_t dspan = ((size_t)(dv.rows - 1) * dv.ld + dv.W) * sizeof(float);
     store_patch2<C>(
-        t, v, ov, dv, plane, pr, pc, win, qw, add, [=](const float* a) { return load16_sc1(dbase, dspan, a); },
-        [](const float* a) { return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); });
+        t, v, ov, dv, plane, pr, pc, win, qw, add, [=]<int R1, int C1>(const float* a) RPSF_AI { return load16_sc1(dbase, dspan, a); },
+        [](const float* a) { return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); },
+        pstore4, pstore1);
     STAMP(11);
     direct_end(p, frame, plane, qw);
     STAMP(12);
+  } else if (p.tile_done) {
+    // Plane sum fused into this launch: the plane stores are write-through, and once they have drained the patch is
+    // counted on its four tiles; the workgroups behind the patches in the grid sum a tile as soon as its count is complete.
+    const float* pbase = ov.out;
+    const __amdgpu_buffer_rsrc_t rsrc = plane_rsrc(pbase);
+    store_patch2<C>(
+        t, v, ov, ov, plane, pr, pc, win, nullptr, add, []<int R1, int C1>(const float* a) RPSF_AI { return *reinterpret_cast<const f32x4*>(a); },
+        [](const float* a) { return *a; }, [=](float* a, f32x4 val) RPSF_AI { plane_store16_wt(rsrc, (size_t)(a - pbase), val); },
+        [](float* a, float val) RPSF_AI { __hip_atomic_store(reinterpret_cast<unsigned*>(a), __float_as_uint(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); });
+    STAMP(10);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    if (t < 4) {
+      const uint4 q4 = p.quads[p.seq_base + seq];
+      const uint32_t w = t == 0 ? q4.x : t == 1 ? q4.y : t == 2 ? q4.z : q4.w;
+      __hip_atomic_fetch_add(p.tile_done + (size_t)frame * p.n_tiles + quad_tile(w), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    STAMP(12);
   } else {
-    store_patch2<C>(t, v, ov, ov, plane, pr, pc, win, nullptr, add, [](const float* a) { return *reinterpret_cast<const f32x4*>(a); },
-                    [](const float* a) { return *a; });
+    store_patch2<C>(t, v, ov, ov, plane, pr, pc, win, nullptr, add, []<int R1, int C1>(const float* a) RPSF_AI { return *reinterpret_cast<const f32x4*>(a); },
+                    [](const float* a) { return *a; }, pstore4, pstore1);
   }
   STAMP(13);
 }

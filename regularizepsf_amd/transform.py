@@ -8,15 +8,36 @@ arithmetic inside the kernels; patch sizes other than 16..256 powers of two run 
 
 from __future__ import annotations
 
+import hashlib
 import math
 import numbers
 import pathlib
+import threading
 
 import numpy as np
 
 from regularizepsf_amd import _native
 from regularizepsf_amd.exceptions import InvalidCoordinateError
 from regularizepsf_amd.util import IndexedCube
+
+
+def _kernel_stamp(cube: IndexedCube) -> tuple:
+    """What the device copy of a transfer kernel was made from: identity, edit count and a fingerprint of the values.
+
+    The reference multiplies by ``values`` as they are at every ``apply`` (transform.py:164), and ``IndexedCube`` does not
+    copy them, so a caller may edit the array in place between two applies.  ``__setitem__`` is counted exactly; edits that
+    bypass it (``cube.values[i] = ...``, ``k *= 2``) are caught by hashing an evenly strided sample of about 64 K
+    elements (every patch of a 256-pixel cube contributes ~60 of them; 0.2 ms).  An edit confined to elements between
+    two samples is not seen - call :meth:`ArrayPSFTransform.invalidate` after such surgical edits.
+    """
+    values = cube.values
+    if values.flags.c_contiguous or values.flags.f_contiguous:
+        flat = values.reshape(-1, order="A")
+        sample = flat[:: max(1, flat.size // 65536)]
+    else:  # strided views are rare and small: hash everything
+        sample = np.ascontiguousarray(values)
+    digest = hashlib.blake2b(sample.tobytes(), digest_size=8).digest()
+    return (id(values), cube._edits, values.shape, values.dtype.str, digest)
 
 
 class ArrayPSFTransform:
@@ -28,6 +49,8 @@ class ArrayPSFTransform:
         self._plan: _native.Plan | None = None
         self._plan_stamp: tuple | None = None
         self._corner_bounds: tuple | None = None
+        # one device plan (staging buffers, colour planes, one stream) per transform: calls from several threads take turns
+        self._lock = threading.RLock()
 
     # ------------------------------------------------------------------ accessors (transform.py:37-51)
     @property
@@ -88,15 +111,17 @@ class ArrayPSFTransform:
                 b.free()
         cube = IndexedCube(source.coordinates, kernel)
         out = cls(cube, device=device)
-        out._plan, out._plan_stamp = plan, (id(cube.values), cube._edits, len(cube))
+        out._plan, out._plan_stamp = plan, _kernel_stamp(cube)
         return out
 
     # ------------------------------------------------------------------ device plan
     def invalidate(self) -> None:
-        """Drop the device copy of the transfer kernel (call after editing ``values`` in place)."""
-        if self._plan is not None:
-            self._plan.close()
-        self._plan, self._plan_stamp = None, None
+        """Drop the device copy of the transfer kernel.  Edits of ``values`` are noticed by themselves (see
+        ``_kernel_stamp``) except single-element ones that fall between the fingerprint's samples: call this after those."""
+        with self._lock:
+            if self._plan is not None:
+                self._plan.close()
+            self._plan, self._plan_stamp = None, None
 
     def _checked_patch_size(self) -> int:
         n0, n1 = self.psf_shape
@@ -110,7 +135,7 @@ class ArrayPSFTransform:
 
     def _device_plan(self) -> _native.Plan:
         cube = self._transfer_kernel
-        stamp = (id(cube.values), cube._edits, len(cube))
+        stamp = _kernel_stamp(cube)
         if self._plan is None or self._plan_stamp != stamp:
             self.invalidate()
             n = self._checked_patch_size()
@@ -147,6 +172,10 @@ class ArrayPSFTransform:
         on the GPU).  The input is never modified.
         """
         del workers
+        with self._lock:
+            return self._apply_locked(image, pad_mode, saturation_threshold, saturation_dilation, neighborhood_width)
+
+    def _apply_locked(self, image, pad_mode, saturation_threshold, saturation_dilation, neighborhood_width) -> np.ndarray:
         image = np.asarray(image)
         if image.ndim != 2:
             msg = f"image must be two dimensional, got shape {image.shape}"
@@ -216,6 +245,12 @@ class ArrayPSFTransform:
         ``dtype`` is the result dtype (the reference returns float64; ``np.float32`` skips the conversion).
         Extension of the reference API - there is no ``apply_batch`` upstream.
         """
+        with self._lock:
+            return self._apply_batch_locked(images, workers, pad_mode, saturation_threshold, saturation_dilation,
+                                            neighborhood_width, dtype)
+
+    def _apply_batch_locked(self, images, workers, pad_mode, saturation_threshold, saturation_dilation, neighborhood_width,
+                            dtype) -> np.ndarray:
         images = np.asarray(images)
         if images.ndim != 3:
             msg = f"images must have shape (frames, H, W), got {images.shape}"

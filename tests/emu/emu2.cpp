@@ -38,8 +38,10 @@ static int emu2_apply_t(int n_patches, const int32_t* coords, int H, int W, int 
   OutView ov{out, H, W, W, 0, H, 0, sink.data()};
   memset(out, 0, sizeof(float) * (size_t)H * W);
   auto add = [](float* p, float v) { *p += v; };
-  auto load4 = [](const float* p) { return *reinterpret_cast<const f32x4*>(p); };
+  auto load4 = []<int R1, int C1>(const float* p) { return *reinterpret_cast<const f32x4*>(p); };
   auto load1 = [](const float* p) { return *p; };
+  auto pstore4 = [](float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; };
+  auto pstore1 = [](float* p, float v) { *p = v; };
   std::vector<int> maps(2 * N);
   cf* park = lds.data() + C::BUF_UNITS;
   std::vector<uint8_t> touched;  // direct mode: which quadrant tiles of the output have been initialised (by N/2 tiles from the first corner)
@@ -99,7 +101,7 @@ static int emu2_apply_t(int n_patches, const int32_t* coords, int H, int W, int 
     for (int t = 0; t < T; ++t) x1_read2<C, 1>(t, R(t), lds.data());
     for (int t = 0; t < T; ++t) stage1h<C, 1, true>(t, R(t), tw.data());
     if (!direct) {
-      for (int t = 0; t < T; ++t) store_patch2<C>(t, R(t), ov, ov, 0, pr, pc, win.data(), nullptr, add, load4, load1);
+      for (int t = 0; t < T; ++t) store_patch2<C>(t, R(t), ov, ov, 0, pr, pc, win.data(), nullptr, add, load4, load1, pstore4, pstore1);
     } else {
       // direct stores, sequential: the first patch over a tile stores, later ones accumulate (the flags' job on the GPU);
       // tiles are indexed from the first patch corner (the caller passes a lattice)
@@ -112,7 +114,7 @@ static int emu2_apply_t(int n_patches, const int32_t* coords, int H, int W, int 
         qw[q] = quad_word(QUAD_DIRECT, 0, 0) | (seen ? QUAD_ACC : 0u);
         seen = 1;
       }
-      for (int t = 0; t < T; ++t) store_patch2<C>(t, R(t), ov, ov, 0, pr, pc, win.data(), qw, add, load4, load1);
+      for (int t = 0; t < T; ++t) store_patch2<C>(t, R(t), ov, ov, 0, pr, pc, win.data(), qw, add, load4, load1, pstore4, pstore1);
     }
   }
   return 0;

@@ -52,8 +52,31 @@ def sha(a: np.ndarray) -> str:
 from tests.helpers import APPLY_CASES, make_psfs  # noqa: E402
 
 
+def complex128_case(util, psf, transform) -> None:
+    """(v) the reference's own precision end to end: float64 PSFs give a complex128 K, and apply multiplies in complex128
+    (transform.py:164).  The GPU path rounds K to complex64 when it is uploaded; this pins that rounding against a
+    reference result that never saw it."""
+    h, w, n, alpha, eps, seed = 160, 200, 64, 3.0, 0.1, 51
+    coords = [tuple(int(v) for v in t) for t in util.calculate_covering((h, w), n)]
+    src, tgt = make_psfs("coma", coords, n, h, w)
+    s = psf.ArrayPSF(util.IndexedCube(coords, src))
+    t = psf.ArrayPSF(util.IndexedCube(coords, tgt))
+    tr = transform.ArrayPSFTransform.construct(s, t, alpha, eps)
+    k = tr._transfer_kernel.values
+    assert k.dtype == np.complex128 and np.isfinite(k).all()
+    image = orc.starfield(h, w, seed)
+    expected = tr.apply(image)
+    np.savez_compressed(HERE / "apply_c128_n64.npz", image=image, coords=np.array(coords, np.int64), expected=expected,
+                        k_sha256=np.array(sha(k)), meta=np.array([h, w, n]), alpha=np.array(alpha), eps=np.array(eps),
+                        seed=np.array(seed))
+    print("c128_n64", len(coords), expected.shape, float(np.abs(expected).max()))
+
+
 def main() -> None:
     util, psf, transform = load_reference()
+    if "--only-c128" in sys.argv:  # added in round 2: leaves the other fixtures byte for byte as they are
+        complex128_case(util, psf, transform)
+        return
 
     # (i) calculate_covering, including order
     cov = {}
@@ -132,6 +155,7 @@ def main() -> None:
         sat[f"expected_d{dil}_w{nbw}"] = tr.apply(image, saturation_threshold=10, saturation_dilation=dil,
                                                    neighborhood_width=nbw)
     np.savez_compressed(HERE / "apply_saturation.npz", image=image, coords=np.array(coords, np.int64), **sat)
+    complex128_case(util, psf, transform)
     print("done")
 
 

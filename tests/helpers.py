@@ -67,3 +67,14 @@ def rel_errors(out: np.ndarray, ref: np.ndarray) -> tuple[float, float]:
     """(max|d| / max|ref|, ||d||2 / ||ref||2): the parity metric of SURVEY.md 8d."""
     d = out.astype(np.float64) - ref.astype(np.float64)
     return float(np.abs(d).max() / np.abs(ref).max()), float(np.linalg.norm(d) / np.linalg.norm(ref))
+
+
+def load_c128_case():
+    """The complex128 fixture (tests/golden/make_golden.py, case v): (fixture, coords, K complex128 rebuilt with the oracle)."""
+    fx = np.load(GOLDEN / "apply_c128_n64.npz")
+    h, w, n = (int(v) for v in fx["meta"])
+    coords = [tuple(int(v) for v in t) for t in fx["coords"]]
+    src, tgt = make_psfs("coma", coords, n, h, w)
+    k = orc.construct_transfer(orc.psf_fft(src), orc.psf_fft(tgt), float(fx["alpha"]), float(fx["eps"]))
+    assert k.dtype == np.complex128 and sha(k) == str(fx["k_sha256"]), "oracle construct differs from the reference (complex128 case)"
+    return fx, coords, k

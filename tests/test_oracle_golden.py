@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import regpsf_oracle as orc
-from tests.helpers import APPLY_CASES, GOLDEN, load_apply_case, make_psfs
+from tests.helpers import APPLY_CASES, GOLDEN, load_apply_case, load_c128_case, make_psfs
 
 
 def test_covering_matches_reference_including_order():
@@ -78,3 +78,10 @@ def test_apply_saturation_matches_reference():
                                      saturation_dilation=dil, neighborhood_width=nbw)
         assert np.array_equal(out, fx[f"expected_d{dil}_w{nbw}"], equal_nan=True)
         assert out[80, 80] == 100
+
+
+def test_apply_with_complex128_kernel_bit_identical_to_reference():
+    """float64 PSFs -> complex128 K, multiplied in complex128 (transform.py:164): the reference's own precision end to end."""
+    fx, coords, k = load_c128_case()
+    out = orc.apply_transfer(fx["image"], coords, k)
+    assert np.array_equal(out, fx["expected"])

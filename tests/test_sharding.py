@@ -134,3 +134,28 @@ def test_seam_exchange_world_size_2_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert results[0] < 1e-9 and results[1] < 1e-9
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_band_plan_of_config4(world):
+    """BASELINE.json configs[3]: 8192^2 / 256-px patches (65 lattice rows of 65 patches) cut into `world` row bands - what
+    `bench.py --gpus N` runs for N > 1.  Whole lattice rows per band, every patch in exactly one band, 128 spill rows
+    (N/2) from each band to the next, owned rows tiling the image."""
+    import numpy as np
+
+    from regularizepsf_amd.sharding import make_band_plans
+    from regularizepsf_amd.util import calculate_covering
+
+    coords = [tuple(int(v) for v in t) for t in calculate_covering((8192, 8192), 256)]
+    plans = make_band_plans(coords, 256, 8192, world)
+    counts = [len(b.patch_index) for b in plans]
+    assert sum(counts) == 4225 and all(c % 65 == 0 for c in counts)
+    assert max(counts) - min(counts) <= 65
+    assert sorted(i for b in plans for i in b.patch_index) == list(range(4225))
+    assert [b.send_rows for b in plans] == [128] * (world - 1) + [0]
+    assert [b.recv_rows for b in plans] == [0] + [128] * (world - 1)
+    assert sum(b.own_rows for b in plans) == 8192
+    assert [b.out_row0 for b in plans] == list(np.cumsum([0] + [b.own_rows for b in plans[:-1]]))
+    recompute = make_band_plans(coords, 256, 8192, world, seam="recompute")
+    assert all(b.send_rows == 0 and b.recv_rows == 0 and b.out_rows == b.own_rows for b in recompute)
+    assert sum(len(b.patch_index) for b in recompute) == 4225 + 65 * (world - 1)  # one shared lattice row per seam
