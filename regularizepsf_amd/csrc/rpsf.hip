@@ -108,6 +108,7 @@ struct rpsf_plan {
   uint32_t* d_sum_queue = nullptr;   // position in d_sum_order, never reset
   uint32_t sum_queue_base = 0;
   bool no_fuse = false;
+  int sum_first = 0;                 // summing workgroups that run beside the patches from the start (multiple of 8: one per XCD)
   bool fuse_pays = false;            // one workgroup per CU (N = 256): measured -5..6 % per apply; with four small ones per CU (N = 128) +3 %
   uint4* d_quads = nullptr;        // per processing-order slot: quadrant words (rpsf_core.hpp, store_patch_direct)
   uint8_t* d_tile_info = nullptr;  // per lattice tile: static side mask | 16 if any patch covers it
@@ -525,6 +526,9 @@ extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int
 #endif
     p->v2 = has_v2(N);
     p->no_fuse = std::getenv("RPSF_NO_FUSE") != nullptr;
+    // (measured, profiles/r02u, r02v: 32 of them are worth -1 % at 4096^2 and -2.5 % at 8192^2; 48 cost more patch time than they hide)
+    p->sum_first = n_patches >= 2 * 256 ? 32 : 0;
+    if (const char* e = std::getenv("RPSF_SUM_FIRST")) p->sum_first = std::max(0, std::atoi(e)) / 8 * 8;
     p->fuse_pays = N >= 256 || std::getenv("RPSF_FUSE_ALWAYS") != nullptr;
     int rl = p->v2 ? dispatch_v2(N, [&]<class C>() -> int {
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_kernel2<C>),
@@ -783,7 +787,9 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
         ts.lat_r0 = p->lat_r0 + g.origin_row, ts.lat_c0 = p->lat_c0 + g.origin_col, ts.half = p->N / 2, ts.ntj = p->ntj;
         ts.cover = p->d_cover, ts.tiles = p->d_sum_order, ts.count = n_tiles;
         ts.done = p->d_tile_done, ts.epoch = p->done_epoch;
-        const int nsum = std::max(8, std::min(n_tiles, p->round_capacity));  // as many summing workgroups as the chip holds
+        int nsum = std::max(8, std::min(n_tiles, p->round_capacity));  // at the tail: as many summing workgroups as the chip holds
+        pp.sum_first = p->sum_first;
+        nsum += pp.sum_first;
         ts.queue = p->d_sum_queue, ts.queue_base = p->sum_queue_base;
         p->sum_queue_base += (uint32_t)(n_tiles + nsum);  // every workgroup draws one position past the end
         blocks += (size_t)nsum;

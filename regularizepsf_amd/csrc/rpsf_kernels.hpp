@@ -69,7 +69,7 @@ __device__ __forceinline__ void sum_tile(const TileSum& p, uint32_t tile, int ti
   if (vec) {
     const __amdgpu_buffer_rsrc_t rsrc = plane_rsrc(p.planes);
     const int gw = (x1 - x0) >> 2, total = gw * (y1 - y0);
-    constexpr int UN = 4;  // groups in flight per thread: 16 sixteen-byte loads
+    constexpr int UN = 8;  // groups in flight per thread: 32 sixteen-byte loads - a whole tile per pass for the patch kernels' workgroup sizes
     for (int i0 = tid; i0 < total; i0 += UN * nthreads) {
       f4 v[UN][4];
 #pragma unroll
@@ -139,7 +139,8 @@ struct PatchParams {
   int chunk;                // patches per XCD chunk
   int seq_base;             // first processing-order slot of this launch
   int slot0;                // first slot of every chunk this launch covers (the apply may be cut into a main and a tail launch)
-  int patch_blocks;         // workgroups [0, patch_blocks) process patches; the ones beyond sum colour-plane tiles
+  int sum_first;            // fused plane sum: workgroups [0, sum_first) sum tiles beside the patches for the whole launch,
+  int patch_blocks;         // [sum_first, sum_first + patch_blocks) process patches, the ones beyond sum tiles again
   TileSum ts;               // ... of this list
   uint32_t* tile_done;      // fused plane sum: per (frame, tile) count of contributors whose plane stores are complete (nullptr: off)
   unsigned long long* stamps;  // diagnostic builds (RPSF_STAMPS): 16 phase timestamps per patch

@@ -45,16 +45,20 @@ __global__ __launch_bounds__(Launch2<C>::WG, 2) void patch_kernel2(PatchParams p
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int T = C::T, N = C::N;
   const int t = threadIdx.x;
-  if ((int)blockIdx.x >= p.patch_blocks) {  // workgroup-uniform: a CU the partial last round leaves idle sums finished tiles
-    sum_tiles_worker(p.ts, blockIdx.x - p.patch_blocks, gridDim.x - p.patch_blocks);
+  // Fused plane sum: a few workgroups at the head of the grid sum finished tiles beside the patches for the whole
+  // launch (the patches leave half of the HBM bandwidth unused), the ones at its tail take the CUs the partial last
+  // round of patches leaves idle.  All of them draw tiles from one queue.
+  const int pb = (int)blockIdx.x - p.sum_first;  // workgroup-uniform
+  if (pb < 0 || pb >= p.patch_blocks) {
+    sum_tiles_worker(p.ts, 0, 1);
     return;
   }
-  int frame = 0, xrow = p.slot0 + (blockIdx.x >> 3);
+  int frame = 0, xrow = p.slot0 + (pb >> 3);
   if (p.n_frames > 1) {
     frame = xrow % p.n_frames;
     xrow /= p.n_frames;
   }
-  const int seq = (blockIdx.x & 7) * p.chunk + xrow;
+  const int seq = (pb & 7) * p.chunk + xrow;
   if (xrow >= p.chunk || seq >= p.n_patches) return;  // workgroup-uniform
   ImageView im = p.im;
   OutView ov = p.ov;
@@ -65,9 +69,9 @@ __global__ __launch_bounds__(Launch2<C>::WG, 2) void patch_kernel2(PatchParams p
   // Start-up stagger.  The workgroups of one round move in lock step otherwise - all CUs stream K at one moment, store at
   // another, and the memory system alternates between idle and saturated.  The first resident workgroup of each CU is
   // held back by a different fraction of stagger_ticks (later workgroups inherit the offset of the one they replace).
-  if (p.stagger_ticks > 0 && (int)blockIdx.x < p.stagger_blocks) {
+  if (p.stagger_ticks > 0 && pb < p.stagger_blocks) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    const unsigned long long wait = (unsigned long long)(((blockIdx.x >> 3) * 0x9E3779B1u >> 22) & 1023) * p.stagger_ticks >> 10;
+    const unsigned long long wait = (unsigned long long)((((unsigned)pb >> 3) * 0x9E3779B1u >> 22) & 1023) * p.stagger_ticks >> 10;
     while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
   }
   STAMP(0);
