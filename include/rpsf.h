@@ -152,6 +152,10 @@ int rpsf_build_transfer_device(int device, size_t count, const void* s_dev, cons
 /* Batched un-shifted 2-D FFT of real PSF cubes (ArrayPSF.__init__, psf.py:216-219), float32 in,
  * complex64 out, (count, N, N) host arrays. */
 int rpsf_psf_fft(int device, int patch_size, int count, const float* values_host, float* fft_c64_host);
+/* Same, leaving the spectra on the device (count * N * N complex64 at fft_c64_dev, allocated by the caller): the input
+ * of rpsf_build_transfer_device, so that ArrayPSF -> construct (psf.py:216-219 -> transform.py:78-82) -> apply never
+ * moves a spectrum or K over PCIe. */
+int rpsf_psf_fft_device(int device, int patch_size, int count, const float* values_host, void* fft_c64_dev);
 
 /* Host-side helper for the saturation branch of apply (transform.py:135-138): sequential, row-major
  * NaN-ignoring neighbourhood-mean fill of the masked pixels of the float64 padded image (no GPU involved). */

@@ -73,6 +73,7 @@ _PROTOTYPES = {
     "rpsf_build_transfer_device": (c_int, [c_int, c_size_t, c_void_p, c_void_p, c_int, c_double, c_double, c_void_p,
                                            c_void_p]),
     "rpsf_psf_fft": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rpsf_psf_fft_device": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p]),
     "rpsf_saturation_fill": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int]),
     "rpsf_dev_alloc": (c_int, [c_int, c_size_t, POINTER(c_void_p)]),
     "rpsf_dev_free": (c_int, [c_int, c_void_p]),
@@ -322,6 +323,18 @@ def psf_fft(values: np.ndarray, device: int = 0) -> np.ndarray:
     out = np.empty(v.shape, np.complex64)
     if v.shape[0]:
         check(lib().rpsf_psf_fft(device, v.shape[1], v.shape[0], _ptr(v), _ptr(out)))
+    return out
+
+
+def psf_fft_device(values: np.ndarray, device: int = 0) -> DeviceBuffer:
+    """K3 with the spectra left on the device: returns the DeviceBuffer holding (n, N, N) complex64."""
+    v = np.ascontiguousarray(values, dtype=np.float32)
+    if v.ndim != 3 or v.shape[1] != v.shape[2]:
+        msg = "values must have shape (n, N, N)"
+        raise ValueError(msg)
+    out = DeviceBuffer(max(1, v.size * 8), device)
+    if v.shape[0]:
+        check(lib().rpsf_psf_fft_device(device, v.shape[1], v.shape[0], _ptr(v), out.ptr))
     return out
 
 

@@ -1304,8 +1304,9 @@ extern "C" int rpsf_build_transfer(int device, size_t count, const void* s_host,
 // ------------------------------------------------------------------------------------------------
 // K3 entry point
 // ------------------------------------------------------------------------------------------------
-extern "C" int rpsf_psf_fft(int device, int patch_size, int count, const float* values_host, float* fft_host) {
-  if (!values_host || !fft_host) return fail(RPSF_E_BADARG, "null argument");
+// fft_host / fft_dev: exactly one is non-null - where the spectra go
+static int psf_fft_impl(int device, int patch_size, int count, const float* values_host, float* fft_host, void* fft_dev) {
+  if (!values_host || (!fft_host && !fft_dev)) return fail(RPSF_E_BADARG, "null argument");
   if (count <= 0) return count == 0 ? RPSF_OK : fail(RPSF_E_BADARG, "negative count");
   return dispatch_n(patch_size, [&]<class C>() -> int {
     HIP_TRY(hipSetDevice(device));
@@ -1319,25 +1320,33 @@ extern "C" int rpsf_psf_fft(int device, int patch_size, int count, const float* 
     int chunk = (int)std::max<size_t>(1, (size_t)(64u << 20) / (per * sizeof(cf)));
     if (chunk > count) chunk = count;
     HIP_TRY(b_in.alloc(per * sizeof(float) * chunk));
-    HIP_TRY(b_out.alloc(per * sizeof(cf) * chunk));
+    if (!fft_dev) HIP_TRY(b_out.alloc(per * sizeof(cf) * chunk));
     float* d_in = b_in.as<float>();
-    cf* d_out = b_out.as<cf>();
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&psf_fft_kernel<C>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)Launch<C>::LDS_BYTES));
     for (int first = 0; first < count && rc == RPSF_OK; first += chunk) {
       int cnt = std::min(chunk, count - first);
+      cf* d_out = fft_dev ? static_cast<cf*>(fft_dev) + (size_t)first * per : b_out.as<cf>();
       hipError_t e = hipMemcpy(d_in, values_host + (size_t)first * per, per * sizeof(float) * cnt, hipMemcpyHostToDevice);
       if (e != hipSuccess) { rc = fail(RPSF_E_HIP, hipGetErrorString(e)); break; }
       constexpr int TEAMS = Launch<C>::TEAMS;
       unsigned grid = (unsigned)((cnt + TEAMS - 1) / TEAMS);
       psf_fft_kernel<C><<<dim3(grid), dim3(Launch<C>::WG), Launch<C>::LDS_BYTES, nullptr>>>(d_in, cnt, d_tab, d_tw, d_out);
       e = hipGetLastError();
-      if (e == hipSuccess)
+      if (e == hipSuccess && fft_host)
         e = hipMemcpy(reinterpret_cast<cf*>(fft_host) + (size_t)first * per, d_out, per * sizeof(cf) * cnt, hipMemcpyDeviceToHost);
+      if (e == hipSuccess && !fft_host) e = hipDeviceSynchronize();  // d_in is reused by the next chunk
       if (e != hipSuccess) rc = fail(RPSF_E_HIP, hipGetErrorString(e));
     }
     return rc;
   });
+}
+
+extern "C" int rpsf_psf_fft(int device, int patch_size, int count, const float* values_host, float* fft_host) {
+  return psf_fft_impl(device, patch_size, count, values_host, fft_host, nullptr);
+}
+extern "C" int rpsf_psf_fft_device(int device, int patch_size, int count, const float* values_host, void* fft_c64_dev) {
+  return psf_fft_impl(device, patch_size, count, values_host, nullptr, fft_c64_dev);
 }
 
 // ------------------------------------------------------------------------------------------------

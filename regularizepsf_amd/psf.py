@@ -18,23 +18,28 @@ class ArrayPSF:
     ``fft2`` over the last two axes (psf.py:216-219); by default it is computed on the host with
     the reference's own backend (``scipy.fft``), which keeps ``fft_at`` bit-identical to the
     reference (its tests/test_psf.py:82-89 pins exactly that).  ``device=<gpu index>`` is an opt-in
-    addition that computes float32 spectra with the HIP kernel instead (complex64 result).
+    addition that computes float32 spectra with the HIP kernel instead (complex64 result) and **leaves them on the
+    GPU**: ``ArrayPSFTransform.construct`` then builds, packs and applies K without a spectrum or K ever crossing
+    PCIe; ``fft_evaluations`` / ``fft_at`` download them the first time they are looked at.
     """
 
     def __init__(self, values_cube: IndexedCube, fft_cube: IndexedCube | None = None,
                  workers: int | None = None, device: int | None = None) -> None:
         self._values_cube = values_cube
         self._workers = workers
+        self._fft_dev = None  # (DeviceBuffer, device): the complex64 spectra on the GPU, when they were computed there
         if fft_cube is None:
             from regularizepsf_amd import _native
 
             shape = values_cube.sample_shape
-            if device is None or shape[0] != shape[1] or shape[0] not in _native.SUPPORTED_PATCH_SIZES:
+            if device is None or shape[0] != shape[1] or shape[0] not in _native.SUPPORTED_PATCH_SIZES or len(values_cube) == 0:
                 # reference backend; also for sample sizes the GPU spectrum kernel has no plan for
-                spectra = scipy.fft.fft2(values_cube.values, workers=workers)
+                fft_cube = IndexedCube(values_cube.coordinates, scipy.fft.fft2(values_cube.values, workers=workers))
             else:
-                spectra = _native.psf_fft(values_cube.values, device=device)
-            fft_cube = IndexedCube(values_cube.coordinates, spectra)
+                buf = _native.psf_fft_device(values_cube.values, device=device)
+                self._fft_dev = (buf, device)
+                full = (len(values_cube), *shape)
+                fft_cube = IndexedCube._deferred(values_cube.coordinates, full, lambda: buf.download(full, np.complex64))
         self._fft_cube = fft_cube
 
         if fft_cube.sample_shape != values_cube.sample_shape:

@@ -30,6 +30,8 @@ def _kernel_stamp(cube: IndexedCube) -> tuple:
     elements (every patch of a 256-pixel cube contributes ~60 of them; 0.2 ms).  An edit confined to elements between
     two samples is not seen - call :meth:`ArrayPSFTransform.invalidate` after such surgical edits.
     """
+    if getattr(cube, "_loader", None) is not None:  # still on the GPU only (construct from device-resident spectra): nobody can have edited it
+        return ("deferred", id(cube), cube._edits)
     values = cube.values
     if values.flags.c_contiguous or values.flags.f_contiguous:
         flat = values.reshape(-1, order="A")
@@ -85,6 +87,30 @@ class ArrayPSFTransform:
         if np.any(np.array(source.coordinates) != np.array(target.coordinates)):
             msg = "Source PSF coordinates do not match target PSF coordinates."
             raise InvalidCoordinateError(msg)
+        n_patch = source.sample_shape[0] if len(source) else 0
+        dev_s, dev_t = getattr(source, "_fft_dev", None), getattr(target, "_fft_dev", None)
+        if (dev_s is not None and dev_t is not None and dev_s[1] == dev_t[1] == device and len(source) == len(target) > 0
+                and source.sample_shape == target.sample_shape and n_patch in _native.SUPPORTED_PATCH_SIZES
+                and all(isinstance(v, numbers.Integral) for c in source.coordinates for v in c)):
+            # Both spectra were computed on this GPU (ArrayPSF(device=...)) and are still there: K2 -> pack -> plan without
+            # anything crossing PCIe; the IndexedCube downloads K the first time somebody looks at its values.
+            count = len(source) * n_patch * n_patch
+            kbuf = _native.DeviceBuffer(count * 8, device)
+            _native.build_transfer_device(dev_s[0].ptr, dev_t[0].ptr, kbuf.ptr, count, False, alpha, epsilon, device)
+            plan = _native.Plan(n_patch, source.coordinates, device=device)
+            plan.set_transfer_device(kbuf.ptr)
+            plan.synchronize()
+            shape = (len(source), n_patch, n_patch)
+
+            def fetch(buf=kbuf, shape=shape):
+                values = buf.download(shape, np.complex64)
+                buf.free()
+                return values
+
+            cube = IndexedCube._deferred(source.coordinates, shape, fetch)
+            out = cls(cube, device=device)
+            out._plan, out._plan_stamp = plan, _kernel_stamp(cube)
+            return out
         s_fft, t_fft = source.fft_evaluations, target.fft_evaluations
         resident = (np.result_type(s_fft.dtype, t_fft.dtype) == np.complex64 and s_fft.ndim == 3 and len(source) > 0
                     and s_fft.shape == t_fft.shape and s_fft.shape[1] == s_fft.shape[2]

@@ -45,13 +45,38 @@ class IndexedCube:
             msg = f"{len(coordinates)} coordinates defined but {values.shape[0]} values found."
             raise IncorrectShapeError(msg)
         self._coordinates = coordinates
-        self._values = values
+        self._values_array = values
+        self._loader = None
+        self._shape = values.shape
         self._where = {tuple(c): layer for layer, c in enumerate(coordinates)}
         self._edits = 0  # bumped by __setitem__, lets device-side copies notice they are stale
 
+    @classmethod
+    def _deferred(cls, coordinates: list[tuple[int, int]], shape: tuple[int, int, int], loader) -> "IndexedCube":
+        """A cube whose values live on the GPU until somebody looks at them: ``loader()`` returns the (n, rows, cols)
+        array on first access (regularizepsf_amd extension, used by ``ArrayPSF(device=...)`` and ``construct``)."""
+        if len(shape) != 3 or len(coordinates) != shape[0]:
+            msg = f"{len(coordinates)} coordinates defined but values of shape {shape} announced."
+            raise IncorrectShapeError(msg)
+        self = cls.__new__(cls)
+        self._coordinates = coordinates
+        self._values_array = None
+        self._loader = loader
+        self._shape = tuple(shape)
+        self._where = {tuple(c): layer for layer, c in enumerate(coordinates)}
+        self._edits = 0
+        return self
+
+    @property
+    def _values(self) -> np.ndarray:
+        if self._values_array is None:
+            self._values_array = self._loader()
+            self._loader = None
+        return self._values_array
+
     @property
     def sample_shape(self) -> tuple[int, int]:
-        return self._values.shape[1], self._values.shape[2]
+        return self._shape[1], self._shape[2]
 
     @property
     def coordinates(self) -> list[tuple[int, int]]:

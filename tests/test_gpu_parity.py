@@ -701,3 +701,72 @@ def test_one_transform_from_two_threads():
     for th in threads:
         th.join()
     assert not errors
+
+
+def test_fused_plane_sum_epochs_origins_and_fallback():
+    """The 256-px plan sums its colour planes inside the patch launch when the geometry allows it (per-tile counters that are
+    never reset: a tile is complete at epoch x contributors).  Same plan, many applies: an aligned frame (fused),
+    a frame whose width is not a multiple of 32 (falls back to the separate sum kernel), a host-padded frame (shifted
+    origin, fused again) - every result against the oracle, and the fused result bit-identical to the unfused one."""
+    from regularizepsf_amd import _native
+
+    n = 256
+    rng = np.random.default_rng(21)
+    coords = [tuple(int(v) for v in c) for c in rp.calculate_covering((768, 1024), n)]
+    k = (rng.standard_normal((len(coords), n, n)) + 1j * rng.standard_normal((len(coords), n, n))).astype(np.complex64)
+    t = rp.ArrayPSFTransform(rp.IndexedCube(coords, k))
+    big = (rng.standard_normal((768, 1024)) * 10 + 30).astype(np.float32)
+    odd = big[:700, :1000].copy()       # width 1000: not a multiple of 32 -> unfused
+    refs = {"big": orc.apply_transfer(big, coords, k), "odd": orc.apply_transfer(odd, coords, k)}
+    first = t.apply(big)
+    check(first, refs["big"])
+    check(t.apply(odd), refs["odd"])
+    for _ in range(3):
+        assert np.array_equal(t.apply(big), first)
+    check(t.apply(big, pad_mode="mean"), orc.apply_transfer(big, coords, k, pad_mode="mean"))  # host-padded: origin (2N, 2N)
+    assert np.array_equal(t.apply(big), first)
+    # fused == unfused, bit for bit (same colour order)
+    plan = _native.Plan(n, coords)
+    plan.set_transfer(k)
+    a = plan.apply(big, 1)
+    import os
+    os.environ["RPSF_NO_FUSE"] = "1"
+    try:
+        plan2 = _native.Plan(n, coords)
+        plan2.set_transfer(k)
+        b = plan2.apply(big, 1)
+    finally:
+        del os.environ["RPSF_NO_FUSE"]
+    assert np.array_equal(a, b)
+
+
+def test_device_resident_psf_to_transform_chain():
+    """ArrayPSF(device=0) leaves the spectra on the GPU, construct() builds and packs K there, apply() runs -
+    nothing but the PSF samples and the image crosses PCIe.  The host copies appear only when somebody looks at them, and
+    they are what the host route computes."""
+    from regularizepsf_amd import _native
+
+    n, shape = 64, (200, 260)
+    coords = [tuple(int(v) for v in c) for c in rp.calculate_covering(shape, n)]
+    src, tgt = make_psfs("coma", coords, n, *shape)
+    s = rp.ArrayPSF(rp.IndexedCube(coords, src.astype(np.float32)), device=0)
+    t = rp.ArrayPSF(rp.IndexedCube(coords, tgt.astype(np.float32)), device=0)
+    assert s._fft_cube._loader is not None and s.sample_shape == (n, n) and len(s) == len(coords)
+    image = orc.starfield(*shape, 9)
+    sweep = []
+    for alpha, eps in ((3.0, 0.1), (1.0, 0.05)):  # an alpha / epsilon sweep re-uses the resident spectra
+        tr = rp.ArrayPSFTransform.construct(s, t, alpha, eps)
+        assert tr._transfer_kernel._loader is not None and s._fft_cube._loader is not None  # still nothing downloaded
+        out = tr.apply(image)
+        assert tr._transfer_kernel._loader is not None  # apply() did not need K on the host either
+        sweep.append((alpha, eps, tr, out))
+    got_s, got_t = s.fft_evaluations, t.fft_evaluations  # fetched now
+    assert got_s.dtype == np.complex64 and np.array_equal(got_s, _native.psf_fft(src.astype(np.float32)))
+    ref_s = orc.psf_fft(src.astype(np.float32))
+    assert np.abs(got_s - ref_s).max() <= 1e-5 * np.abs(ref_s).max()
+    for alpha, eps, tr, out in sweep:
+        k = tr._transfer_kernel.values  # fetched now: the same K the host route builds from the same spectra
+        assert k.dtype == np.complex64 and np.array_equal(k, _native.build_transfer(got_s, got_t, alpha, eps), equal_nan=True)
+        check(out, orc.apply_transfer(image, coords, k))
+        tr._transfer_kernel[coords[0]] = np.zeros((n, n), np.complex64)  # edits after the fetch are still noticed
+        assert not np.array_equal(tr.apply(image), out)
