@@ -527,7 +527,7 @@ extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int
     p->v2 = has_v2(N);
     p->no_fuse = std::getenv("RPSF_NO_FUSE") != nullptr;
     // (measured, profiles/r02u, r02v: 32 of them are worth -1 % at 4096^2 and -2.5 % at 8192^2; 48 cost more patch time than they hide)
-    p->sum_first = n_patches >= 2 * 256 ? 32 : 0;
+    p->sum_first = n_patches >= 2048 ? 32 : n_patches >= 512 ? 8 : 0;  // (r02y: a band of 520 patches 130-138 us with 8, 131-146 with 32)
     if (const char* e = std::getenv("RPSF_SUM_FIRST")) p->sum_first = std::max(0, std::atoi(e)) / 8 * 8;
     p->fuse_pays = N >= 256 || std::getenv("RPSF_FUSE_ALWAYS") != nullptr;
     int rl = p->v2 ? dispatch_v2(N, [&]<class C>() -> int {
@@ -903,6 +903,8 @@ static int launch_apply(rpsf_plan* p, const float* d_img, float* d_out, const rp
   const OverlapKind kind = overlap_kind(p);
   if (kind != OV_ATOMIC && !p->lattice) return fail(RPSF_E_STATE, "colour planes need a regular half-overlap lattice of patch corners");
   if (kind == OV_DIRECT && !p->direct_ok) return fail(RPSF_E_STATE, "direct overlap-add needs a lattice and a 128- or 256-pixel patch");
+  if (kind == OV_DIRECT && (size_t)g.out_rows * g.ld_out * sizeof(float) >= ((size_t)1 << 32))
+    return fail(RPSF_E_UNSUPPORTED, "direct overlap-add addresses the output through a 32-bit buffer offset: frame too large");
   // The plan's scratch (planes, flags) serves one apply at a time: an apply on another stream waits for the last one.
   if (p->busy_valid && st != p->last_stream) HIP_TRY(hipStreamWaitEvent(st, p->ev_busy, 0));
   if (kind != OV_ATOMIC) {
@@ -948,7 +950,8 @@ static int launch_apply(rpsf_plan* p, const float* d_img, float* d_out, const rp
   // Fused plane sum: one frame, every plane line written whole by one store instruction (see sum_tile)
   const long tile_r0 = (long)p->lat_r0 + g.origin_row, tile_c0 = (long)p->lat_c0 + g.origin_col;
   const bool fused = kind == OV_PLANES && p->v2 && p->fuse_pays && p->d_tile_done && !p->no_fuse && b.frames == 1 && g.width % 32 == 0 &&
-                     g.ld_out % 4 == 0 && tile_c0 % 32 == 0 && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0;
+                     g.ld_out % 4 == 0 && tile_c0 % 32 == 0 && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0 &&
+                     16 * plane_floats_needed(g) < ((size_t)1 << 32);  // the planes are addressed through one 32-bit buffer offset
   if (fused) {
     if (++p->done_epoch >= (1u << 29)) {  // the counters hold epoch * contributors
       HIP_TRY(hipMemsetAsync(p->d_tile_done, 0, (size_t)p->nti * p->ntj * sizeof(uint32_t), st));

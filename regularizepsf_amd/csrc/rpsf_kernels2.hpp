@@ -15,7 +15,7 @@ struct Launch2 {
 // 16-byte load that bypasses this CU's L1 (agent scope), through a raw buffer descriptor so that the compiler tracks it
 __device__ __forceinline__ f32x4 load16_sc1(const float* base, size_t span_bytes, const float* p) {
   typedef int i32x4 __attribute__((ext_vector_type(4)));
-  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)span_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, span_bytes < 0x7fffffffu ? (int)span_bytes : -1, 0x00020000);
   const i32x4 q = __builtin_amdgcn_raw_buffer_load_b128(r, (int)((p - base) * sizeof(float)), 0, /*sc1*/ 16);
   return f32x4{__int_as_float(q.x), __int_as_float(q.y), __int_as_float(q.z), __int_as_float(q.w)};
 }
