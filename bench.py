@@ -163,6 +163,29 @@ class GlooSeam:
         if req is not None:
             req.wait()
 
+    def seam_exchange(self, send_ptr, send_count, recv_ptr, recv_count, stream=None):
+        """The transfer alone (synchronous here): spill rows to rank + 1, rows from rank - 1 into recv_ptr."""
+        import ctypes
+        import torch
+        import torch.distributed as dist
+        from regularizepsf_amd import _native
+
+        lib = _native.lib()
+        _native.check(lib.rpsf_device_synchronize(self.device))
+        req = None
+        if self.rank + 1 < self.world and send_count:
+            out = np.empty(send_count, np.float32)
+            _native.check(lib.rpsf_memcpy_d2h(self.device, out.ctypes.data_as(ctypes.c_void_p), send_ptr, out.nbytes))
+            req = dist.isend(torch.from_numpy(out), self.rank + 1)
+        if self.rank > 0 and recv_count:
+            got = torch.empty(recv_count, dtype=torch.float32)
+            dist.recv(got, self.rank - 1)
+            _native.check(lib.rpsf_memcpy_h2d(self.device, recv_ptr, got.numpy().ctypes.data_as(ctypes.c_void_p), got.numpy().nbytes))
+        if req is not None:
+            req.wait()
+
+    stream = None
+
     def barrier(self, stream=None):
         import torch.distributed as dist
 
@@ -300,6 +323,9 @@ def main() -> None:
                          "multi-rank flow on a box with fewer GPUs than ranks")
     ap.add_argument("--verify", action="store_true", help="check every rank's owned rows against the CPU oracle")
     ap.add_argument("--frames", type=int, default=8, help="config 5: frames per GPU in one batch")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="--seam exchange: plain apply -> send/recv -> add on one stream instead of computing the spill rows "
+                         "first and sending them beside the rest of the band")
     ap.add_argument("--seam", choices=["recompute", "exchange"], default="exchange",
                     help="N > 1: 'exchange' - the spill rows of a band are sent to the next rank with RCCL send/recv and added "
                          "there (BASELINE's halo reduce); 'recompute' - every band also runs the lattice row above it that "
@@ -387,7 +413,8 @@ def main() -> None:
             comm = GlooSeam(rank, world, device)
     if args.config == 5:
         return run_batch(args, rank, world, device, comm)
-    shard = ShardedApply(coords, kernel_for, n, height, w, rank, world, device, comm, pad_mode=pad, seam=args.seam)
+    shard = ShardedApply(coords, kernel_for, n, height, w, rank, world, device, comm, pad_mode=pad, seam=args.seam,
+                         overlap=not args.no_overlap)
     band = shard.band
     band_image = image_rows(band.image_row0, band.image_row0 + band.image_rows)
     shard.upload_rows(band_image)

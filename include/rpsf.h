@@ -181,6 +181,14 @@ void rpsf_comm_destroy(rpsf_comm* comm);
  * rank-1 (if any) into recv_dev, then add recv_dev[0:recv_count] into accum_dev.  Any count may be 0. */
 int rpsf_comm_seam_exchange_add(rpsf_comm* comm, const void* send_dev, size_t send_count, void* recv_dev,
                                 size_t recv_count, void* accum_dev, void* stream);
+/* The exchange alone, without the add - for callers that compute the spill rows first, on a stream of their own,
+ * and let the transfer run beside the rest of the band (regularizepsf_amd/sharding.py).  stream NULL: the
+ * communicator's own stream (rpsf_comm_stream). */
+int rpsf_comm_seam_exchange(rpsf_comm* comm, const void* send_dev, size_t send_count, void* recv_dev, size_t recv_count,
+                            void* stream);
+void* rpsf_comm_stream(rpsf_comm* comm);
+/* Make `waiter` (a hipStream_t) wait for everything enqueued on `signaller` so far. */
+int rpsf_stream_wait(int device, void* waiter, void* signaller);
 /* accum_dev[0:count] += src_dev[0:count] (float32, on `device`, asynchronous on stream): the add of the seam
  * exchange by itself, for callers that move the seam rows with their own transport. */
 int rpsf_add_rows(int device, void* accum_dev, const void* src_dev, size_t count, void* stream);

@@ -84,6 +84,9 @@ _PROTOTYPES = {
     "rpsf_comm_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_void_p]),
     "rpsf_comm_destroy": (None, [c_void_p]),
     "rpsf_comm_seam_exchange_add": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "rpsf_comm_seam_exchange": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]),
+    "rpsf_comm_stream": (c_void_p, [c_void_p]),
+    "rpsf_stream_wait": (c_int, [c_int, c_void_p, c_void_p]),
     "rpsf_add_rows": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rpsf_comm_barrier": (c_int, [c_void_p, c_void_p]),
     "rpsf_comm_allreduce_max": (c_int, [c_void_p, POINTER(c_double)]),
@@ -352,6 +355,11 @@ def add_rows(accum_ptr: c_void_p, src_ptr: c_void_p, count: int, device: int = 0
     check(lib().rpsf_add_rows(device, accum_ptr, src_ptr, count, stream))
 
 
+def stream_wait(waiter: c_void_p, signaller: c_void_p, device: int = 0) -> None:
+    """Work enqueued on ``waiter`` from now on starts after everything enqueued on ``signaller`` so far."""
+    check(lib().rpsf_stream_wait(device, waiter, signaller))
+
+
 class Comm:
     """RCCL neighbour exchange for the row-band split (one process per GPU)."""
 
@@ -369,6 +377,14 @@ class Comm:
 
     def seam_exchange_add(self, send_ptr, send_count: int, recv_ptr, recv_count: int, accum_ptr, stream=None) -> None:
         check(lib().rpsf_comm_seam_exchange_add(self._handle, send_ptr, send_count, recv_ptr, recv_count, accum_ptr, stream))
+
+    def seam_exchange(self, send_ptr, send_count: int, recv_ptr, recv_count: int, stream=None) -> None:
+        """Send to rank + 1 / receive from rank - 1 without the add (asynchronous on ``stream``, default: the communicator's)."""
+        check(lib().rpsf_comm_seam_exchange(self._handle, send_ptr, send_count, recv_ptr, recv_count, stream))
+
+    @property
+    def stream(self) -> c_void_p:
+        return c_void_p(lib().rpsf_comm_stream(self._handle))
 
     def barrier(self, stream=None) -> None:
         check(lib().rpsf_comm_barrier(self._handle, stream))

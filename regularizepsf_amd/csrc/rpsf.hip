@@ -1541,6 +1541,37 @@ extern "C" int rpsf_comm_seam_exchange_add(rpsf_comm* c, const void* send_dev, s
   return RPSF_OK;
 }
 
+// The exchange alone (no add): for callers that overlap it with the rest of their band's work on another stream
+extern "C" int rpsf_comm_seam_exchange(rpsf_comm* c, const void* send_dev, size_t send_count, void* recv_dev, size_t recv_count,
+                                       void* stream) {
+  if (!c) return fail(RPSF_E_BADARG, "null comm");
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : c->stream;
+  const bool do_send = c->rank + 1 < c->world && send_count > 0;
+  const bool do_recv = c->rank > 0 && recv_count > 0;
+  if ((do_send && !send_dev) || (do_recv && !recv_dev)) return fail(RPSF_E_BADARG, "null buffer");
+  if (do_send || do_recv) {
+    NCCL_TRY(g_rccl.group_start());
+    if (do_send) NCCL_TRY(g_rccl.send(send_dev, send_count, /*ncclFloat32*/ 7, c->rank + 1, c->comm, st));
+    if (do_recv) NCCL_TRY(g_rccl.recv(recv_dev, recv_count, 7, c->rank - 1, c->comm, st));
+    NCCL_TRY(g_rccl.group_end());
+  }
+  return RPSF_OK;
+}
+extern "C" void* rpsf_comm_stream(rpsf_comm* c) { return c ? (void*)c->stream : nullptr; }
+
+// Work enqueued on `waiter` after this call starts only when everything enqueued on `signaller` so far has finished
+extern "C" int rpsf_stream_wait(int device, void* waiter, void* signaller) {
+  HIP_TRY(hipSetDevice(device));
+  hipEvent_t ev = nullptr;
+  HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  hipError_t e = hipEventRecord(ev, reinterpret_cast<hipStream_t>(signaller));
+  if (e == hipSuccess) e = hipStreamWaitEvent(reinterpret_cast<hipStream_t>(waiter), ev, 0);
+  (void)hipEventDestroy(ev);  // released once the recorded work has completed
+  if (e != hipSuccess) return fail(RPSF_E_HIP, hipGetErrorString(e));
+  return RPSF_OK;
+}
+
 // accum[0:count] += src[0:count] on `device` (kernel K4; the add of the seam exchange, exported for callers that move
 // the seam rows themselves)
 extern "C" int rpsf_add_rows(int device, void* accum_dev, const void* src_dev, size_t count, void* stream) {

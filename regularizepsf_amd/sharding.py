@@ -136,22 +136,50 @@ def make_band_plans(coordinates, patch_size: int, height: int, world: int, pad_m
 
 
 class ShardedApply:
-    """One rank's share of a row-band-sharded apply: local K1 launch, then the RCCL seam exchange."""
+    """One rank's share of a row-band-sharded apply: local K1 launch(es), then the RCCL seam exchange.
+
+    ``seam="exchange"`` with ``overlap=True`` (default) hides the transfer behind the band's own work: the spill rows depend
+    only on the band's LAST lattice row of patches, so those run first, as a plan of their own on a stream of their own,
+    straight into a spill buffer; the send (and the receive from the rank above) follows on that stream while the main plan -
+    all patches of the band, output cropped to the rows the band owns - is still running on the other.  The received rows
+    are added (K4) once both are done.  The last lattice row is computed twice (65 of 520 patches at eight bands of the
+    8192-wide configuration; they fit into the band's partial last round).  ``overlap=False`` is the plain sequence
+    apply -> exchange -> add on one stream.
+    """
 
     def __init__(self, coordinates, kernel_for, patch_size: int, height: int, width: int, rank: int, world: int,
-                 device: int, comm: "_native.Comm | None", pad_mode: str = "symmetric", seam: str = "exchange") -> None:
+                 device: int, comm: "_native.Comm | None", pad_mode: str = "symmetric", seam: str = "exchange",
+                 overlap: bool = True) -> None:
         """``kernel_for(index_list)`` returns the (len, N, N) complex64 transfer kernels of those patches."""
-        self.height, self.width, self.rank, self.world = height, width, rank, world
+        self.height, self.width, self.rank, self.world, self.device = height, width, rank, world, device
         self.seam = seam
         self.band = make_band_plans(coordinates, patch_size, height, world, pad_mode, seam)[rank]
-        coords = [tuple(int(v) for v in coordinates[i]) for i in self.band.patch_index]
+        b = self.band
+        coords = [tuple(int(v) for v in coordinates[i]) for i in b.patch_index]
         self.plan = _native.Plan(patch_size, coords, device=device)
-        self.plan.set_transfer(kernel_for(self.band.patch_index))
-        self.geometry = self.band.geometry(height, width, _native.PAD_MODES[pad_mode])
+        self.plan.set_transfer(kernel_for(b.patch_index))
+        self.geometry = b.geometry(height, width, _native.PAD_MODES[pad_mode])
         self.comm = comm
-        self.d_img = _native.DeviceBuffer(self.band.image_rows * width * 4, device)
-        self.d_out = _native.DeviceBuffer(self.band.out_rows * width * 4, device)
-        self.d_recv = _native.DeviceBuffer(max(1, self.band.recv_rows) * width * 4, device)
+        self.overlap = bool(overlap and seam == "exchange" and world > 1 and b.send_rows + b.recv_rows > 0)
+        self.seam_plan = None
+        self.d_img = _native.DeviceBuffer(b.image_rows * width * 4, device)
+        self.d_recv = _native.DeviceBuffer(max(1, b.recv_rows) * width * 4, device)
+        if self.overlap:
+            pm = _native.PAD_MODES[pad_mode]
+            # main plan: output window = the rows this band owns (the spill is the seam plan's business)
+            self.geometry = _native.Geometry(height, width, pm, 0.0, 0, 0, b.image_row0, b.image_rows, width,
+                                             b.out_row0, b.own_rows, width)
+            self.d_out = _native.DeviceBuffer(b.own_rows * width * 4, device)
+            if b.send_rows > 0:
+                last_row = max(int(coordinates[i][0]) for i in b.patch_index)
+                seam_index = [i for i in b.patch_index if int(coordinates[i][0]) == last_row]
+                self.seam_plan = _native.Plan(patch_size, [tuple(int(v) for v in coordinates[i]) for i in seam_index], device=device)
+                self.seam_plan.set_transfer(kernel_for(seam_index))
+                self.seam_geometry = _native.Geometry(height, width, pm, 0.0, 0, 0, b.image_row0, b.image_rows, width,
+                                                      b.out_row0 + b.own_rows, b.send_rows, width)
+                self.d_spill = _native.DeviceBuffer(b.send_rows * width * 4, device)
+        else:
+            self.d_out = _native.DeviceBuffer(b.out_rows * width * 4, device)
 
     def upload_rows(self, band_image: np.ndarray) -> None:
         """``band_image`` = image rows [image_row0, image_row0 + image_rows) as float32."""
@@ -161,15 +189,37 @@ class ShardedApply:
         self.d_img.upload(np.ascontiguousarray(band_image, np.float32))
 
     def step(self) -> None:
-        """Enqueue one apply + seam exchange on the plan's stream (asynchronous)."""
+        """Enqueue one apply + seam exchange (asynchronous; ``synchronize`` waits for all of it)."""
         b, w = self.band, self.width
+        if not self.overlap:
+            self.plan.apply_device(self.d_img.ptr, self.d_out.ptr, self.geometry)
+            if self.comm is not None and self.world > 1 and b.send_rows + b.recv_rows > 0:
+                self.comm.seam_exchange_add(self.d_out.at(b.send_offset_rows * w * 4), b.send_rows * w,
+                                            self.d_recv.ptr, b.recv_rows * w, self.d_out.ptr, self.plan.stream)
+            return
+        xstream = self.seam_plan.stream if self.seam_plan is not None else (self.comm.stream if self.comm is not None else None)
+        if self.seam_plan is not None:  # first in line: its workgroups are dispatched ahead of the main plan's
+            self.seam_plan.apply_device(self.d_img.ptr, self.d_spill.ptr, self.seam_geometry)
         self.plan.apply_device(self.d_img.ptr, self.d_out.ptr, self.geometry)
-        if self.comm is not None and self.world > 1 and b.send_rows + b.recv_rows > 0:
-            self.comm.seam_exchange_add(self.d_out.at(b.send_offset_rows * w * 4), b.send_rows * w,
-                                        self.d_recv.ptr, b.recv_rows * w, self.d_out.ptr, self.plan.stream)
+        if self.comm is None:
+            return
+        self.comm.seam_exchange(self.d_spill.ptr if self.seam_plan is not None else None, b.send_rows * w,
+                                self.d_recv.ptr, b.recv_rows * w, xstream)
+        if b.recv_rows > 0:
+            if xstream is not None:
+                _native.stream_wait(self.plan.stream, xstream, self.device)
+            _native.add_rows(self.d_out.ptr, self.d_recv.ptr, b.recv_rows * w, self.device, self.plan.stream)
+
+    def spill_rows(self) -> np.ndarray:
+        """The rows this band's last lattice row leaves for the next band (after ``step`` + ``synchronize``)."""
+        b, w = self.band, self.width
+        self.synchronize()
+        if self.overlap:
+            return self.d_spill.download((b.send_rows, w)) if self.seam_plan is not None else np.zeros((0, w), np.float32)
+        return self.d_out.download((b.send_rows, w), offset_bytes=b.send_offset_rows * w * 4)
 
     def synchronize(self) -> None:
-        self.plan.synchronize()
+        self.plan.synchronize()  # device-wide: covers the seam plan's and the communicator's streams too
 
     def owned_rows(self) -> np.ndarray:
         """The final output rows this rank owns: rows [out_row0, out_row0 + own_rows) of the full result."""

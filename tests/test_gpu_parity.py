@@ -164,30 +164,34 @@ def test_errors_follow_reference_conventions():
     assert out.dtype == np.float64
 
 
+@pytest.mark.parametrize("overlap", [False, True])
 @pytest.mark.parametrize("world", [2, 3])
-def test_row_bands_on_one_gpu(world):
+def test_row_bands_on_one_gpu(world, overlap):
     """The multi-GPU band geometry (resident row windows, owned/spill rows) run band by band on ONE GPU;
-    the seam add is done on the host here, RCCL does it in production (regularizepsf_amd/sharding.py)."""
+    the seam add is done on the host here, RCCL does it in production (regularizepsf_amd/sharding.py).
+    overlap=True: the spill rows come from a plan of their own (the band's last lattice row, launched first on its own
+    stream so that the transfer can run beside the rest of the band); overlap=False: one plan, spill rows at the end of its buffer."""
     from regularizepsf_amd.sharding import ShardedApply
 
     h, w, n = 1024, 768, 128
     coords, k = orc.synthetic_transfer(h, w, n, alpha=1.0, epsilon=0.1)
     image = orc.starfield(h, w, seed=5)
     ref = orc.apply_transfer(image, coords, k, workers=-1)
-    bufs, bands = [], []
+    own, spill, bands = [], [], []
     for rank in range(world):
-        sh = ShardedApply(coords, lambda idx: k[idx], n, h, w, rank, world, 0, None)
+        sh = ShardedApply(coords, lambda idx: k[idx], n, h, w, rank, world, 0, None, overlap=overlap)
         b = sh.band
+        assert sh.overlap == overlap and (sh.seam_plan is not None) == (overlap and b.send_rows > 0)
         sh.upload_rows(image[b.image_row0 : b.image_row0 + b.image_rows])
         sh.step()
-        sh.synchronize()
-        bufs.append(sh.d_out.download((b.out_rows, w)).astype(np.float64))
+        own.append(sh.owned_rows().astype(np.float64))
+        spill.append(sh.spill_rows().astype(np.float64))
         bands.append(b)
     for g in range(1, world):
-        p = bands[g - 1]
-        bufs[g][: bands[g].recv_rows] += bufs[g - 1][p.send_offset_rows : p.send_offset_rows + p.send_rows]
-    got = np.concatenate([buf[: b.own_rows] for buf, b in zip(bufs, bands)])
-    check(got, ref)
+        own[g][: bands[g].recv_rows] += spill[g - 1]
+    check(np.concatenate(own), ref)
+    if overlap:
+        return
     # seam="recompute": every band also runs the patches above it that reach into its rows; nothing to add afterwards
     parts = []
     for rank in range(world):
@@ -600,9 +604,10 @@ def test_config4_8192_n256_eight_bands_both_seam_modes():
         sh.upload_rows(image[b.image_row0 : b.image_row0 + b.image_rows])
         sh.step()
         sh.synchronize()
-        if prev is not None:  # what rpsf_comm_seam_exchange_add does on the receiving rank, minus the transport
+        if prev is not None:  # what the receiving rank does with the rows RCCL delivers: K4 on its own output
             psh, pb = prev
-            _native.add_rows(sh.d_out.ptr, psh.d_out.at(pb.send_offset_rows * w * 4), pb.send_rows * w)
+            assert psh.overlap and psh.seam_plan is not None  # spill rows computed first, by a plan of their own
+            _native.add_rows(sh.d_out.ptr, psh.d_spill.ptr, pb.send_rows * w)
             sh.synchronize()
         out[b.out_row0 : b.out_row0 + b.own_rows] = sh.d_out.download((b.own_rows, w))
         prev = (sh, b)
