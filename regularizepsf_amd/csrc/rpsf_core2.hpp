@@ -459,7 +459,7 @@ template <class C>
 RPSF_HD void load_raw2(int t, cf* v, const ImageView& im, int pr, int pc, bool fast, const int* maps) {
   ThreadPos2<C> tp(t);
   constexpr int NR = 1 << C::A1, NCOL = 1 << C::B1;
-  if (fast) {
+  if (__builtin_expect(fast, 1)) {
     const float* base = im.img + (size_t)(pr - im.row0) * im.ld + pc;
     StaticFor<0, NR>::run([&]<int R1>() RPSF_AI {
       const int r = (R1 << (C::A2 + C::AL)) + tp.r_low;
@@ -471,6 +471,38 @@ RPSF_HD void load_raw2(int t, cf* v, const ImageView& im, int pr, int pc, bool f
       });
     });
   } else {
+    // Rim patches.  A thread's two column units are the same for all its rows: where the np.pad index map sends a unit to
+    // four consecutive image columns - ascending (inside the image, 'wrap') or descending ('symmetric' mirrors whole units
+    // when the image edge is unit-aligned) - or to the constant fill, the unit is still one 16-byte load (reversed in
+    // registers); only units the map tears apart ('reflect', 'edge', widths that are no multiple of 4) go pixel by pixel.
+    int xq[NCOL];
+    bool rev[NCOL], cst[NCOL];
+    bool quad = quads_aligned(im.img, im.ld, 0);
+    StaticFor<0, NCOL>::run([&]<int C1>() RPSF_AI {
+      const int* m = maps + C::N + 4 * ((C1 << C::B2) + tp.c2);
+      const int m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3];
+      const bool up = m0 >= 0 && m1 == m0 + 1 && m2 == m0 + 2 && m3 == m0 + 3 && (m0 & 3) == 0;
+      const bool dn = m3 >= 0 && m2 == m3 + 1 && m1 == m3 + 2 && m0 == m3 + 3 && (m3 & 3) == 0;
+      cst[C1] = (m0 & m1 & m2 & m3) < 0;  // all four are "constant value"
+      rev[C1] = dn;
+      xq[C1] = up ? m0 : dn ? m3 : 0;
+      quad = quad && (up || dn || cst[C1]);
+    });
+    if (quad) {
+      StaticFor<0, NR>::run([&]<int R1>() RPSF_AI {
+        const int r = (R1 << (C::A2 + C::AL)) + tp.r_low;
+        const int yl = maps[r];
+        const float* row = im.img + (size_t)(yl < 0 ? 0 : yl) * im.ld;
+        StaticFor<0, NCOL>::run([&]<int C1>() RPSF_AI {
+          const f32x4 q = *reinterpret_cast<const f32x4*>(row + xq[C1]);  // always in bounds; select afterwards
+          const bool fill = yl < 0 || cst[C1];
+          const float pv = im.pad_value;
+          v[2 * (R1 * NCOL + C1)] = cf{fill ? pv : rev[C1] ? q.w : q.x, fill ? pv : rev[C1] ? q.z : q.y};
+          v[2 * (R1 * NCOL + C1) + 1] = cf{fill ? pv : rev[C1] ? q.y : q.z, fill ? pv : rev[C1] ? q.x : q.w};
+        });
+      });
+      return;
+    }
     StaticFor<0, NR>::run([&]<int R1>() RPSF_AI {
       const int r = (R1 << (C::A2 + C::AL)) + tp.r_low;
       const int yl = maps[r];
@@ -529,7 +561,7 @@ RPSF_HD void store_patch2(int t, const cf* v, const OutView& pv, const OutView& 
   float* pbase = pv.out + (size_t)plane * pv.plane_stride;
   const bool fast = patch_inside<C>(pr, pc, pv.H, pv.W, pv.row0, pv.rows) && quads_aligned(pbase, pv.ld, pc) &&
                     (planes || qw) && (!qw || quads_aligned(dv.out, dv.ld, pc));
-  if (fast) {
+  if (__builtin_expect(fast, 1)) {
     float* prow0 = pbase + (size_t)(pr - pv.row0) * pv.ld + pc;
     float* drow0 = qw ? dv.out + (size_t)(pr - dv.row0) * dv.ld + pc : nullptr;
     constexpr int BATCH = 4;  // rows of units whose running sums are in flight together
@@ -555,6 +587,27 @@ RPSF_HD void store_patch2(int t, const cf* v, const OutView& pv, const OutView& 
         } else if (quad_mode(qw[QD]) == QUAD_DIRECT) {
           val += old[U];
           *reinterpret_cast<f32x4*>(drow0 + (size_t)r * dv.ld + 4 * cp) = val;
+        }
+      });
+    });
+    return;
+  }
+  if (planes && !qw && quads_aligned(pbase, pv.ld, pc) && (pv.W & 3) == 0) {
+    // Rim patches in plane mode: with the corner column and the image width multiples of 4 a unit lies wholly inside or
+    // wholly outside the image, so the part of the patch that is inside still goes out in 16-byte stores (and a 128-byte
+    // line is still written whole by one store instruction whenever the image edges are line-aligned, which is what
+    // the fused plane sum asks of its producers).
+    StaticFor<0, NR>::run([&]<int R1>() RPSF_AI {
+      const int r = (R1 << (C::A2 + C::AL)) + tp.r_low;
+      const float wr = win[r];
+      const int y = pr + r, yl = y - pv.row0;
+      const bool row_ok = y >= 0 && y < pv.H && yl >= 0 && yl < pv.rows;
+      StaticFor<0, NCOL>::run([&]<int C1>() RPSF_AI {
+        const int cp = (C1 << C::B2) + tp.c2, x = pc + 4 * cp;
+        if (row_ok && x >= 0 && x + 4 <= pv.W) {
+          const f32x4 w4 = *reinterpret_cast<const f32x4*>(win + 4 * cp);
+          const cf a = v[2 * (R1 * NCOL + C1)], b = v[2 * (R1 * NCOL + C1) + 1];
+          pstore4(pbase + (size_t)yl * pv.ld + x, f32x4{a.x * (w4.x * wr), a.y * (w4.y * wr), b.x * (w4.z * wr), b.y * (w4.w * wr)});
         }
       });
     });

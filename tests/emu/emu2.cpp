@@ -11,7 +11,7 @@
 
 using namespace rpsf;
 
-// overlap: 0 = atomics (plain adds here), 1 = colour planes + sum, 2 = direct with the quadrant words below
+// direct: 0 = atomics (plain adds here), 1 = direct with the quadrant words below, 2 = colour planes + sum
 template <class C>
 static int emu2_apply_t(int n_patches, const int32_t* coords, int H, int W, int pad_mode, float pad_value,
                         const float* img, const float* kfull, float* out, int direct) {
@@ -37,6 +37,11 @@ static int emu2_apply_t(int n_patches, const int32_t* coords, int H, int W, int 
   std::vector<float> sink(128);
   OutView ov{out, H, W, W, 0, H, 0, sink.data()};
   memset(out, 0, sizeof(float) * (size_t)H * W);
+  // colour planes: 16-byte aligned like the device buffer (the 16-byte rim stores need it)
+  std::vector<float> plane_mem(direct == 2 ? (size_t)4 * H * W + 4 : 0, 0.f);
+  float* planes = plane_mem.data();
+  while (reinterpret_cast<uintptr_t>(planes) & 15) ++planes;
+  OutView pv{planes, H, W, W, 0, H, (size_t)H * W, sink.data()};
   auto add = [](float* p, float v) { *p += v; };
   auto load4 = []<int R1, int C1>(const float* p) { return *reinterpret_cast<const f32x4*>(p); };
   auto load1 = [](const float* p) { return *p; };
@@ -102,6 +107,9 @@ static int emu2_apply_t(int n_patches, const int32_t* coords, int H, int W, int 
     for (int t = 0; t < T; ++t) stage1h<C, 1, true>(t, R(t), tw.data());
     if (!direct) {
       for (int t = 0; t < T; ++t) store_patch2<C>(t, R(t), ov, ov, 0, pr, pc, win.data(), nullptr, add, load4, load1, pstore4, pstore1);
+    } else if (direct == 2) {  // the plane of the patch's lattice parity (the caller passes a lattice with corners at multiples of N/2)
+      const int half = N / 2, plane = 2 * (((pr + 8 * N) / half) & 1) + (((pc + 8 * N) / half) & 1);
+      for (int t = 0; t < T; ++t) store_patch2<C>(t, R(t), pv, pv, plane, pr, pc, win.data(), nullptr, add, load4, load1, pstore4, pstore1);
     } else {
       // direct stores, sequential: the first patch over a tile stores, later ones accumulate (the flags' job on the GPU);
       // tiles are indexed from the first patch corner (the caller passes a lattice)
@@ -117,6 +125,8 @@ static int emu2_apply_t(int n_patches, const int32_t* coords, int H, int W, int 
       for (int t = 0; t < T; ++t) store_patch2<C>(t, R(t), ov, ov, 0, pr, pc, win.data(), qw, add, load4, load1, pstore4, pstore1);
     }
   }
+  if (direct == 2)
+    for (size_t i = 0; i < (size_t)H * W; ++i) out[i] = ((planes[i] + planes[i + pv.plane_stride]) + planes[i + 2 * pv.plane_stride]) + planes[i + 3 * pv.plane_stride];
   return 0;
 }
 

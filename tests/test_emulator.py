@@ -64,11 +64,12 @@ def emu2():
     return ctypes.CDLL(str(EMU2_LIB))
 
 
-@pytest.mark.parametrize("direct", [0, 1])
+@pytest.mark.parametrize("direct", [0, 1, 2])
 @pytest.mark.parametrize("case", [c[0] for c in APPLY_CASES if c[7] in MODES and c[3] >= 128])
 def test_emulated_second_generation_kernel_matches_reference_golden(emu2, case, direct):
     """direct = 1: quadrant by quadrant, the first patch over a lattice tile stores and the later ones accumulate
-    (what the tile flags arrange on the GPU); direct = 0: plain adds into a cleared image."""
+    (what the tile flags arrange on the GPU); direct = 0: plain adds into a cleared image; direct = 2: four colour planes
+    (16-byte stores, rim patches included where the image width allows) summed at the end."""
     fx, coords, k = load_apply_case(case)
     image = np.ascontiguousarray(fx["image"], np.float32)
     h, w = image.shape
@@ -81,3 +82,30 @@ def test_emulated_second_generation_kernel_matches_reference_golden(emu2, case, 
     assert rc == 0
     rel_max, rel_l2 = rel_errors(out, fx["expected"])
     assert rel_max <= 1e-5 and rel_l2 <= 1e-5, (rel_max, rel_l2)
+
+
+@pytest.mark.parametrize("mode", sorted(MODES))
+@pytest.mark.parametrize("shape", [(256, 384), (200, 250)])
+def test_emulated_rim_patches_every_pad_mode(emu2, mode, shape):
+    """Rim patches of the second-generation plans take 16-byte loads where the np.pad map keeps a unit of four pixels
+    together (ascending, or mirrored by 'symmetric') and pixel-by-pixel loads elsewhere; 16-byte plane stores where the
+    image width is a multiple of 4.  Every pad mode the kernel evaluates itself, an aligned and an unaligned width,
+    against the oracle."""
+    from oracle import regpsf_oracle as orc
+
+    n = 128
+    h, w = shape
+    rng = np.random.default_rng(5)
+    image = (100 + 5 * rng.standard_normal((h, w))).astype(np.float32)
+    coords = [tuple(int(v) for v in c) for c in orc.calculate_covering((h, w), n)]
+    k = (rng.standard_normal((len(coords), n, n)) + 1j * rng.standard_normal((len(coords), n, n))).astype(np.complex64)
+    expected = orc.apply_transfer(image, coords, k, pad_mode=mode)
+    c = np.ascontiguousarray(np.array(coords, np.int32))
+    vp = ctypes.c_void_p
+    for direct in (0, 2):
+        out = np.zeros((h, w), np.float32)
+        rc = emu2.emu2_apply(n, len(coords), c.ctypes.data_as(vp), h, w, MODES[mode], ctypes.c_float(0.0), image.ctypes.data_as(vp),
+                             k.ctypes.data_as(vp), out.ctypes.data_as(vp), direct)
+        assert rc == 0
+        rel_max, rel_l2 = rel_errors(out, expected)
+        assert rel_max <= 1e-5 and rel_l2 <= 1e-5, (mode, direct, rel_max, rel_l2)
