@@ -15,7 +15,7 @@ import sys
 
 PKG = pathlib.Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
-SOURCES = [CSRC / n for n in ("rpsf.hip", "k1_256.hip", "k1_128.hip", "k1_small.hip", "k2_256.hip", "k2_128.hip")]
+SOURCES = [CSRC / n for n in ("rpsf.hip", "k1_256.hip", "k1_128.hip", "k1_small.hip", "k2_256.hip", "k2_256p.hip", "k2_128.hip")]
 HEADERS = [CSRC / n for n in ("rpsf_core.hpp", "rpsf_core2.hpp", "rpsf_kernels.hpp", "rpsf_kernels2.hpp", "rpsf_device.hpp")] + [
     PKG.parent / "include" / "rpsf.h"]
 TARGET = PKG / "librpsf_hip.so"
@@ -28,6 +28,45 @@ def is_stale() -> bool:
         return True
     built = TARGET.stat().st_mtime
     return any(p.stat().st_mtime > built for p in SOURCES + HEADERS)
+
+
+def check_reentry_contract(obj: pathlib.Path, kernel: str = "patch_kernel2_256p") -> None:
+    """The persistent patch kernel jumps back to its own first instruction (RPSF_REENTER, csrc/rpsf_kernels2.hpp) and
+    rebuilds the state a fresh workgroup starts with: s[0:1] = kernarg segment pointer, s2 = workgroup id x, v0 = workitem
+    id x.  That is only right while the kernel descriptor asks the hardware for exactly these; read it back from the
+    built code object and fail the build otherwise."""
+    import struct
+    import tempfile
+
+    llvm = pathlib.Path("/opt/rocm/lib/llvm/bin")
+    with tempfile.TemporaryDirectory() as tmp:
+        fat, co = pathlib.Path(tmp) / "fat.bin", pathlib.Path(tmp) / "k.co"
+        subprocess.run([str(llvm / "llvm-objcopy"), "--dump-section", f".hip_fatbin={fat}", str(obj), str(pathlib.Path(tmp) / "x.o")], check=True)
+        subprocess.run([str(llvm / "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={fat}",
+                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
+        elf = co.read_bytes()
+    shoff, = struct.unpack_from("<Q", elf, 0x28)
+    shentsize, shnum, _ = struct.unpack_from("<HHH", elf, 0x3A)
+    secs = [struct.unpack_from("<IIQQQQIIQQ", elf, shoff + i * shentsize) for i in range(shnum)]
+    kd = None
+    for name_off, typ, _, addr, off, size, link, _, _, entsize in secs:
+        if typ not in (2, 11):  # SHT_SYMTAB, SHT_DYNSYM
+            continue
+        str_off = secs[link][4]
+        for j in range(size // entsize):
+            st_name, _, _, st_shndx, st_value, st_size = struct.unpack_from("<IBBHQQ", elf, off + j * entsize)
+            end = elf.index(b"\0", str_off + st_name)
+            if elf[str_off + st_name:end].decode() == kernel + ".kd":
+                sec = secs[st_shndx]
+                kd = elf[sec[4] + st_value - sec[3]:sec[4] + st_value - sec[3] + 64]
+    if kd is None or len(kd) != 64:
+        raise RuntimeError(f"{kernel}.kd not found in {obj}")
+    rsrc2, props = struct.unpack_from("<IH", kd, 52)
+    got = {"user_sgprs": (rsrc2 >> 1) & 31, "wg_id_x": (rsrc2 >> 7) & 1, "wg_id_y": (rsrc2 >> 8) & 1, "wg_id_z": (rsrc2 >> 9) & 1,
+           "wg_info": (rsrc2 >> 10) & 1, "workitem_id": (rsrc2 >> 11) & 3, "code_properties": props & 0x7F}
+    want = {"user_sgprs": 2, "wg_id_x": 1, "wg_id_y": 0, "wg_id_z": 0, "wg_info": 0, "workitem_id": 0, "code_properties": 0x08}
+    if got != want:
+        raise RuntimeError(f"{kernel}: the kernel descriptor no longer matches what RPSF_REENTER restores: {got} != {want}")
 
 
 def build(force: bool = False, verbose: bool = True, defines: tuple[str, ...] = (), target: pathlib.Path | None = None) -> pathlib.Path:
@@ -56,6 +95,7 @@ def build(force: bool = False, verbose: bool = True, defines: tuple[str, ...] = 
     workers = max(1, min(len(SOURCES), (os.cpu_count() or 2)))
     with concurrent.futures.ThreadPoolExecutor(workers) as pool:
         objs = list(pool.map(compile_one, SOURCES))
+    check_reentry_contract(next(o for o in objs if o.stem == "k2_256p"))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(out), *[str(o) for o in objs], "-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)

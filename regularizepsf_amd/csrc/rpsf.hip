@@ -110,6 +110,10 @@ struct rpsf_plan {
   bool no_fuse = false;
   int sum_first = 0;                 // summing workgroups that run beside the patches from the start (multiple of 8: one per XCD)
   bool fuse_pays = false;            // one workgroup per CU (N = 256): measured -5..6 % per apply; with four small ones per CU (N = 128) +3 %
+  // Persistent patch workgroups (patch_kernel2_256p; fused launches of the 256-pixel plan): per-XCD slot queues, never reset
+  bool persist = false;
+  uint32_t* d_xq = nullptr;          // 8 counters, one per 128-byte line
+  uint32_t xq_base[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint4* d_quads = nullptr;        // per processing-order slot: quadrant words (rpsf_core.hpp, store_patch_direct)
   uint8_t* d_tile_info = nullptr;  // per lattice tile: static side mask | 16 if any patch covers it
   uint32_t* d_flags = nullptr;     // per (frame, tile)
@@ -301,6 +305,8 @@ static int setup_lattice(rpsf_plan* p) {
     HIP_TRY(hipMemset(p->d_tile_done, 0, order.size() * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&p->d_sum_queue, sizeof(uint32_t)));
     HIP_TRY(hipMemset(p->d_sum_queue, 0, sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&p->d_xq, 8 * 32 * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(p->d_xq, 0, 8 * 32 * sizeof(uint32_t)));
   }
   if (p->direct_ok) {
     std::vector<uint4> quads(n);
@@ -530,6 +536,10 @@ extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int
     p->sum_first = n_patches >= 2048 ? 32 : n_patches >= 512 ? 8 : 0;  // (r02y: a band of 520 patches 130-138 us with 8, 131-146 with 32)
     if (const char* e = std::getenv("RPSF_SUM_FIRST")) p->sum_first = std::max(0, std::atoi(e)) / 8 * 8;
     p->fuse_pays = N >= 256 || std::getenv("RPSF_FUSE_ALWAYS") != nullptr;
+    p->persist = N == 256 && std::getenv("RPSF_NO_PERSIST") == nullptr;  // (profiles/r02ag: -3.7 % per apply at 4096^2)
+    if (p->persist)
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_kernel2_256p), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)Launch2<Cfg256v2>::LDS_BYTES));
     int rl = p->v2 ? dispatch_v2(N, [&]<class C>() -> int {
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_kernel2<C>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)Launch2<C>::LDS_BYTES));
@@ -615,6 +625,7 @@ extern "C" void rpsf_plan_destroy(rpsf_plan* p) {
   (void)hipFree(p->d_tile_done);
   (void)hipFree(p->d_sum_order);
   (void)hipFree(p->d_sum_queue);
+  (void)hipFree(p->d_xq);
   if (p->ev_busy) (void)hipEventDestroy(p->ev_busy);
   (void)hipHostFree(p->h_pin_in);
   (void)hipHostFree(p->h_pin_out);
@@ -789,8 +800,25 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
         ts.done = p->d_tile_done, ts.epoch = p->done_epoch;
         int nsum = std::max(8, std::min(n_tiles, p->round_capacity));  // at the tail: as many summing workgroups as the chip holds
         pp.sum_first = p->sum_first;
-        nsum += pp.sum_first;
         ts.queue = p->d_sum_queue, ts.queue_base = p->sum_queue_base;
+        if constexpr (std::is_same_v<C, Cfg256v2>) {
+          // persistent form: as many patch workgroups as the chip holds beside the summing ones; each works through the slots
+          // of its XCD's chunk and ends as a summing workgroup itself (no workgroups behind the patches)
+          const int rows = std::min(pp.chunk, std::max(0, (p->round_capacity - pp.sum_first) / 8));
+          if (p->persist && rows > 0) {
+            pp.persist = rows, pp.xq = p->d_xq;
+            for (int x = 0; x < 8; ++x) {
+              pp.xq_base[x] = p->xq_base[x];
+              p->xq_base[x] += (uint32_t)std::min(pp.chunk, std::max(0, p->n_patches - x * pp.chunk));  // draws of this launch
+            }
+            const int wgs = pp.sum_first + 8 * rows;
+            p->sum_queue_base += (uint32_t)(n_tiles + wgs);  // every workgroup draws one position past the end
+            patch_kernel2_256p<<<dim3((unsigned)wgs), dim3(Launch2<C>::WG), Launch2<C>::LDS_BYTES, st>>>(pp);
+            HIP_TRY(hipGetLastError());
+            return RPSF_OK;
+          }
+        }
+        nsum += pp.sum_first;
         p->sum_queue_base += (uint32_t)(n_tiles + nsum);  // every workgroup draws one position past the end
         blocks += (size_t)nsum;
       }

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#include <type_traits>
 
 #include "../../include/rpsf.h"
 #include "rpsf_core.hpp"

@@ -37,8 +37,12 @@ struct TileSum {
 // Raw buffer accesses, so that the compiler tracks them; a descriptor spans up to 4 GiB from `base`.
 typedef float rpsf_f4 __attribute__((ext_vector_type(4)));
 typedef int rpsf_i4 __attribute__((ext_vector_type(4)));
+// (the base is the same for every lane; saying so - readfirstlane - keeps the descriptor in scalar registers, otherwise the
+// compiler wraps every buffer access in a waterfall loop over the descriptor values it believes may differ between lanes)
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const float* base) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, -1, 0x00020000);
+  const uint64_t b = reinterpret_cast<uint64_t>(base);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((uint64_t)hi << 32) | lo), 0, -1, 0x00020000);
 }
 __device__ __forceinline__ rpsf_f4 plane_load16_wt(__amdgpu_buffer_rsrc_t r, size_t float_offset) {
   const rpsf_i4 q = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(float_offset * sizeof(float)), 0, /*sc1 | nt*/ 16 | 2);
@@ -166,6 +170,11 @@ struct PatchParams {
   uint32_t flag_epoch;        // 1 .. 2^24-1, new for every apply
   uint32_t n_tiles;
   int orphan_mod;             // testing aid: workgroups with seq % orphan_mod == 1 behave as if they ran on a foreign XCD
+  // persistent launch (patch_kernel2_256p): the grid is sum_first + 8 * persist workgroups; the resident ones start on
+  // slots [0, persist) of their XCD's chunk and draw the later ones from xq[xcd * 32] (one counter per XCD on a line of its own)
+  int persist;
+  uint32_t* xq;
+  uint32_t xq_base[8];
 };
 
 template <class C>

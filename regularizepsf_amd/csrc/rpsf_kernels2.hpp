@@ -40,26 +40,86 @@ __device__ __forceinline__ f32x4 load16_sc1(const float* base, size_t span_bytes
 #define ABL_BAR() lds_barrier()
 #endif
 
-template <class C>
-__global__ __launch_bounds__(Launch2<C>::WG, 2) void patch_kernel2(PatchParams p) {  // 2 waves per SIMD: 256 registers
+// Persistent form (fused plane sum only): a workgroup that has finished its patch takes the next slot of its XCD's chunk from
+// a queue and JUMPS BACK TO THE FIRST INSTRUCTION OF THE KERNEL with the state the hardware hands a fresh workgroup
+// (s[0:1] = kernarg segment, s2 = workgroup id x - the virtual block of the new slot -, v0 = workitem id x, exec = all lanes:
+// the kernel descriptor asks for nothing else; regularizepsf_amd/build.py checks that against the built code object).  To the
+// compiler the kernel stays straight-line code - a source-level loop costs it 60-650 B of scratch per lane and 15 % of the
+// kernel - and the 5 us between the last store of one workgroup and the first load of its successor (s_endpgm,
+// dispatch, kernarg and descriptor loads) shrink to the queue draw, which is in flight under the stores.
+// SYM must be the kernel's own (extern "C") symbol.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RPSF_REENTER(SYM, BLK_, TID_)                                                                      \
+  do {                                                                                                     \
+    const void* ka_ = __builtin_amdgcn_kernarg_segment_ptr();                                              \
+    asm volatile(                                                                                          \
+        "s_mov_b64 s[92:93], %[ka]\n\t"                                                                    \
+        "s_mov_b32 s94, %[blk]\n\t"                                                                        \
+        "v_mov_b32 v0, %[tid]\n\t"                                                                         \
+        "s_getpc_b64 s[90:91]\n"                                                                           \
+        "1:\n\t"                                                                                           \
+        "s_add_u32 s90, s90, " #SYM "-1b\n\t"                                                              \
+        "s_addc_u32 s91, s91, -1\n\t"                                                                      \
+        "s_mov_b64 s[0:1], s[92:93]\n\t"                                                                   \
+        "s_mov_b32 s2, s94\n\t"                                                                            \
+        "s_mov_b64 exec, -1\n\t"                                                                           \
+        "s_setpc_b64 s[90:91]\n\t" ::[ka] "s"(ka_),                                                        \
+        [blk] "s"(BLK_), [tid] "v"(TID_)                                                                   \
+        : "s90", "s91", "s92", "s93", "s94", "s0", "s1", "s2", "v0", "memory", "scc");                     \
+    __builtin_unreachable();                                                                               \
+  } while (0)
+#else
+#define RPSF_REENTER(SYM, BLK_, TID_) ((void)0)
+#endif
+struct NoReenter {
+  static constexpr bool enabled = false;
+  __device__ __forceinline__ void operator()(unsigned, unsigned) const {}
+};
+
+template <class C, class REENTER>
+__device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reenter) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int T = C::T, N = C::N;
+  constexpr bool PERSIST = std::remove_reference_t<REENTER>::enabled;
   const int t = threadIdx.x;
   // Fused plane sum: a few workgroups at the head of the grid sum finished tiles beside the patches for the whole
   // launch (the patches leave half of the HBM bandwidth unused), the ones at its tail take the CUs the partial last
   // round of patches leaves idle.  All of them draw tiles from one queue.
-  const int pb = (int)blockIdx.x - p.sum_first;  // workgroup-uniform
-  if (pb < 0 || pb >= p.patch_blocks) {
+  // (persistent form: bit 30 of the block index says that this is a re-entry - the tables are in LDS already and the park
+  // words hold the tiles of the previous patch, still to be counted)
+  const bool again = PERSIST && ((blockIdx.x >> 30) & 1u);
+  const int pb = (int)(blockIdx.x & 0x3fffffffu) - p.sum_first;  // workgroup-uniform
+  bool patchy = pb >= 0 && pb < p.patch_blocks;
+  int frame = 0, xrow = 0, seq = 0;
+  if (patchy) {
+    xrow = p.slot0 + (pb >> 3);
+    if (p.n_frames > 1) {
+      frame = xrow % p.n_frames;
+      xrow /= p.n_frames;
+    }
+    seq = (pb & 7) * p.chunk + xrow;
+    if (xrow >= p.chunk || seq >= p.n_patches) {  // workgroup-uniform
+      if constexpr (!PERSIST) return;
+      patchy = false;  // every workgroup of a persistent launch ends as a summing one
+    }
+  }
+  cf* const lds = reinterpret_cast<cf*>(smem + Launch2<C>::TABLE_FLOATS);
+  cf* const park = lds + C::BUF_UNITS;
+  // persistent form: the previous patch of this workgroup is counted on its tiles once its plane stores have drained
+  [[maybe_unused]] auto count_previous = [&]() RPSF_AI {
+    if (t < 4) __hip_atomic_fetch_add(p.tile_done + reinterpret_cast<const unsigned*>(park)[1 + t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  if (!patchy) {
+    if constexpr (PERSIST) {
+      if (again) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+        count_previous();
+      }
+    }
     sum_tiles_worker(p.ts, 0, 1);
     return;
   }
-  int frame = 0, xrow = p.slot0 + (pb >> 3);
-  if (p.n_frames > 1) {
-    frame = xrow % p.n_frames;
-    xrow /= p.n_frames;
-  }
-  const int seq = (pb & 7) * p.chunk + xrow;
-  if (xrow >= p.chunk || seq >= p.n_patches) return;  // workgroup-uniform
   ImageView im = p.im;
   OutView ov = p.ov;
   im.img += (size_t)frame * p.im_frame_floats;
@@ -80,14 +140,17 @@ __global__ __launch_bounds__(Launch2<C>::WG, 2) void patch_kernel2(PatchParams p
   cf* tw = reinterpret_cast<cf*>(smem);
   float* win = smem + 2 * N;
   uint32_t* ot = reinterpret_cast<uint32_t*>(smem + 3 * N);
-  cf* lds = reinterpret_cast<cf*>(smem + Launch2<C>::TABLE_FLOATS);
-  cf* park = lds + C::BUF_UNITS;
   // Table values first (VMEM returns in order: they arrive ahead of the pixels requested right behind them and are
   // put into LDS while the gather is in flight).
   static_assert(N <= 2 * T && Launch2<C>::OT_WORDS <= T, "one or two table entries per thread");
-  const cf tw0 = p.tw[t < N ? t : 0], tw1 = p.tw[t + T < N ? t + T : 0];
-  const float wn0 = p.win[t < N ? t : 0], wn1 = p.win[t + T < N ? t + T : 0];
-  const uint32_t ot0 = p.pairtab[t < Launch2<C>::OT_WORDS ? t : 0];
+  cf tw0 = {0.f, 0.f}, tw1 = {0.f, 0.f};
+  float wn0 = 0.f, wn1 = 0.f;
+  uint32_t ot0 = 0;
+  if (!again) {
+    tw0 = p.tw[t < N ? t : 0], tw1 = p.tw[t + T < N ? t + T : 0];
+    wn0 = p.win[t < N ? t : 0], wn1 = p.win[t + T < N ? t + T : 0];
+    ot0 = p.pairtab[t < Launch2<C>::OT_WORDS ? t : 0];
+  }
   GroupIds<C> gids;
   gids.load(p.tab, t);
   cf v[64];
@@ -103,9 +166,11 @@ __global__ __launch_bounds__(Launch2<C>::WG, 2) void patch_kernel2(PatchParams p
 #else
   load_raw2<C>(t, v, im, pr, pc, fast, maps);
 #endif
-  if (t < N) tw[t] = tw0, win[t] = wn0;
-  if (t + T < N) tw[t + T] = tw1, win[t + T] = wn1;
-  if (t < Launch2<C>::OT_WORDS) ot[t] = ot0;
+  if (!again) {
+    if (t < N) tw[t] = tw0, win[t] = wn0;
+    if (t + T < N) tw[t + T] = tw1, win[t + T] = wn1;
+    if (t < Launch2<C>::OT_WORDS) ot[t] = ot0;
+  }
   lds_barrier();  // tables staged; the maps (which share LDS with the exchange buffer) are no longer needed
   window_patch2<C>(t, v, win);
   STAMP(1);
@@ -134,6 +199,11 @@ __global__ __launch_bounds__(Launch2<C>::WG, 2) void patch_kernel2(PatchParams p
     StaticFor<0, C::ORBIT_ROUNDS>::run([&]<int R>() RPSF_AI { load_stream16(gs + (size_t)(R * 64 + t) * 2, ko[2 * R], ko[2 * R + 1]); });
   }
   ABL_BAR();  // every wave has left its X1 region (X2 uses the whole buffer)
+  if constexpr (PERSIST) {
+    // every wave has its pixels, so - VMEM returns in order - the plane stores of the workgroup's previous patch, issued
+    // ahead of them, are acknowledged: that patch can be counted on its tiles
+    if (again) count_previous();
+  }
   ABL_LDS(x2_mid_write2<C, 0>(t, v, lds));
   ABL_VALU(stage2h<C, 1, false>(t, v, tw));
   ABL_BAR();
@@ -224,11 +294,36 @@ __global__ __launch_bounds__(Launch2<C>::WG, 2) void patch_kernel2(PatchParams p
     // counted on its four tiles; the workgroups behind the patches in the grid sum a tile as soon as its count is complete.
     const float* pbase = ov.out;
     const __amdgpu_buffer_rsrc_t rsrc = plane_rsrc(pbase);
+    // persistent: the next slot of this XCD's chunk, drawn now so that the round trip hides under the stores (VMEM returns
+    // in order: the value is back before the stores are acknowledged).  xq counters are never reset: this launch owns the
+    // positions from xq_base[xcd] on, position 0 = slot p.persist (the first p.persist slots went to the resident workgroups)
+    unsigned drawn = 0, my_tile = 0;
+    if constexpr (PERSIST) {
+      if (t < 4) {  // (and the tiles this patch will be counted on: a load behind the stores would wait for them)
+        const uint4 q4 = p.quads[p.seq_base + seq];
+        my_tile = quad_tile(t == 0 ? q4.x : t == 1 ? q4.y : t == 2 ? q4.z : q4.w);
+      }
+      if (t == 0)
+        drawn = __hip_atomic_fetch_add(p.xq + (pb & 7) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.xq_base[pb & 7] + (unsigned)p.persist;
+    }
     store_patch2<C>(
         t, v, ov, ov, plane, pr, pc, win, nullptr, add, []<int R1, int C1>(const float* a) RPSF_AI { return *reinterpret_cast<const f32x4*>(a); },
         [](const float* a) { return *a; }, [=](float* a, f32x4 val) RPSF_AI { plane_store16_wt(rsrc, (size_t)(a - pbase), val); },
         [](float* a, float val) RPSF_AI { __hip_atomic_store(reinterpret_cast<unsigned*>(a), __float_as_uint(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); });
     STAMP(10);
+    if constexpr (PERSIST) {
+      // No drain here: the next patch's loads queue behind these stores anyway, and the patch is counted on its tiles from
+      // inside the next pass (count_previous), when the stores are known to have been acknowledged.
+      if (t == 0) *reinterpret_cast<unsigned*>(park) = drawn;  // (park: idle since the frequency step)
+      if (t < 4) reinterpret_cast<unsigned*>(park)[1 + t] = my_tile;
+      lds_barrier();
+      STAMP(12);
+      const unsigned nx = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const unsigned*>(park));
+      const int left = p.n_patches - (pb & 7) * p.chunk;  // slots of this XCD's chunk that hold a patch
+      // ... or, once the chunk is exhausted, a block index behind the patches: the workgroup sums tiles with the others
+      const bool more = (int)nx < (left < p.chunk ? left : p.chunk);
+      reenter(0x40000000u | ((unsigned)p.sum_first + (more ? ((nx << 3) | (unsigned)(pb & 7)) : (unsigned)p.patch_blocks)), (unsigned)t);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
     if (t < 4) {
@@ -243,6 +338,13 @@ __global__ __launch_bounds__(Launch2<C>::WG, 2) void patch_kernel2(PatchParams p
   }
   STAMP(13);
 }
+
+template <class C>
+__global__ __launch_bounds__(Launch2<C>::WG, 2) void patch_kernel2(PatchParams p) {  // 2 waves per SIMD: 256 registers
+  patch_body2<C>(p, NoReenter());
+}
+// the persistent form of the 256-pixel plan (instantiated in k2_256p.hip)
+extern "C" __global__ __launch_bounds__(512, 2) void patch_kernel2_256p(PatchParams p);
 
 // K pack: the caller's full complex64 K (n, N, N) -> folded pair words in the stream layout [word][thread], plus the
 // side array of the self-paired bin pairs

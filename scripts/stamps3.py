@@ -1,0 +1,37 @@
+"""Development aid: per-phase timing of the 256-pixel patch kernel (RPSF_STAMPS build), persistent form included: the gap
+between a workgroup's consecutive patches is measured on the timeline of start stamps.
+    RPSF_LIB=devlibs/stamps_p.so [RPSF_PERSIST=1] python scripts/stamps3.py [--size 4096]"""
+import argparse, pathlib, sys
+import numpy as np
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+from regularizepsf_amd import _native, calculate_covering
+ap = argparse.ArgumentParser()
+ap.add_argument("--size", type=int, default=4096)
+a = ap.parse_args()
+n, size = 256, a.size
+rng = np.random.default_rng(0)
+coords = [tuple(int(v) for v in t) for t in calculate_covering((size, size), n)]
+plan = _native.Plan(n, coords)
+k = np.empty((len(coords), n, n), np.complex64); k.real = rng.standard_normal(k.shape, dtype=np.float32); k.imag = rng.standard_normal(k.shape, dtype=np.float32)
+plan.set_transfer(k)
+img = (100 + 5 * rng.standard_normal((size, size), dtype=np.float32)).astype(np.float32)
+d_img = _native.DeviceBuffer(img.nbytes).upload(img); d_out = _native.DeviceBuffer(img.nbytes)
+geom = _native.Geometry.whole(size, size, 1)
+plan.apply_device_timed(d_img.ptr, d_out.ptr, geom, 5)
+tot, ker = plan.apply_device_timed(d_img.ptr, d_out.ptr, geom, 1)
+st = plan.debug_stamps().astype(np.int64)
+last = 13 if (st[:, 13] > st[:, 0]).all() else 12
+idx = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, last]
+names = ["setup+gather", "S1 + X1", "S2 h0", "X2 fwd", "freq_a", "freq_b", "X2 inv", "X1 inv", "S1 inv", "stores issued", "drain / barrier"]
+d = np.diff(st[:, idx], axis=1) * 0.01
+print(f"kernel {ker[0]*1e3:.1f} us; patches {len(st)}; stamp 0 -> {last}: mean {(st[:,last]-st[:,0]).mean()*0.01:.1f} us")
+for i, nm in enumerate(names):
+    print(f"  {nm:18s} mean {d[:, i].mean():6.2f}  p10 {np.percentile(d[:, i],10):6.2f}  p90 {np.percentile(d[:, i],90):6.2f} us")
+t0 = st[:, 0].min()
+start = np.sort((st[:, 0] - t0) * 0.01)
+end = np.sort((st[:, last] - t0) * 0.01)
+# the i-th start after the first 256 follows the (i-256)-th end (any workgroup): the gap between patches on one CU
+cap = 256 if len(st) > 256 else len(st)
+gaps = start[cap:] - end[: len(start) - cap]
+print(f"gap between an end stamp and the start stamp that takes its place: mean {gaps.mean():.2f}  p10 {np.percentile(gaps,10):.2f}  p90 {np.percentile(gaps,90):.2f} us")
+print("last end", end[-1].round(1), "us")

@@ -745,6 +745,36 @@ def test_fused_plane_sum_epochs_origins_and_fallback():
     assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("shape", [(768, 1024), (2048, 2304), (512, 512)])
+def test_persistent_patch_workgroups_bit_identical(shape):
+    """The fused launch of the 256-px plan keeps its patch workgroups resident: each draws the next slot of its XCD's chunk
+    from a queue and jumps back to the kernel's first instruction (the queues and the tile counters are never reset, the
+    previous patch is counted on its tiles from inside the next pass).  Repeated applies of one plan, more patches than the
+    chip holds workgroups (2048 x 2304: 323 > 256 - 8), fewer patches than XCDs have slots (512^2: 25) - against the oracle
+    and bit-identical to the one-patch-per-workgroup launch (RPSF_NO_PERSIST)."""
+    import os
+
+    from regularizepsf_amd import _native
+
+    n = 256
+    rng = np.random.default_rng(77)
+    coords = [tuple(int(v) for v in c) for c in rp.calculate_covering(shape, n)]
+    k = (rng.standard_normal((len(coords), n, n)) + 1j * rng.standard_normal((len(coords), n, n))).astype(np.complex64)
+    image = (rng.standard_normal(shape) * 10 + 30).astype(np.float32)
+    plan = _native.Plan(n, coords)
+    plan.set_transfer(k)
+    outs = [plan.apply(image, 1) for _ in range(4)]
+    check(outs[0].astype(np.float64), orc.apply_transfer(image, coords, k))
+    assert all(np.array_equal(o, outs[0]) for o in outs[1:])
+    os.environ["RPSF_NO_PERSIST"] = "1"
+    try:
+        plain = _native.Plan(n, coords)
+        plain.set_transfer(k)
+        assert np.array_equal(plain.apply(image, 1), outs[0])
+    finally:
+        del os.environ["RPSF_NO_PERSIST"]
+
+
 def test_device_resident_psf_to_transform_chain():
     """ArrayPSF(device=0) leaves the spectra on the GPU, construct() builds and packs K there, apply() runs -
     nothing but the PSF samples and the image crosses PCIe.  The host copies appear only when somebody looks at them, and
