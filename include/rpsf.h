@@ -72,7 +72,9 @@ int rpsf_plan_set_transfer_device(rpsf_plan* plan, const void* k_c64_device);
  * measured slower than the planes, kept for comparison). */
 int rpsf_plan_set_overlap_mode(rpsf_plan* plan, int mode);
 /* Start-up stagger of the patch kernel's first resident workgroups (microseconds, 0 = off): spreads
- * the gather / K-stream / store phases of different CUs in time so that HBM traffic overlaps compute. */
+ * the gather / K-stream / store phases of different CUs in time so that HBM traffic overlaps compute.
+ * Without this call the library decides: 10 us for the persistent launches of the 256-pixel plan from
+ * 1024 patches on, none otherwise. */
 int rpsf_plan_set_stagger(rpsf_plan* plan, int microseconds);
 /* Development aid: in builds compiled with -DRPSF_STAMPS the patch kernel records 16 phase
  * timestamps per patch (10 ns ticks); this copies them out.  All zeros in a normal build. */

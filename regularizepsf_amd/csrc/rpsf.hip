@@ -94,7 +94,7 @@ struct rpsf_plan {
   // overlap-add strategy: on regular half-overlap lattices direct accumulation through the XCD's L2 (three-stage
   // plans) or colour planes + plane sum (the small-patch plans); float atomics for any other corner list
   int overlap_mode = 0;  // 0 auto, 1 atomics, 2 planes, 3 direct
-  int stagger_us = 0, cu_count = 256;
+  int stagger_us = -1, cu_count = 256;  // -1: automatic (10 us for persistent launches of four rounds and more, else none)
   int round_capacity = 0;  // patches the chip holds at once (CUs x resident workgroups x patches per workgroup)
   bool lattice = false;
   bool direct_ok = false;  // lattice and one patch per workgroup
@@ -769,7 +769,7 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
     pp.tab = p->d_tab, pp.pairtab = p->d_pairtab, pp.tw = p->d_tw, pp.win = p->d_win, pp.g = p->d_g, pp.gs = p->d_gs;
     pp.stamps = p->d_stamps;
     pp.chunk = ((count + 7) / 8 + teams - 1) / teams * teams;  // patches per XCD, whole workgroups
-    pp.stagger_ticks = p->stagger_us * 100;
+    pp.stagger_ticks = std::max(0, p->stagger_us) * 100;
     pp.n_frames = b.frames, pp.im_frame_floats = b.im_stride;
     pp.ov_frame_floats = kind != OV_ATOMIC ? 4 * p->planes_floats : b.out_stride;
     pp.dv = OutView{nullptr, 0, 0, 0, 0, 0, 0, nullptr};
@@ -807,6 +807,9 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
           const int rows = std::min(pp.chunk, std::max(0, (p->round_capacity - pp.sum_first) / 8));
           if (p->persist && rows > 0) {
             pp.persist = rows, pp.xq = p->d_xq;
+            // persistent workgroups keep the phase they start with: holding the resident ones back by up to 10 us spreads the
+            // store bursts of the chip over the patch period (profiles/r02ai, r02ak: -2..3 % from four rounds of patches on)
+            if (p->stagger_us < 0 && p->n_patches >= 1024) pp.stagger_ticks = 1000;
             for (int x = 0; x < 8; ++x) {
               pp.xq_base[x] = p->xq_base[x];
               p->xq_base[x] += (uint32_t)std::min(pp.chunk, std::max(0, p->n_patches - x * pp.chunk));  // draws of this launch

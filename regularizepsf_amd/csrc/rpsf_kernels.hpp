@@ -44,13 +44,23 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const float* base) 
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
   return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((uint64_t)hi << 32) | lo), 0, -1, 0x00020000);
 }
+// Development-only timing experiments (results are wrong): RPSF_DEV_PLANE_WRAP=<bits> folds the plane offsets onto a window of
+// 2^bits floats (would planes that stay resident in the Infinity Cache be cheaper?); RPSF_DEV_PLANE_AUX overrides the cache policy.
+#if defined(RPSF_DEV_PLANE_WRAP)
+#define RPSF_PLANE_OFF(o) ((o) & ((size_t(1) << RPSF_DEV_PLANE_WRAP) - 1))
+#else
+#define RPSF_PLANE_OFF(o) (o)
+#endif
+#if !defined(RPSF_DEV_PLANE_AUX)
+#define RPSF_DEV_PLANE_AUX (16 | 2) /* sc1 | nt */
+#endif
 __device__ __forceinline__ rpsf_f4 plane_load16_wt(__amdgpu_buffer_rsrc_t r, size_t float_offset) {
-  const rpsf_i4 q = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(float_offset * sizeof(float)), 0, /*sc1 | nt*/ 16 | 2);
+  const rpsf_i4 q = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(RPSF_PLANE_OFF(float_offset) * sizeof(float)), 0, RPSF_DEV_PLANE_AUX);
   return rpsf_f4{__int_as_float(q.x), __int_as_float(q.y), __int_as_float(q.z), __int_as_float(q.w)};
 }
 __device__ __forceinline__ void plane_store16_wt(__amdgpu_buffer_rsrc_t r, size_t float_offset, rpsf_f4 v) {
   const rpsf_i4 q = {__float_as_int(v.x), __float_as_int(v.y), __float_as_int(v.z), __float_as_int(v.w)};
-  __builtin_amdgcn_raw_buffer_store_b128(q, r, (int)(float_offset * sizeof(float)), 0, /*sc1 | nt*/ 16 | 2);
+  __builtin_amdgcn_raw_buffer_store_b128(q, r, (int)(RPSF_PLANE_OFF(float_offset) * sizeof(float)), 0, RPSF_DEV_PLANE_AUX);
 }
 
 __device__ __forceinline__ void sum_tile(const TileSum& p, uint32_t tile, int tid, int nthreads) {

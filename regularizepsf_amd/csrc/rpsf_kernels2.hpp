@@ -129,7 +129,7 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   // Start-up stagger.  The workgroups of one round move in lock step otherwise - all CUs stream K at one moment, store at
   // another, and the memory system alternates between idle and saturated.  The first resident workgroup of each CU is
   // held back by a different fraction of stagger_ticks (later workgroups inherit the offset of the one they replace).
-  if (p.stagger_ticks > 0 && pb < p.stagger_blocks) {
+  if (p.stagger_ticks > 0 && pb < p.stagger_blocks && !again) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long wait = (unsigned long long)((((unsigned)pb >> 3) * 0x9E3779B1u >> 22) & 1023) * p.stagger_ticks >> 10;
     while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
