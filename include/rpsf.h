@@ -158,6 +158,20 @@ int rpsf_psf_fft(int device, int patch_size, int count, const float* values_host
  * of rpsf_build_transfer_device, so that ArrayPSF -> construct (psf.py:216-219 -> transform.py:78-82) -> apply never
  * moves a spectrum or K over PCIe. */
 int rpsf_psf_fft_device(int device, int patch_size, int count, const float* values_host, void* fft_c64_dev);
+/* Built-in parametric PSF models rasterised on the device (kernel K6) and transformed there: replaces the host loop of
+ * VariedFunctionalPSF.as_array_psf (regularizepsf/psf.py:159-165: one Python call of the model per patch on an N x N
+ * meshgrid) followed by ArrayPSF.__init__ (psf.py:216-219) for models the library knows, so that model parameters ->
+ * samples -> spectra -> K -> apply never leaves the GPU.  params_host: count x RPSF_MODEL_PARAMS doubles, per model
+ *   RPSF_MODEL_ELLIPTICAL_GAUSSIAN: amplitude, row0, col0, sigma_row, sigma_col, theta, background, unused
+ *   RPSF_MODEL_MOFFAT:              amplitude, row0, col0, alpha, beta, unused, background, unused
+ * Element [i][j] of a patch is the model at (row = j, col = i), as the reference's meshgrid hands it over.  normalize != 0
+ * scales every patch to unit sum.  values_f32_dev (optional, count * N * N floats) keeps the samples, fft_c64_dev
+ * (count * N * N complex64) receives the spectra; both allocated by the caller on `device`. */
+#define RPSF_MODEL_PARAMS 8
+#define RPSF_MODEL_ELLIPTICAL_GAUSSIAN 0
+#define RPSF_MODEL_MOFFAT 1
+int rpsf_psf_model_fft_device(int device, int model, int patch_size, int count, const double* params_host, int normalize,
+                              void* values_f32_dev, void* fft_c64_dev);
 
 /* Host-side helper for the saturation branch of apply (transform.py:135-138): sequential, row-major
  * NaN-ignoring neighbourhood-mean fill of the masked pixels of the float64 padded image (no GPU involved). */

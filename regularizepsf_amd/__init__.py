@@ -1,6 +1,7 @@
 """MI355X-native patch-wise Fourier PSF correction with the regularizepsf class API.
 
-Drop-in for the ``ArrayPSF`` / ``ArrayPSFTransform`` / ``IndexedCube`` / ``calculate_covering`` path of
+Drop-in for the ``ArrayPSF`` / ``ArrayPSFTransform`` / ``IndexedCube`` / ``calculate_covering`` path (and the functional
+PSF models that feed it) of
 punch-mission/regularizepsf (regularizepsf/__init__.py:5-16 re-exports the same names); the compute
 runs in hand-written HIP kernels behind the C ABI of include/rpsf.h.
 """
@@ -13,6 +14,14 @@ from regularizepsf_amd.exceptions import (
     InvalidFunctionError,
     PSFBuilderError,
     RegularizePSFError,
+)
+from regularizepsf_amd.functional import (
+    SimpleFunctionalPSF,
+    VariedFunctionalPSF,
+    elliptical_gaussian,
+    moffat,
+    simple_functional_psf,
+    varied_functional_psf,
 )
 from regularizepsf_amd.psf import ArrayPSF
 from regularizepsf_amd.transform import ArrayPSFTransform
@@ -31,5 +40,11 @@ __all__ = [
     "InvalidFunctionError",
     "PSFBuilderError",
     "RegularizePSFError",
+    "SimpleFunctionalPSF",
+    "VariedFunctionalPSF",
     "calculate_covering",
+    "elliptical_gaussian",
+    "moffat",
+    "simple_functional_psf",
+    "varied_functional_psf",
 ]

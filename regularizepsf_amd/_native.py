@@ -74,6 +74,7 @@ _PROTOTYPES = {
                                            c_void_p]),
     "rpsf_psf_fft": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p]),
     "rpsf_psf_fft_device": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rpsf_psf_model_fft_device": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "rpsf_saturation_fill": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int]),
     "rpsf_dev_alloc": (c_int, [c_int, c_size_t, POINTER(c_void_p)]),
     "rpsf_dev_free": (c_int, [c_int, c_void_p]),
@@ -339,6 +340,28 @@ def psf_fft_device(values: np.ndarray, device: int = 0) -> DeviceBuffer:
     if v.shape[0]:
         check(lib().rpsf_psf_fft_device(device, v.shape[1], v.shape[0], _ptr(v), out.ptr))
     return out
+
+
+MODEL_PARAMS = 8  # RPSF_MODEL_PARAMS
+MODELS = {"elliptical_gaussian": 0, "moffat": 1}  # RPSF_MODEL_*
+
+
+def psf_model_fft_device(model: str, patch_size: int, params: np.ndarray, normalize: bool = False, device: int = 0,
+                         keep_values: bool = True) -> tuple[DeviceBuffer | None, DeviceBuffer]:
+    """K6 + K3: rasterise a built-in parametric PSF model for every row of ``params`` (n, 8) on the device and transform the
+    samples there.  Returns (float32 samples or None, complex64 spectra), both device-resident (n, N, N)."""
+    q = np.ascontiguousarray(params, dtype=np.float64)
+    if q.ndim != 2 or q.shape[1] != MODEL_PARAMS:
+        msg = f"params must have shape (n, {MODEL_PARAMS})"
+        raise ValueError(msg)
+    count = q.shape[0]
+    per = patch_size * patch_size
+    values = DeviceBuffer(max(1, count * per * 4), device) if keep_values else None
+    spectra = DeviceBuffer(max(1, count * per * 8), device)
+    if count:
+        check(lib().rpsf_psf_model_fft_device(device, MODELS[model], patch_size, count, _ptr(q), int(bool(normalize)),
+                                              values.ptr if values is not None else None, spectra.ptr))
+    return values, spectra
 
 
 def saturation_fill(padded: np.ndarray, mask: np.ndarray, neighborhood_width: int) -> None:

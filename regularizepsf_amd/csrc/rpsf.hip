@@ -1339,8 +1339,12 @@ extern "C" int rpsf_build_transfer(int device, size_t count, const void* s_host,
 // K3 entry point
 // ------------------------------------------------------------------------------------------------
 // fft_host / fft_dev: exactly one is non-null - where the spectra go
-static int psf_fft_impl(int device, int patch_size, int count, const float* values_host, float* fft_host, void* fft_dev) {
-  if (!values_host || (!fft_host && !fft_dev)) return fail(RPSF_E_BADARG, "null argument");
+// model < 0: the samples come from values_host; otherwise they are rasterised on the device from params_host
+// (count x RPSF_MODEL_PARAMS doubles) and, if values_dev is given, kept there as float32 as well
+static int psf_fft_impl(int device, int patch_size, int count, const float* values_host, float* fft_host, void* fft_dev,
+                        int model = -1, const double* params_host = nullptr, int normalize = 0, void* values_dev = nullptr) {
+  if ((model < 0 ? !values_host : !params_host) || (!fft_host && !fft_dev)) return fail(RPSF_E_BADARG, "null argument");
+  if (model > MODEL_MOFFAT) return fail(RPSF_E_BADARG, "unknown PSF model");
   if (count <= 0) return count == 0 ? RPSF_OK : fail(RPSF_E_BADARG, "negative count");
   return dispatch_n(patch_size, [&]<class C>() -> int {
     HIP_TRY(hipSetDevice(device));
@@ -1348,20 +1352,31 @@ static int psf_fft_impl(int device, int patch_size, int count, const float* valu
     cf* d_tw = nullptr;
     int rc = upload_tables<C>(device, &d_tab, &d_tw, nullptr);
     if (rc != RPSF_OK) return rc;
-    DevBuf keep_tab, keep_tw, b_in, b_out;
+    DevBuf keep_tab, keep_tw, b_in, b_out, b_par;
     keep_tab.p = d_tab, keep_tw.p = d_tw;
     const size_t per = (size_t)C::N * C::N;
     int chunk = (int)std::max<size_t>(1, (size_t)(64u << 20) / (per * sizeof(cf)));
     if (chunk > count) chunk = count;
-    HIP_TRY(b_in.alloc(per * sizeof(float) * chunk));
+    if (!(model >= 0 && values_dev)) HIP_TRY(b_in.alloc(per * sizeof(float) * chunk));  // (rasterised straight into values_dev otherwise)
     if (!fft_dev) HIP_TRY(b_out.alloc(per * sizeof(cf) * chunk));
-    float* d_in = b_in.as<float>();
+    if (model >= 0) {
+      HIP_TRY(b_par.alloc(sizeof(double) * RPSF_MODEL_PARAMS_DEV * (size_t)count));
+      HIP_TRY(hipMemcpy(b_par.p, params_host, sizeof(double) * RPSF_MODEL_PARAMS_DEV * (size_t)count, hipMemcpyHostToDevice));
+    }
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&psf_fft_kernel<C>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)Launch<C>::LDS_BYTES));
     for (int first = 0; first < count && rc == RPSF_OK; first += chunk) {
       int cnt = std::min(chunk, count - first);
       cf* d_out = fft_dev ? static_cast<cf*>(fft_dev) + (size_t)first * per : b_out.as<cf>();
-      hipError_t e = hipMemcpy(d_in, values_host + (size_t)first * per, per * sizeof(float) * cnt, hipMemcpyHostToDevice);
+      float* d_in = model >= 0 && values_dev ? static_cast<float*>(values_dev) + (size_t)first * per : b_in.as<float>();
+      hipError_t e = hipSuccess;
+      if (model < 0) {
+        e = hipMemcpy(d_in, values_host + (size_t)first * per, per * sizeof(float) * cnt, hipMemcpyHostToDevice);
+      } else {
+        rasterize_kernel<<<dim3((unsigned)cnt), dim3(256), 0, nullptr>>>(model, C::N, b_par.as<double>() + (size_t)first * RPSF_MODEL_PARAMS_DEV,
+                                                                      normalize, d_in);
+        e = hipGetLastError();
+      }
       if (e != hipSuccess) { rc = fail(RPSF_E_HIP, hipGetErrorString(e)); break; }
       constexpr int TEAMS = Launch<C>::TEAMS;
       unsigned grid = (unsigned)((cnt + TEAMS - 1) / TEAMS);
@@ -1381,6 +1396,13 @@ extern "C" int rpsf_psf_fft(int device, int patch_size, int count, const float* 
 }
 extern "C" int rpsf_psf_fft_device(int device, int patch_size, int count, const float* values_host, void* fft_c64_dev) {
   return psf_fft_impl(device, patch_size, count, values_host, nullptr, fft_c64_dev);
+}
+static_assert(RPSF_MODEL_PARAMS == RPSF_MODEL_PARAMS_DEV && RPSF_MODEL_ELLIPTICAL_GAUSSIAN == MODEL_ELLIPTICAL_GAUSSIAN &&
+              RPSF_MODEL_MOFFAT == MODEL_MOFFAT, "rpsf.h and the kernel agree on the model table");
+extern "C" int rpsf_psf_model_fft_device(int device, int model, int patch_size, int count, const double* params_host,
+                                         int normalize, void* values_f32_dev, void* fft_c64_dev) {
+  if (model < 0) return fail(RPSF_E_BADARG, "unknown PSF model");
+  return psf_fft_impl(device, patch_size, count, nullptr, nullptr, fft_c64_dev, model, params_host, normalize, values_f32_dev);
 }
 
 // ------------------------------------------------------------------------------------------------

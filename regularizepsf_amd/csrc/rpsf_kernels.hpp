@@ -757,6 +757,43 @@ __global__ void build_transfer_kernel(const R* __restrict__ s, const R* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
+// K6: parametric PSF models rasterised on the sample grid of every patch (the built-in device models of
+// regularizepsf_amd/functional.py; the reference evaluates a Python callable per patch on the host,
+// regularizepsf/psf.py:65-70,159-165).  One workgroup per patch; element [i][j] of a patch is the model at row = j, col = i:
+// the reference hands np.meshgrid(arange, arange) - 'xy' indexing - to the model as (row, col).  Evaluated in float64 from
+// float64 parameters, stored as float32 (what the spectrum kernel K3 takes).  normalize: every patch is scaled to unit sum.
+enum PsfModel : int { MODEL_ELLIPTICAL_GAUSSIAN = 0, MODEL_MOFFAT = 1 };
+constexpr int RPSF_MODEL_PARAMS_DEV = 8;
+__device__ __forceinline__ double psf_model_value(int model, const double* __restrict__ q, double row, double col) {
+  const double dr = row - q[1], dc = col - q[2];
+  if (model == MODEL_ELLIPTICAL_GAUSSIAN) {  // q: amplitude, row0, col0, sigma_row, sigma_col, theta, background, -
+    const double ct = cos(q[5]), st = sin(q[5]);
+    const double u = dr * ct + dc * st, v = dc * ct - dr * st;
+    return q[6] + q[0] * exp(-0.5 * ((u * u) / (q[3] * q[3]) + (v * v) / (q[4] * q[4])));
+  }
+  // Moffat.  q: amplitude, row0, col0, alpha, beta, -, background, -
+  return q[6] + q[0] * pow(1.0 + (dr * dr + dc * dc) / (q[3] * q[3]), -q[4]);
+}
+__global__ __launch_bounds__(256) void rasterize_kernel(int model, int n, const double* __restrict__ params, int normalize,
+                                                        float* __restrict__ out) {
+  __shared__ double part[256];
+  const double* q = params + (size_t)blockIdx.x * RPSF_MODEL_PARAMS_DEV;
+  float* dst = out + (size_t)blockIdx.x * n * n;
+  double scale = 1.0;
+  if (normalize) {
+    double acc = 0.0;
+    for (int e = threadIdx.x; e < n * n; e += 256) acc += psf_model_value(model, q, (double)(e % n), (double)(e / n));
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {  // fixed tree: the sum does not depend on the launch
+      if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+      __syncthreads();
+    }
+    scale = 1.0 / part[0];
+  }
+  for (int e = threadIdx.x; e < n * n; e += 256) dst[e] = (float)(psf_model_value(model, q, (double)(e % n), (double)(e / n)) * scale);
+}
+
 // K4: accum[i] += src[i]
 // ------------------------------------------------------------------------------------------------
 __global__ void add_rows_kernel(float* __restrict__ accum, const float* __restrict__ src, size_t count) {

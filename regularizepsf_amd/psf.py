@@ -54,6 +54,18 @@ class ArrayPSF:
             msg = "Values cube and FFT cube have different coordinates"
             raise InvalidCoordinateError(msg)
 
+    @classmethod
+    def _from_device(cls, coordinates: list[tuple[int, int]], size: int, values_buf, fft_buf, device: int) -> "ArrayPSF":
+        """Samples and spectra that were produced on the GPU (regularizepsf_amd.functional, built-in device models): both
+        cubes are fetched only when somebody looks at them; ``construct`` uses the resident spectra."""
+        full = (len(coordinates), size, size)
+        self = cls.__new__(cls)
+        self._workers = None
+        self._values_cube = IndexedCube._deferred(coordinates, full, lambda: values_buf.download(full, np.float32))
+        self._fft_cube = IndexedCube._deferred(coordinates, full, lambda: fft_buf.download(full, np.complex64))
+        self._fft_dev = (fft_buf, device)
+        return self
+
     @property
     def coordinates(self) -> list[tuple[int, int]]:
         return self._values_cube.coordinates
@@ -120,3 +132,14 @@ class ArrayPSF:
             raise NotImplementedError(msg)
         msg = f"Unsupported file type {path.suffix}. Change to .h5 or .fits."
         raise NotImplementedError(msg)
+
+
+def __getattr__(name: str):
+    """The reference keeps its functional models in the same module (regularizepsf/psf.py:25-189); here they live in
+    regularizepsf_amd.functional, which needs ArrayPSF - resolve the upstream import path lazily."""
+    if name in ("SimpleFunctionalPSF", "VariedFunctionalPSF", "simple_functional_psf", "varied_functional_psf"):
+        from regularizepsf_amd import functional
+
+        return getattr(functional, name)
+    msg = f"module {__name__!r} has no attribute {name!r}"
+    raise AttributeError(msg)
