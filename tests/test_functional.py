@@ -80,6 +80,38 @@ def test_built_in_models_on_the_host():
     assert np.allclose(normal.values.sum(axis=(1, 2)), 1.0) and normal.values.dtype == np.float64
 
 
+def _golden():
+    import pathlib
+
+    from tests.golden import make_functional_golden as gen
+
+    return np.load(pathlib.Path(__file__).parent / "golden" / "functional.npz"), gen
+
+
+def test_as_array_psf_equals_the_reference_bit_for_bit():
+    """tests/golden/functional.npz holds what the reference's decorators and as_array_psf produce for the same callables:
+    the host route here gives the same samples and spectra, bit for bit."""
+    fx, gen = _golden()
+    simple = simple_functional_psf(lambda row, col, a=10: 100 * row + col + a)
+    assert np.array_equal(simple.as_array_psf([(0, 0), (1, 0)], 5, a=3).values, fx["simple_values"])
+    coords = [tuple(int(v) for v in c) for c in fx["coords"]]
+    for name, base, field in (("gaussian", rp.elliptical_gaussian, gen.gaussian_field), ("moffat", rp.moffat, gen.moffat_field)):
+        arr = varied_functional_psf(base)(field).as_array_psf(coords, int(fx["size"]))
+        assert arr.values.dtype == np.float64 and np.array_equal(arr.values, fx[f"{name}_values"])
+        assert np.array_equal(arr.fft_evaluations, fx[f"{name}_fft"])
+
+
+@pytest.mark.gpu
+def test_device_rasterisation_against_the_reference_golden():
+    fx, gen = _golden()
+    coords = [tuple(int(v) for v in c) for c in fx["coords"]]
+    for name, base, field in (("gaussian", rp.elliptical_gaussian, gen.gaussian_field), ("moffat", rp.moffat, gen.moffat_field)):
+        dev = varied_functional_psf(base)(field).as_array_psf(coords, int(fx["size"]), device=0)
+        want, want_fft = fx[f"{name}_values"], fx[f"{name}_fft"]
+        assert np.abs(dev.values - want).max() <= 2e-7 * np.abs(want).max()
+        assert np.abs(dev.fft_evaluations - want_fft).max() <= 1e-5 * np.abs(want_fft).max()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("model", ["elliptical_gaussian", "moffat"])
 def test_device_rasterisation_matches_the_host_formula(model):
