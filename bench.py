@@ -494,7 +494,7 @@ def main() -> None:
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
             "frac_of_measured_copy_ceiling": round(achieved / MEASURED_COPY_GBS, 4),
-            "kernel": "patch_kernel2" if n in (128, 256) else "patch_kernel",
+            "kernel": "patch_kernel2_256p" if n == 256 else "patch_kernel2" if n == 128 else "patch_kernel",
             "whole_apply_ms": round(step_ms, 4), "kernel_avg_ms": round(kern_avg_ms, 4), "kernel_launches": iters,
             "frac_patch_kernel_only": round(achieved_kernel / HBM_PEAK_GBS, 4),
             "algorithmic_bytes": int(alg_bytes), "packed_k_bytes": int(plan.transfer_bytes),
