@@ -124,7 +124,12 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   OutView ov = p.ov;
   im.img += (size_t)frame * p.im_frame_floats;
   ov.out += (size_t)frame * p.ov_frame_floats;
-  const int4 dsc = p.desc[p.seq_base + seq];
+  // The slot descriptor through the scalar cache (a constant-address-space load of a uniform address): as a vector load it
+  // would queue behind the plane stores of the workgroup's previous patch - VMEM returns in order - and the gather, which
+  // needs the corner, would not even be issued before those stores are acknowledged.
+  typedef const int __attribute__((address_space(4))) cint_as4;
+  const cint_as4* dptr = (const cint_as4*)(const void*)(p.desc + (p.seq_base + seq));
+  const int4 dsc = make_int4(dptr[0], dptr[1], dptr[2], dptr[3]);
   const int patch = dsc.z;
   // Start-up stagger.  The workgroups of one round move in lock step otherwise - all CUs stream K at one moment, store at
   // another, and the memory system alternates between idle and saturated.  The first resident workgroup of each CU is
