@@ -76,6 +76,10 @@ int rpsf_plan_set_overlap_mode(rpsf_plan* plan, int mode);
  * Without this call the library decides: 10 us for the persistent launches of the 256-pixel plan from
  * 1024 patches on, none otherwise. */
 int rpsf_plan_set_stagger(rpsf_plan* plan, int microseconds);
+/* The persistent launch of the 256-pixel plan keeps one workgroup on every CU until its patches are done, so a kernel
+ * enqueued beside it on another stream - RCCL's send/recv of the seam rows (rpsf_comm_seam_exchange) - would wait for the
+ * first of them to finish.  `cus` CUs (0..128; 8 is what the sharded apply asks for) are left without a patch workgroup. */
+int rpsf_plan_set_reserved_cus(rpsf_plan* plan, int cus);
 /* Development aid: in builds compiled with -DRPSF_STAMPS the patch kernel records 16 phase
  * timestamps per patch (10 ns ticks); this copies them out.  All zeros in a normal build. */
 int rpsf_plan_debug_stamps(rpsf_plan* plan, unsigned long long* host, size_t count);

@@ -58,6 +58,7 @@ _PROTOTYPES = {
     "rpsf_plan_transfer_bytes": (c_int, [c_void_p, POINTER(c_size_t)]),
     "rpsf_plan_set_overlap_mode": (c_int, [c_void_p, c_int]),
     "rpsf_plan_set_stagger": (c_int, [c_void_p, c_int]),
+    "rpsf_plan_set_reserved_cus": (c_int, [c_void_p, c_int]),
     "rpsf_plan_debug_stamps": (c_int, [c_void_p, c_void_p, c_size_t]),
     "rpsf_apply": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "rpsf_apply_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int]),
@@ -207,6 +208,10 @@ class Plan:
 
     def set_stagger(self, microseconds: int) -> None:
         check(lib().rpsf_plan_set_stagger(self._handle, int(microseconds)))
+
+    def set_reserved_cus(self, cus: int) -> None:
+        """Persistent launches leave ``cus`` CUs free for kernels enqueued beside them (the RCCL seam exchange)."""
+        check(lib().rpsf_plan_set_reserved_cus(self._handle, int(cus)))
 
     @property
     def transfer_bytes(self) -> int:

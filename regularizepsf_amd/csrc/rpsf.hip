@@ -112,6 +112,7 @@ struct rpsf_plan {
   bool fuse_pays = false;            // one workgroup per CU (N = 256): measured -5..6 % per apply; with four small ones per CU (N = 128) +3 %
   // Persistent patch workgroups (patch_kernel2_256p; fused launches of the 256-pixel plan): per-XCD slot queues, never reset
   bool persist = false;
+  int reserved_cus = 0;              // persistent launches leave this many CUs without a patch workgroup (rpsf_plan_set_reserved_cus)
   uint32_t* d_xq = nullptr;          // 8 counters, one per 128-byte line
   uint32_t xq_base[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint4* d_quads = nullptr;        // per processing-order slot: quadrant words (rpsf_core.hpp, store_patch_direct)
@@ -804,7 +805,7 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
         if constexpr (std::is_same_v<C, Cfg256v2>) {
           // persistent form: as many patch workgroups as the chip holds beside the summing ones; each works through the slots
           // of its XCD's chunk and ends as a summing workgroup itself (no workgroups behind the patches)
-          const int rows = std::min(pp.chunk, std::max(0, (p->round_capacity - pp.sum_first) / 8));
+          const int rows = std::min(pp.chunk, std::max(1, (p->round_capacity - pp.sum_first - p->reserved_cus) / 8));
           if (p->persist && rows > 0) {
             pp.persist = rows, pp.xq = p->d_xq;
             // persistent workgroups keep the phase they start with: holding the resident ones back by up to 10 us spreads the
@@ -1022,6 +1023,12 @@ extern "C" int rpsf_plan_debug_stamps(rpsf_plan* p, unsigned long long* host, si
   HIP_TRY(hipDeviceSynchronize());
   count = std::min(count, (size_t)16 * p->n_patches);
   HIP_TRY(hipMemcpy(host, p->d_stamps, count * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return RPSF_OK;
+}
+
+extern "C" int rpsf_plan_set_reserved_cus(rpsf_plan* p, int cus) {
+  if (!p || cus < 0 || cus > 128) return fail(RPSF_E_BADARG, "reserved CUs must be 0..128");
+  p->reserved_cus = cus;
   return RPSF_OK;
 }
 

@@ -166,6 +166,10 @@ class ShardedApply:
         self.d_recv = _native.DeviceBuffer(max(1, b.recv_rows) * width * 4, device)
         if self.overlap:
             pm = _native.PAD_MODES[pad_mode]
+            if comm is not None:
+                # the main plan's persistent workgroups would otherwise hold every CU until their patches are done, and the
+                # send/recv kernels of the seam exchange - enqueued beside them - would start only then
+                self.plan.set_reserved_cus(8)
             # main plan: output window = the rows this band owns (the spill is the seam plan's business)
             self.geometry = _native.Geometry(height, width, pm, 0.0, 0, 0, b.image_row0, b.image_rows, width,
                                              b.out_row0, b.own_rows, width)

@@ -1,6 +1,6 @@
 """Development aid: device time of every row band of BASELINE config 4 (8192^2 / 256) at world 1/2/4/8, one band at a time on
 one GPU (no seam transport: the local apply only), and of 3968^2 vs 4096^2 frames (whole rounds vs a partial last round).
-    python scripts/band_times.py"""
+    python scripts/band_times.py [reserved CUs]   (as ShardedApply reserves them for the seam exchange when it has a communicator)"""
 import json, pathlib, sys
 import numpy as np
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
@@ -31,6 +31,8 @@ for world in (1, 2, 4, 8):
     times = []
     for rank in range(world):
         sh = ShardedApply(coords, lambda idx: np.resize(kk, (len(idx), n, n)), n, h, w, rank, world, 0, None)
+        if len(sys.argv) > 1:
+            sh.plan.set_reserved_cus(int(sys.argv[1]))
         b = sh.band
         sh.upload_rows(image[b.image_row0:b.image_row0 + b.image_rows])
         sh.plan.apply_device_timed(sh.d_img.ptr, sh.d_out.ptr, sh.geometry, 3)
