@@ -766,6 +766,11 @@ def test_persistent_patch_workgroups_bit_identical(shape):
     outs = [plan.apply(image, 1) for _ in range(4)]
     check(outs[0].astype(np.float64), orc.apply_transfer(image, coords, k))
     assert all(np.array_equal(o, outs[0]) for o in outs[1:])
+    plan.set_reserved_cus(8)  # what the sharded apply asks for when RCCL kernels have to run beside the launch
+    assert np.array_equal(plan.apply(image, 1), outs[0])
+    plan.set_reserved_cus(0)
+    plan.set_stagger(0)
+    assert np.array_equal(plan.apply(image, 1), outs[0])
     os.environ["RPSF_NO_PERSIST"] = "1"
     try:
         plain = _native.Plan(n, coords)
