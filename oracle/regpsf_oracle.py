@@ -8,7 +8,7 @@ no CPU fallback.
 
 Parity status: PINNED.  ``tests/test_oracle_golden.py`` checks every function here
 against fixtures under ``tests/golden/`` that were produced by importing the real
-reference in the build container (``scripts/make_golden.py``), bit-for-bit for the
+reference in the build container (``tests/golden/make_golden.py``), bit-for-bit for the
 ``apply`` restatement (np.array_equal) and for ``calculate_covering``.
 
 Each function cites the reference lines it follows (paths relative to the reference
