@@ -112,6 +112,10 @@ struct rpsf_plan {
   bool fuse_pays = false;            // one workgroup per CU (N = 256): measured -5..6 % per apply; with four small ones per CU (N = 128) +3 %
   // Persistent patch workgroups (patch_kernel2_256p; fused launches of the 256-pixel plan): per-XCD slot queues, never reset
   bool persist = false;
+  // Co-resident summing waves (sum_waves_kernel): a second stream and the events that tie it to the apply's stream
+  bool cosum = false;
+  hipStream_t st_sum = nullptr;
+  hipEvent_t ev_sum_go = nullptr, ev_sum_done = nullptr;
   int reserved_cus = 0;              // persistent launches leave this many CUs without a patch workgroup (rpsf_plan_set_reserved_cus)
   uint32_t* d_xq = nullptr;          // 8 counters, one per 128-byte line
   uint32_t xq_base[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -541,6 +545,14 @@ extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int
     if (p->persist)
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_kernel2_256p), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)Launch2<Cfg256v2>::LDS_BYTES));
+#if defined(RPSF_VGPR_CAP)  // (development builds only: the product's patch kernel takes all 512 registers of a SIMD lane)
+    p->cosum = p->persist && std::getenv("RPSF_COSUM") != nullptr;
+#endif
+    if (p->cosum) {
+      HIP_TRY(hipStreamCreateWithFlags(&p->st_sum, hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&p->ev_sum_go, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&p->ev_sum_done, hipEventDisableTiming));
+    }
     int rl = p->v2 ? dispatch_v2(N, [&]<class C>() -> int {
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_kernel2<C>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)Launch2<C>::LDS_BYTES));
@@ -627,6 +639,9 @@ extern "C" void rpsf_plan_destroy(rpsf_plan* p) {
   (void)hipFree(p->d_sum_order);
   (void)hipFree(p->d_sum_queue);
   (void)hipFree(p->d_xq);
+  if (p->ev_sum_go) (void)hipEventDestroy(p->ev_sum_go);
+  if (p->ev_sum_done) (void)hipEventDestroy(p->ev_sum_done);
+  if (p->st_sum) (void)hipStreamDestroy(p->st_sum);
   if (p->ev_busy) (void)hipEventDestroy(p->ev_busy);
   (void)hipHostFree(p->h_pin_in);
   (void)hipHostFree(p->h_pin_out);
@@ -805,6 +820,7 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
         if constexpr (std::is_same_v<C, Cfg256v2>) {
           // persistent form: as many patch workgroups as the chip holds beside the summing ones; each works through the slots
           // of its XCD's chunk and ends as a summing workgroup itself (no workgroups behind the patches)
+          if (p->cosum) pp.sum_first = 0;  // the summing is done by waves beside the patch workgroups: every CU takes patches
           const int rows = std::min(pp.chunk, std::max(1, (p->round_capacity - pp.sum_first - p->reserved_cus) / 8));
           if (p->persist && rows > 0) {
             pp.persist = rows, pp.xq = p->d_xq;
@@ -816,9 +832,22 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
               p->xq_base[x] += (uint32_t)std::min(pp.chunk, std::max(0, p->n_patches - x * pp.chunk));  // draws of this launch
             }
             const int wgs = pp.sum_first + 8 * rows;
-            p->sum_queue_base += (uint32_t)(n_tiles + wgs);  // every workgroup draws one position past the end
+            const int ncos = p->cosum ? p->cu_count : 0;  // one workgroup of summing waves per CU
+            p->sum_queue_base += (uint32_t)(n_tiles + wgs + ncos);  // every workgroup draws one position past the end
+            if (ncos) {  // the summing waves may start once everything before this apply on `st` is done ...
+              HIP_TRY(hipEventRecord(p->ev_sum_go, st));
+              HIP_TRY(hipStreamWaitEvent(p->st_sum, p->ev_sum_go, 0));
+            }
             patch_kernel2_256p<<<dim3((unsigned)wgs), dim3(Launch2<C>::WG), Launch2<C>::LDS_BYTES, st>>>(pp);
             HIP_TRY(hipGetLastError());
+            if (ncos) {  // ... and the apply is complete on `st` when they are
+#if defined(RPSF_VGPR_CAP)
+              sum_waves_kernel<<<dim3((unsigned)ncos), dim3(256), 16 << 10, p->st_sum>>>(pp.ts);
+#endif
+              HIP_TRY(hipGetLastError());
+              HIP_TRY(hipEventRecord(p->ev_sum_done, p->st_sum));
+              HIP_TRY(hipStreamWaitEvent(st, p->ev_sum_done, 0));
+            }
             return RPSF_OK;
           }
         }
@@ -1025,6 +1054,30 @@ extern "C" int rpsf_plan_debug_stamps(rpsf_plan* p, unsigned long long* host, si
   HIP_TRY(hipMemcpy(host, p->d_stamps, count * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return RPSF_OK;
 }
+
+#if defined(RPSF_DEV_PROBE)
+// Development probe: do the workgroups of a small second kernel (<= 16 registers, 16 KiB of LDS, 4 waves) get CUs while the
+// persistent patch kernel holds one workgroup on every CU?  Every probe workgroup records when and where it started.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(8))) void probe_kernel(unsigned long long* out, int spin_us) {
+  extern __shared__ float probe_lds[];
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) {
+    unsigned hw = 0, xcc = 0;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    out[2 * blockIdx.x] = t0;
+    out[2 * blockIdx.x + 1] = ((unsigned long long)xcc << 32) | hw;
+    probe_lds[0] = 1.f;
+  }
+  while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)spin_us * 100) __builtin_amdgcn_s_sleep(16);
+}
+extern "C" int rpsf_dev_probe(int device, int blocks, int spin_us, void* out_dev, void* stream) {
+  HIP_TRY(hipSetDevice(device));
+  probe_kernel<<<dim3((unsigned)blocks), dim3(256), 16 << 10, reinterpret_cast<hipStream_t>(stream)>>>(static_cast<unsigned long long*>(out_dev), spin_us);
+  HIP_TRY(hipGetLastError());
+  return RPSF_OK;
+}
+#endif
 
 extern "C" int rpsf_plan_set_reserved_cus(rpsf_plan* p, int cus) {
   if (!p || cus < 0 || cus > 128) return fail(RPSF_E_BADARG, "reserved CUs must be 0..128");

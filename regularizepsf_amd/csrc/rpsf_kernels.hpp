@@ -794,6 +794,63 @@ __global__ __launch_bounds__(256) void rasterize_kernel(int model, int n, const 
   for (int e = threadIdx.x; e < n * n; e += 256) dst[e] = (float)(psf_model_value(model, q, (double)(e % n), (double)(e / n)) * scale);
 }
 
+#if defined(RPSF_VGPR_CAP)
+// K5c (development builds with -DRPSF_VGPR_CAP=124 only; measured, not adopted - DESIGN.md 5.1): the plane sum as waves that run
+// BESIDE the persistent patch kernel (fused launches of the 256-pixel plan).  With the cap that kernel is
+// built at 248 registers, which leaves 16 per lane and SIMD - one more wave - and 19 KiB of LDS on every CU; a workgroup of this
+// kernel is four such waves (<= 16 registers, 16 KiB of LDS: exactly one fits beside a patch workgroup), launched on a second
+// stream, and the dispatcher places one on every CU (scripts/probe_coresidency.py).  It draws tiles from the same queue as the
+// summing workgroups of the patch launch and waits for a tile's contributors the same way; the plane values travel global -> LDS
+// by LDS-DMA (no registers for data in flight: 4 KiB per wave and pass) and are added in the fixed colour order, so the result is
+// bit-identical to every other form of the sum.  Geometry as for the fused sum: image edges and lattice origin multiples of 32 floats.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(8))) void sum_waves_kernel(TileSum p) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) float sw_stage[];  // [wave][plane][64 lanes x 4 floats]
+  __shared__ uint32_t sw_next;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* mine = sw_stage + wave * (4 * 256);
+  for (;;) {
+    if (threadIdx.x == 0) sw_next = __hip_atomic_fetch_add(p.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.queue_base;
+    __syncthreads();
+    const uint32_t i = __builtin_amdgcn_readfirstlane(sw_next);
+    __syncthreads();
+    if (i >= (uint32_t)p.count) return;
+    const uint32_t tile = __builtin_amdgcn_readfirstlane(p.tiles[i]);
+    const int cov = __builtin_amdgcn_readfirstlane((int)p.cover[tile]);
+    if (threadIdx.x == 0) {
+      const uint32_t want = p.epoch * (uint32_t)__builtin_popcount(cov & 15);
+      while (__hip_atomic_load(p.done + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) __builtin_amdgcn_s_sleep(8);
+    }
+    __syncthreads();
+    const int ti = tile / p.ntj, tj = tile % p.ntj;
+    const int y0 = max(p.lat_r0 + ti * p.half, p.row0), y1 = min(p.lat_r0 + (ti + 1) * p.half, p.row0 + p.rows);
+    const int x0 = max(p.lat_c0 + tj * p.half, 0), x1 = min(p.lat_c0 + (tj + 1) * p.half, p.W);
+    if (y0 >= y1 || x0 >= x1) continue;
+    const int x = x0 + ((lane & 31) << 2);
+    for (int yb = y0 + 2 * wave; yb < y1; yb += 8) {  // wave-uniform trip count; lanes 0-31 take row yb, lanes 32-63 row yb + 1
+      const int y = yb + (lane >> 5);
+      const bool on = y < y1 && x < x1;
+      const uint32_t off = (uint32_t)(y - p.row0) * (uint32_t)p.ld_planes + (uint32_t)x;  // floats (the planes of a fused launch are < 4 GiB)
+      if (on) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if ((cov >> k) & 1)
+            __builtin_amdgcn_global_load_lds(p.planes + k * p.plane_stride + off, (__attribute__((address_space(3))) float*)(mine + k * 256), 16, 0,
+                                             /*sc1 | nt*/ 16 | 2);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (on) {
+        f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if ((cov >> k) & 1) acc += *reinterpret_cast<const f4*>(mine + k * 256 + lane * 4);
+        __builtin_nontemporal_store(acc, reinterpret_cast<f4*>(p.out + (size_t)(y - p.row0) * p.ld_out + x));
+      }
+    }
+  }
+}
+#endif  // RPSF_VGPR_CAP
+
 // K4: accum[i] += src[i]
 // ------------------------------------------------------------------------------------------------
 __global__ void add_rows_kernel(float* __restrict__ accum, const float* __restrict__ src, size_t count) {

@@ -349,7 +349,14 @@ __global__ __launch_bounds__(Launch2<C>::WG, 2) void patch_kernel2(PatchParams p
   patch_body2<C>(p, NoReenter());
 }
 // the persistent form of the 256-pixel plan (instantiated in k2_256p.hip)
-extern "C" __global__ __launch_bounds__(512, 2) void patch_kernel2_256p(PatchParams p);
+// (RPSF_VGPR_CAP: development builds that leave registers for co-resident waves of another kernel; the attribute counts the
+// unified register file in halves, so 124 caps the kernel at 248)
+#if defined(RPSF_VGPR_CAP)
+#define RPSF_VGPR_ATTR __attribute__((amdgpu_num_vgpr(RPSF_VGPR_CAP)))
+#else
+#define RPSF_VGPR_ATTR
+#endif
+extern "C" __global__ __launch_bounds__(512, 2) RPSF_VGPR_ATTR void patch_kernel2_256p(PatchParams p);
 
 // K pack: the caller's full complex64 K (n, N, N) -> folded pair words in the stream layout [word][thread], plus the
 // side array of the self-paired bin pairs
