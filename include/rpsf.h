@@ -73,7 +73,7 @@ int rpsf_plan_set_transfer_device(rpsf_plan* plan, const void* k_c64_device);
 int rpsf_plan_set_overlap_mode(rpsf_plan* plan, int mode);
 /* Start-up stagger of the patch kernel's first resident workgroups (microseconds, 0 = off): spreads
  * the gather / K-stream / store phases of different CUs in time so that HBM traffic overlaps compute.
- * Without this call the library decides: 10 us for the persistent launches of the 256-pixel plan from
+ * Without this call the library decides: 12 us for the persistent launches of the 256-pixel plan from
  * 1024 patches on, none otherwise. */
 int rpsf_plan_set_stagger(rpsf_plan* plan, int microseconds);
 /* The persistent launch of the 256-pixel plan keeps one workgroup on every CU until its patches are done, so a kernel

@@ -94,7 +94,7 @@ struct rpsf_plan {
   // overlap-add strategy: on regular half-overlap lattices direct accumulation through the XCD's L2 (three-stage
   // plans) or colour planes + plane sum (the small-patch plans); float atomics for any other corner list
   int overlap_mode = 0;  // 0 auto, 1 atomics, 2 planes, 3 direct
-  int stagger_us = -1, cu_count = 256;  // -1: automatic (10 us for persistent launches of four rounds and more, else none)
+  int stagger_us = -1, cu_count = 256;  // -1: automatic (12 us for persistent launches of four rounds and more, else none)
   int round_capacity = 0;  // patches the chip holds at once (CUs x resident workgroups x patches per workgroup)
   bool lattice = false;
   bool direct_ok = false;  // lattice and one patch per workgroup
@@ -538,8 +538,11 @@ extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int
     p->v2 = has_v2(N);
     p->no_fuse = std::getenv("RPSF_NO_FUSE") != nullptr;
     // (measured, profiles/r02u, r02v: 32 of them are worth -1 % at 4096^2 and -2.5 % at 8192^2; 48 cost more patch time than they hide)
-    p->sum_first = n_patches >= 2048 ? 32 : n_patches >= 512 ? 8 : 0;  // (r02y: a band of 520 patches 130-138 us with 8, 131-146 with 32)
+    // (r02y: a band of 520 patches 130-138 us with 8, 131-146 with 32; r02av, plane stores kept in the Infinity Cache: 4096^2 0.193 / 0.190 /
+    // 0.196 ms with 8 / 16 / 24, 8192^2 0.78 / 0.77 / 0.74 / 0.765 ms with 8 / 16 / 32 / 48 - the sooner a tile is summed, the likelier its planes are still cached)
+    p->sum_first = n_patches >= 2048 ? 32 : n_patches >= 1024 ? 16 : n_patches >= 512 ? 8 : 0;
     if (const char* e = std::getenv("RPSF_SUM_FIRST")) p->sum_first = std::max(0, std::atoi(e)) / 8 * 8;
+    if (const char* e = std::getenv("RPSF_STAGGER_US")) p->stagger_us = std::max(0, std::atoi(e));  // development sweeps
     p->fuse_pays = N >= 256 || std::getenv("RPSF_FUSE_ALWAYS") != nullptr;
     p->persist = N == 256 && std::getenv("RPSF_NO_PERSIST") == nullptr;  // (profiles/r02ag: -3.7 % per apply at 4096^2)
     if (p->persist)
@@ -825,8 +828,9 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
           if (p->persist && rows > 0) {
             pp.persist = rows, pp.xq = p->d_xq;
             // persistent workgroups keep the phase they start with: holding the resident ones back by up to 10 us spreads the
-            // store bursts of the chip over the patch period (profiles/r02ai, r02ak: -2..3 % from four rounds of patches on)
-            if (p->stagger_us < 0 && p->n_patches >= 1024) pp.stagger_ticks = 1000;
+            // store bursts of the chip over the patch period (profiles/r02ai, r02ak: -2..3 % from four rounds of patches on; with the
+            // plane stores kept in the Infinity Cache, r02av: 0.210 / 0.208 / 0.193 / 0.190 / 0.189 / 0.191 / 0.195 ms at 0 / 5 / 8 / 10 / 12 / 15 / 20 us)
+            if (p->stagger_us < 0 && p->n_patches >= 1024) pp.stagger_ticks = 1200;
             for (int x = 0; x < 8; ++x) {
               pp.xq_base[x] = p->xq_base[x];
               p->xq_base[x] += (uint32_t)std::min(pp.chunk, std::max(0, p->n_patches - x * pp.chunk));  // draws of this launch

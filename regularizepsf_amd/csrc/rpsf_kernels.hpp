@@ -51,11 +51,19 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const float* base) 
 #else
 #define RPSF_PLANE_OFF(o) (o)
 #endif
+// Cache policy of the fused mode's plane accesses.  Both are sc1 (write-through stores, L1/L2-bypassing loads: what makes them
+// visible across XCDs).  The stores are NOT marked streaming: a plane line is read by the sum a few tens of microseconds after it was
+// written, and without `nt` it is still in the Infinity Cache then; the loads ARE (each line is read once).  Measured
+// (profiles/r02av): 4096^2 0.2066 -> 0.192 ms; with nt on both, or on the stores only, or on neither: 0.207 / 0.215 / 0.212 ms;
+// 8192^2, whose planes are four times the cache, unchanged.
 #if !defined(RPSF_DEV_PLANE_AUX)
-#define RPSF_DEV_PLANE_AUX (16 | 2) /* sc1 | nt */
+#define RPSF_DEV_PLANE_AUX 16 /* sc1 */
+#endif
+#if !defined(RPSF_DEV_PLANE_AUX_LOAD)
+#define RPSF_DEV_PLANE_AUX_LOAD (16 | 2) /* sc1 | nt */
 #endif
 __device__ __forceinline__ rpsf_f4 plane_load16_wt(__amdgpu_buffer_rsrc_t r, size_t float_offset) {
-  const rpsf_i4 q = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(RPSF_PLANE_OFF(float_offset) * sizeof(float)), 0, RPSF_DEV_PLANE_AUX);
+  const rpsf_i4 q = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(RPSF_PLANE_OFF(float_offset) * sizeof(float)), 0, RPSF_DEV_PLANE_AUX_LOAD);
   return rpsf_f4{__int_as_float(q.x), __int_as_float(q.y), __int_as_float(q.z), __int_as_float(q.w)};
 }
 __device__ __forceinline__ void plane_store16_wt(__amdgpu_buffer_rsrc_t r, size_t float_offset, rpsf_f4 v) {
