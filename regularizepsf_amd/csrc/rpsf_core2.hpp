@@ -465,7 +465,11 @@ RPSF_HD void load_raw2(int t, cf* v, const ImageView& im, int pr, int pc, bool f
       const int r = (R1 << (C::A2 + C::AL)) + tp.r_low;
       StaticFor<0, NCOL>::run([&]<int C1>() RPSF_AI {
         const int cp = (C1 << C::B2) + tp.c2;
+#if defined(RPSF_DEV_GATHER_NT)  // development: pixel gather with the streaming hint
+        const f32x4 q = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base + (size_t)r * im.ld + 4 * cp));
+#else
         const f32x4 q = *reinterpret_cast<const f32x4*>(base + (size_t)r * im.ld + 4 * cp);
+#endif
         v[2 * (R1 * NCOL + C1)] = cf{q.x, q.y};
         v[2 * (R1 * NCOL + C1) + 1] = cf{q.z, q.w};
       });

@@ -112,7 +112,11 @@ __device__ __forceinline__ void sum_tile(const TileSum& p, uint32_t tile, int ti
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           if ((cov >> k) & 1) acc += v[u][k];
+#if defined(RPSF_DEV_OUT_PLAIN)  // development: output stores of the tile sum without the streaming hint
+        *reinterpret_cast<f4*>(p.out + (size_t)(y0 + i / gw - p.row0) * p.ld_out + x0 + ((i % gw) << 2)) = acc;
+#else
         __builtin_nontemporal_store(acc, reinterpret_cast<f4*>(p.out + (size_t)(y0 + i / gw - p.row0) * p.ld_out + x0 + ((i % gw) << 2)));
+#endif
       }
     }
   } else {

@@ -277,7 +277,11 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
 #endif
   const int plane = ov.plane_stride ? dsc.w : 0;
   auto add = [](float* a, float val) { unsafeAtomicAdd(a, val); };
+#if defined(RPSF_DEV_PSTORE_PLAIN)  // development: plane stores of the non-fused path without the streaming hint
+  auto pstore4 = [](float* a, f32x4 val) RPSF_AI { *reinterpret_cast<f32x4*>(a) = val; };
+#else
   auto pstore4 = [](float* a, f32x4 val) RPSF_AI { __builtin_nontemporal_store(val, reinterpret_cast<f32x4*>(a)); };
+#endif
   auto pstore1 = [](float* a, float val) RPSF_AI { *a = val; };
   if (p.dv.out) {  // direct overlap-add (opt-in; moves as many bytes as the planes do and waits on top - DESIGN.md)
     OutView dv = p.dv;
