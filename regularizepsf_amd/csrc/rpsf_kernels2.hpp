@@ -136,7 +136,8 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   // held back by a different fraction of stagger_ticks (later workgroups inherit the offset of the one they replace).
   if (p.stagger_ticks > 0 && pb < p.stagger_blocks && !again) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    const unsigned long long wait = (unsigned long long)((((unsigned)pb >> 3) * 0x9E3779B1u >> 22) & 1023) * p.stagger_ticks >> 10;
+    // evenly spaced delays in bit-reversed order of the chunk row (profiles/r02av: -1 % against hashed delays at 12 us)
+    const unsigned long long wait = (unsigned long long)(__brev((unsigned)pb >> 3) >> 22) * p.stagger_ticks >> 10;
     while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
   }
   STAMP(0);
