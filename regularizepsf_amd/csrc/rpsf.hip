@@ -223,9 +223,17 @@ static int setup_lattice(rpsf_plan* p) {
         const int r = p->h_coords[2 * i], c = p->h_coords[2 * i + 1];
         return r == r0 || r == r1 || c == c0 || c == c1;
       };
+      // ... until the rim patches got their 16-byte paths: they are now the cheaper ones (half or a quarter of the stores).  With one
+      // patch per CU (N = 256) they go LAST, so that the patches of the partial last round are the short ones (4096^2: -1 %,
+      // profiles/r02av); with four workgroups per CU (N = 128) first is still the better order (2048^2: 0.0685 vs 0.0705 ms).
+      bool rim_last = p->N == 256;
+      if (const char* e = std::getenv("RPSF_RIM_LAST")) rim_last = std::atoi(e) != 0;
       for (int x = 0; x < 8; ++x) {
         const int lo = std::min(n, x * chunk), hi = std::min(n, lo + chunk);
-        std::stable_partition(p->h_order.begin() + lo, p->h_order.begin() + hi, rim);
+        if (rim_last)
+          std::stable_partition(p->h_order.begin() + lo, p->h_order.begin() + hi, [&](int32_t i) { return !rim(i); });
+        else
+          std::stable_partition(p->h_order.begin() + lo, p->h_order.begin() + hi, rim);
       }
     }
   } else {
