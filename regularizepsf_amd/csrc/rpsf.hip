@@ -551,6 +551,7 @@ extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int
     p->sum_first = n_patches >= 2048 ? 32 : n_patches >= 1024 ? 16 : n_patches >= 512 ? 8 : 0;
     if (const char* e = std::getenv("RPSF_SUM_FIRST")) p->sum_first = std::max(0, std::atoi(e)) / 8 * 8;
     if (const char* e = std::getenv("RPSF_STAGGER_US")) p->stagger_us = std::max(0, std::atoi(e));  // development sweeps
+    if (const char* e = std::getenv("RPSF_RESERVED_CUS")) p->reserved_cus = std::min(128, std::max(0, std::atoi(e)));
     p->fuse_pays = N >= 256 || std::getenv("RPSF_FUSE_ALWAYS") != nullptr;
     p->persist = N == 256 && std::getenv("RPSF_NO_PERSIST") == nullptr;  // (profiles/r02ag: -3.7 % per apply at 4096^2)
     if (p->persist)
