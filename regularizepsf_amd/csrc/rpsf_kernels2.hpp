@@ -87,15 +87,6 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   // round of patches leaves idle.  All of them draw tiles from one queue.
   // (persistent form: bit 30 of the block index says that this is a re-entry - the tables are in LDS already and the park
   // words hold the tiles of the previous patch, still to be counted)
-  // One batch of scalar loads for everything the path to the first pixel load needs (the compiler would fetch these kernel
-  // arguments branch by branch: five dependent round trips through the scalar cache between a re-entry and the gather)
-  if constexpr (PERSIST) {
-    const int a0 = p.sum_first, a1 = p.patch_blocks, a2 = p.slot0, a3 = p.n_frames, a4 = p.chunk, a5 = p.n_patches, a6 = p.seq_base;
-    const int a7 = p.origin_row, a8 = p.origin_col, a9 = p.im.ld, a10 = p.im.H, a11 = p.im.W, a12 = p.im.row0, a13 = p.im.rows;
-    const void *b0 = p.desc, *b1 = p.im.img;
-    asm volatile("" ::"s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(a5), "s"(a6), "s"(a7), "s"(a8), "s"(a9), "s"(a10), "s"(a11), "s"(a12),
-                 "s"(a13), "s"(b0), "s"(b1));
-  }
   const bool again = PERSIST && ((blockIdx.x >> 30) & 1u);
   const int pb = (int)(blockIdx.x & 0x3fffffffu) - p.sum_first;  // workgroup-uniform
   bool patchy = pb >= 0 && pb < p.patch_blocks;
