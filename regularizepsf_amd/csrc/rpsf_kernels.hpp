@@ -71,12 +71,12 @@ __device__ __forceinline__ void plane_store16_wt(__amdgpu_buffer_rsrc_t r, size_
   __builtin_amdgcn_raw_buffer_store_b128(q, r, (int)(RPSF_PLANE_OFF(float_offset) * sizeof(float)), 0, RPSF_DEV_PLANE_AUX);
 }
 
-__device__ __forceinline__ void sum_tile(const TileSum& p, uint32_t tile, int tid, int nthreads) {
+__device__ __forceinline__ void sum_tile(const TileSum& p, uint32_t tile, int tid, int nthreads, bool known_complete = false) {
   typedef float f4 __attribute__((ext_vector_type(4)));
   const int ti = tile / p.ntj, tj = tile % p.ntj;
   const int cov = p.cover[tile];
   const bool fused = p.done != nullptr;
-  if (fused) {  // wait until every contributor of the tile has published its stores
+  if (fused && !known_complete) {  // wait until every contributor of the tile has published its stores
     if (tid == 0) {
       const uint32_t want = p.epoch * (uint32_t)__builtin_popcount(cov & 15);
       while (__hip_atomic_load(p.done + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) __builtin_amdgcn_s_sleep(4);
@@ -142,6 +142,50 @@ __device__ __forceinline__ void sum_tiles_worker(const TileSum& p, int block, in
     for (int i = block; i < p.count; i += nblocks) sum_tile(p, p.tiles[i], threadIdx.x, blockDim.x);
     return;
   }
+#if !defined(RPSF_DEV_SUM_BLOCKING)
+  // A workgroup holds up to SUM_LOOKAHEAD drawn tiles and sums whichever of them is complete first, instead of waiting for the
+  // head of the (predicted) order while later tiles are complete already - with the plane stores kept in the Infinity Cache,
+  // the sooner a complete tile is summed the likelier its planes are still there.  Thread 0 keeps the list.
+#if !defined(RPSF_SUM_LOOKAHEAD)
+#define RPSF_SUM_LOOKAHEAD 4
+#endif
+  constexpr int SUM_LOOKAHEAD = RPSF_SUM_LOOKAHEAD;
+  __shared__ uint32_t pend[SUM_LOOKAHEAD];
+  __shared__ uint32_t pick;
+  int npend = 0;
+  bool exhausted = false;
+  for (;;) {
+    if (threadIdx.x == 0) {
+      uint32_t chosen = 0xffffffffu;
+      for (;;) {
+        for (int j = 0; j < npend; ++j) {
+          const uint32_t tile = pend[j];
+          const uint32_t want = p.epoch * (uint32_t)__builtin_popcount(p.cover[tile] & 15);
+          if (__hip_atomic_load(p.done + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want) {
+            chosen = tile;
+            for (int m = j + 1; m < npend; ++m) pend[m - 1] = pend[m];
+            --npend;
+            break;
+          }
+        }
+        if (chosen != 0xffffffffu) break;
+        if (!exhausted && npend < SUM_LOOKAHEAD) {
+          const uint32_t i = __hip_atomic_fetch_add(p.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.queue_base;
+          if (i >= (uint32_t)p.count) exhausted = true; else pend[npend++] = p.tiles[i];
+          continue;
+        }
+        if (npend == 0) break;  // every position drawn, nothing left to wait for
+        __builtin_amdgcn_s_sleep(4);
+      }
+      pick = chosen;
+    }
+    __syncthreads();
+    const uint32_t tile = pick;
+    __syncthreads();
+    if (tile == 0xffffffffu) return;
+    sum_tile(p, tile, threadIdx.x, blockDim.x, true);
+  }
+#else
   __shared__ uint32_t next;
   for (;;) {
     if (threadIdx.x == 0) next = __hip_atomic_fetch_add(p.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.queue_base;
@@ -151,6 +195,7 @@ __device__ __forceinline__ void sum_tiles_worker(const TileSum& p, int block, in
     if (i >= (uint32_t)p.count) return;
     sum_tile(p, p.tiles[i], threadIdx.x, blockDim.x);
   }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
