@@ -242,6 +242,8 @@ def run_batch(args, rank, world, device, comm):
 
     def barrier():
         plan.synchronize()
+        for q, _ in pipeline:
+            q.synchronize()
         if comm is not None:
             comm.barrier()
             plan.synchronize()
@@ -323,6 +325,10 @@ def main() -> None:
                          "multi-rank flow on a box with fewer GPUs than ranks")
     ap.add_argument("--verify", action="store_true", help="check every rank's owned rows against the CPU oracle")
     ap.add_argument("--frames", type=int, default=8, help="config 5: frames per GPU in one batch")
+    ap.add_argument("--in-flight", type=int, default=1,
+                    help="N = 1 only: this many plans (own stream, planes and output; the same K) take turns, so that the head of "
+                         "one apply overlaps the tail of the previous one - the throughput of a frame pipeline.  Default 1: one "
+                         "apply after the other, which is also what roofline.frac is always computed on")
     ap.add_argument("--no-overlap", action="store_true",
                     help="--seam exchange: plain apply -> send/recv -> add on one stream instead of computing the spill rows "
                          "first and sending them beside the rest of the band")
@@ -420,6 +426,19 @@ def main() -> None:
     shard.upload_rows(band_image)
     plan, geom, d_img, d_out = shard.plan, shard.geometry, shard.d_img, shard.d_out
     run_step = shard.step
+    pipeline = []  # --in-flight > 1: further plans with their own streams, planes and outputs (world 1 only)
+    if world == 1 and args.in_flight > 1:
+        for _ in range(args.in_flight - 1):
+            extra = _native.Plan(n, [coords[i] for i in band.patch_index], device=device)
+            extra.set_transfer(kernel_for(band.patch_index))
+            pipeline.append((extra, _native.DeviceBuffer(band.out_rows * w * 4, device)))
+        turn = [0]
+        plans = [(plan, d_out)] + pipeline
+
+        def run_step():  # noqa: F811
+            q, out = plans[turn[0] % len(plans)]
+            turn[0] += 1
+            q.apply_device(d_img.ptr, out.ptr, geom)
 
     def barrier():
         plan.synchronize()
@@ -450,7 +469,8 @@ def main() -> None:
     kern_avg_ms, apply_avg_ms = float(np.mean(kernel_ms)), float(np.mean(total_ms))
     my_patches = plan.n_patches
     alg_bytes = my_patches * n * (n // 2 + 1) * 8 + band.image_rows * w * 4 + band.out_rows * w * 4
-    step_ms = ms_per_step if world == 1 else apply_avg_ms  # one rank's apply; at N = 1 the wall-clock step itself
+    # one rank's apply; at N = 1 the wall-clock step itself (with --in-flight > 1 the steps overlap: the single apply by events)
+    step_ms = ms_per_step if world == 1 and not pipeline else apply_avg_ms
     achieved = alg_bytes / (step_ms * 1e-3) / 1e9
     achieved_kernel = alg_bytes / (kern_avg_ms * 1e-3) / 1e9
 
@@ -489,6 +509,7 @@ def main() -> None:
                         f"coma PSF grid -> Gaussian target, alpha=3 eps=0.1, pad symmetric",
             "image": [height, w], "patch": n, "patches": len(coords), "device": name, "compute_units": cus,
             "resident": "image, output and packed transfer kernel in HBM before the timed region",
+            "in_flight": 1 + len(pipeline),
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -503,6 +524,8 @@ def main() -> None:
             "apply_avg_ms_events": round(apply_avg_ms, 4), "patches_this_rank": my_patches,
         },
     }
+    if pipeline:  # the overlapped steps priced on the same bytes (not roofline.frac: SURVEY 8d's t is one device-resident apply)
+        line["roofline"]["frac_steps_in_flight"] = round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     traffic_file = ROOT / "profiles" / "traffic_latest.json"
     if world == 1 and args.config == 3 and traffic_file.exists():  # PMC counters cannot be read from inside the process
         tr = json.loads(traffic_file.read_text())
