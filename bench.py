@@ -241,9 +241,7 @@ def run_batch(args, rank, world, device, comm):
         plan.apply_batch_device(d_in.ptr, d_out.ptr, frames, stride, stride, geom)
 
     def barrier():
-        plan.synchronize()
-        for q, _ in pipeline:
-            q.synchronize()
+        plan.synchronize()  # (device-wide)
         if comm is not None:
             comm.barrier()
             plan.synchronize()

@@ -109,7 +109,7 @@ struct rpsf_plan {
   uint32_t sum_queue_base = 0;
   bool no_fuse = false;
   int sum_first = 0;                 // summing workgroups that run beside the patches from the start (multiple of 8: one per XCD)
-  bool fuse_pays = false;            // one workgroup per CU (N = 256): measured -5..6 % per apply; with four small ones per CU (N = 128) +3 %
+  bool fuse_pays = false;            // the second-generation plans (N = 128, 256)
   // Persistent patch workgroups (patch_kernel2_256p; fused launches of the 256-pixel plan): per-XCD slot queues, never reset
   bool persist = false;
   // Co-resident summing waves (sum_waves_kernel): a second stream and the events that tie it to the apply's stream
@@ -550,10 +550,14 @@ extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int
     // (r02y: a band of 520 patches 130-138 us with 8, 131-146 with 32; r02av, plane stores kept in the Infinity Cache: 4096^2 0.193 / 0.190 /
     // 0.196 ms with 8 / 16 / 24, 8192^2 0.78 / 0.77 / 0.74 / 0.765 ms with 8 / 16 / 32 / 48 - the sooner a tile is summed, the likelier its planes are still cached)
     p->sum_first = n_patches >= 2048 ? 32 : n_patches >= 1024 ? 16 : n_patches >= 512 ? 8 : 0;
+    // (128-pixel plan: 128-thread workgroups, four per CU - 4096^2: 0.217 / 0.214 / 0.212 / 0.206 ms with 16 / 64 / 96 / 128 against 0.218 ms
+    // with the separate sum kernel; 2048^2: 0.067 ms with 0 ... 24 against 0.069)
+    if (N == 128) p->sum_first = n_patches >= 2048 ? 128 : n_patches >= 512 ? 8 : 0;
     if (const char* e = std::getenv("RPSF_SUM_FIRST")) p->sum_first = std::max(0, std::atoi(e)) / 8 * 8;
     if (const char* e = std::getenv("RPSF_STAGGER_US")) p->stagger_us = std::max(0, std::atoi(e));  // development sweeps
     if (const char* e = std::getenv("RPSF_RESERVED_CUS")) p->reserved_cus = std::min(128, std::max(0, std::atoi(e)));
-    p->fuse_pays = N >= 256 || std::getenv("RPSF_FUSE_ALWAYS") != nullptr;
+    // (until the plane stores were kept in the Infinity Cache the fused sum cost the 128-pixel plan 3 %; now it gains 3 ... 6 %)
+    p->fuse_pays = N >= 128 || std::getenv("RPSF_FUSE_ALWAYS") != nullptr;
     p->persist = N == 256 && std::getenv("RPSF_NO_PERSIST") == nullptr;  // (profiles/r02ag: -3.7 % per apply at 4096^2)
     if (p->persist)
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_kernel2_256p), hipFuncAttributeMaxDynamicSharedMemorySize,
