@@ -105,10 +105,11 @@ struct rpsf_plan {
   uint32_t* d_tile_done = nullptr;   // per tile: contributors done, never reset (epoch * contributors after every apply)
   uint32_t* d_sum_order = nullptr;   // all tiles, the ones whose contributors run first first
   uint32_t done_epoch = 0;
+  size_t done_frames = 1;            // frames the tile counters are sized for (batches: one set per frame)
   uint32_t* d_sum_queue = nullptr;   // position in d_sum_order, never reset
   uint32_t sum_queue_base = 0;
   bool no_fuse = false;
-  int sum_first = 0;                 // summing workgroups that run beside the patches from the start (multiple of 8: one per XCD)
+  int sum_first = -1;                // RPSF_SUM_FIRST override of sum_first_for(), -1 = none
   bool fuse_pays = false;            // the second-generation plans (N = 128, 256)
   // Persistent patch workgroups (patch_kernel2_256p; fused launches of the 256-pixel plan): per-XCD slot queues, never reset
   bool persist = false;
@@ -547,12 +548,7 @@ extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int
     p->v2 = has_v2(N);
     p->no_fuse = std::getenv("RPSF_NO_FUSE") != nullptr;
     // (measured, profiles/r02u, r02v: 32 of them are worth -1 % at 4096^2 and -2.5 % at 8192^2; 48 cost more patch time than they hide)
-    // (r02y: a band of 520 patches 130-138 us with 8, 131-146 with 32; r02av, plane stores kept in the Infinity Cache: 4096^2 0.193 / 0.190 /
-    // 0.196 ms with 8 / 16 / 24, 8192^2 0.78 / 0.77 / 0.74 / 0.765 ms with 8 / 16 / 32 / 48 - the sooner a tile is summed, the likelier its planes are still cached)
-    p->sum_first = n_patches >= 2048 ? 32 : n_patches >= 1024 ? 16 : n_patches >= 512 ? 8 : 0;
-    // (128-pixel plan: 128-thread workgroups, four per CU - 4096^2: 0.217 / 0.214 / 0.212 / 0.206 ms with 16 / 64 / 96 / 128 against 0.218 ms
-    // with the separate sum kernel; 2048^2: 0.067 ms with 0 ... 24 against 0.069)
-    if (N == 128) p->sum_first = n_patches >= 2048 ? 128 : n_patches >= 512 ? 8 : 0;
+    p->sum_first = -1;  // decided per launch (sum_first_for) unless the environment pins it
     if (const char* e = std::getenv("RPSF_SUM_FIRST")) p->sum_first = std::max(0, std::atoi(e)) / 8 * 8;
     if (const char* e = std::getenv("RPSF_STAGGER_US")) p->stagger_us = std::max(0, std::atoi(e));  // development sweeps
     if (const char* e = std::getenv("RPSF_RESERVED_CUS")) p->reserved_cus = std::min(128, std::max(0, std::atoi(e)));
@@ -787,6 +783,20 @@ struct Batch {
 
 enum OverlapKind { OV_ATOMIC = 0, OV_PLANES = 1, OV_DIRECT = 2 };
 
+// Summing workgroups that run beside the patches from the start of a fused launch (multiple of 8: one per XCD), by the
+// amount of work in the launch.  256-pixel plan (512-thread workgroups, one per CU): r02y, a band of 520 patches 130-138 us
+// with 8, 131-146 with 32; r02av, plane stores kept in the Infinity Cache: 4096^2 0.193 / 0.190 / 0.196 ms with 8 / 16 / 24,
+// 8192^2 0.78 / 0.77 / 0.74 / 0.765 ms with 8 / 16 / 32 / 48 - the sooner a tile is summed, the likelier its planes are still
+// cached.  128-pixel plan (128-thread workgroups, four per CU): 4096^2 0.217 / 0.214 / 0.212 / 0.206 ms with 16 / 64 / 96 / 128
+// against 0.218 ms with the separate sum kernel; 2048^2 0.067 ms with 0 ... 24 against 0.069; 8 x 2048^2 0.372 / 0.360 / 0.352 /
+// 0.343 / 0.340 ms with 8 / 32 / 64 / 128 / 192 against 0.362.
+static int sum_first_for(const rpsf_plan* p, int frames) {
+  if (p->sum_first >= 0) return p->sum_first;
+  const long work = (long)p->n_patches * frames;
+  if (p->N == 128) return work >= 2048 ? 128 : work >= 512 ? 8 : 0;
+  return work >= 2048 ? 32 : work >= 1024 ? 16 : work >= 512 ? 8 : 0;
+}
+
 // fused: the plane sum runs in this launch (see rpsf_plan::d_tile_done)
 static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const rpsf_geometry& g, OverlapKind kind,
                           hipStream_t st, Batch b = Batch(), bool fused = false) {
@@ -829,17 +839,19 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
         ts.out = d_out, ts.ld_out = g.ld_out;
         ts.rows = g.out_rows, ts.W = g.width, ts.row0 = g.out_row0;
         ts.lat_r0 = p->lat_r0 + g.origin_row, ts.lat_c0 = p->lat_c0 + g.origin_col, ts.half = p->N / 2, ts.ntj = p->ntj;
-        ts.cover = p->d_cover, ts.tiles = p->d_sum_order, ts.count = n_tiles;
+        ts.cover = p->d_cover, ts.tiles = p->d_sum_order, ts.count = n_tiles * b.frames;
         ts.done = p->d_tile_done, ts.epoch = p->done_epoch;
-        int nsum = std::max(8, std::min(n_tiles, p->round_capacity));  // at the tail: as many summing workgroups as the chip holds
-        pp.sum_first = p->sum_first;
+        ts.n_frames = b.frames, ts.n_tiles = (uint32_t)n_tiles;
+        ts.planes_frame_floats = 4 * p->planes_floats, ts.out_frame_floats = b.out_stride;
+        int nsum = std::max(8, std::min(ts.count, p->round_capacity));  // at the tail: as many summing workgroups as the chip holds
+        pp.sum_first = sum_first_for(p, b.frames);
         ts.queue = p->d_sum_queue, ts.queue_base = p->sum_queue_base;
         if constexpr (std::is_same_v<C, Cfg256v2>) {
           // persistent form: as many patch workgroups as the chip holds beside the summing ones; each works through the slots
           // of its XCD's chunk and ends as a summing workgroup itself (no workgroups behind the patches)
           if (p->cosum) pp.sum_first = 0;  // the summing is done by waves beside the patch workgroups: every CU takes patches
           const int rows = std::min(pp.chunk, std::max(1, (p->round_capacity - pp.sum_first - p->reserved_cus) / 8));
-          if (p->persist && rows > 0) {
+          if (p->persist && rows > 0 && b.frames == 1) {
             pp.persist = rows, pp.xq = p->d_xq;
             // persistent workgroups keep the phase they start with: holding the resident ones back by up to 10 us spreads the
             // store bursts of the chip over the patch period (profiles/r02ai, r02ak: -2..3 % from four rounds of patches on; with the
@@ -851,7 +863,7 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
             }
             const int wgs = pp.sum_first + 8 * rows;
             const int ncos = p->cosum ? p->cu_count : 0;  // one workgroup of summing waves per CU
-            p->sum_queue_base += (uint32_t)(n_tiles + wgs + ncos);  // every workgroup draws one position past the end
+            p->sum_queue_base += (uint32_t)(ts.count + wgs + ncos);  // every workgroup draws one position past the end
             if (ncos) {  // the summing waves may start once everything before this apply on `st` is done ...
               HIP_TRY(hipEventRecord(p->ev_sum_go, st));
               HIP_TRY(hipStreamWaitEvent(p->st_sum, p->ev_sum_go, 0));
@@ -870,7 +882,7 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
           }
         }
         nsum += pp.sum_first;
-        p->sum_queue_base += (uint32_t)(n_tiles + nsum);  // every workgroup draws one position past the end
+        p->sum_queue_base += (uint32_t)(ts.count + nsum);  // every workgroup draws one position past the end
         blocks += (size_t)nsum;
       }
       patch_kernel2<C><<<dim3((unsigned)blocks), dim3(Launch2<C>::WG), Launch2<C>::LDS_BYTES, st>>>(pp);
@@ -1028,19 +1040,30 @@ static int launch_apply(rpsf_plan* p, const float* d_img, float* d_out, const rp
                                (size_t)g.width * sizeof(float), g.out_rows, st));
   // Fused plane sum: one frame, every plane line written whole by one store instruction (see sum_tile)
   const long tile_r0 = (long)p->lat_r0 + g.origin_row, tile_c0 = (long)p->lat_c0 + g.origin_col;
-  const bool fused = kind == OV_PLANES && p->v2 && p->fuse_pays && p->d_tile_done && !p->no_fuse && b.frames == 1 && g.width % 32 == 0 &&
+  const bool fused = kind == OV_PLANES && p->v2 && p->fuse_pays && p->d_tile_done && !p->no_fuse && b.frames <= 255 && g.width % 32 == 0 &&
                      g.ld_out % 4 == 0 && tile_c0 % 32 == 0 && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0 &&
                      16 * plane_floats_needed(g) < ((size_t)1 << 32);  // the planes are addressed through one 32-bit buffer offset
   if (fused) {
+    const size_t n_tiles = (size_t)p->nti * p->ntj;
+    if ((size_t)b.frames > p->done_frames) {  // one set of tile counters per frame of a batch
+      HIP_TRY(hipDeviceSynchronize());
+      (void)hipFree(p->d_tile_done);
+      p->d_tile_done = nullptr;
+      HIP_TRY(hipMalloc(&p->d_tile_done, n_tiles * b.frames * sizeof(uint32_t)));
+      HIP_TRY(hipMemset(p->d_tile_done, 0, n_tiles * b.frames * sizeof(uint32_t)));
+      p->done_frames = (size_t)b.frames, p->done_epoch = 0;
+    }
     if (++p->done_epoch >= (1u << 29)) {  // the counters hold epoch * contributors
-      HIP_TRY(hipMemsetAsync(p->d_tile_done, 0, (size_t)p->nti * p->ntj * sizeof(uint32_t), st));
+      HIP_TRY(hipMemsetAsync(p->d_tile_done, 0, n_tiles * p->done_frames * sizeof(uint32_t), st));
       p->done_epoch = 1;
     }
     // the tile sums write lattice tiles only: pixels of the window outside the tile grid are cleared here
     const int half = p->N / 2;
     if (tile_r0 > g.out_row0 || tile_r0 + (long)p->nti * half < (long)g.out_row0 + g.out_rows || tile_c0 > 0 ||
         tile_c0 + (long)p->ntj * half < g.width)
-      HIP_TRY(hipMemset2DAsync(d_out, (size_t)g.ld_out * sizeof(float), 0, (size_t)g.width * sizeof(float), g.out_rows, st));
+      for (int f = 0; f < b.frames; ++f)
+        HIP_TRY(hipMemset2DAsync(d_out + (size_t)f * b.out_stride, (size_t)g.ld_out * sizeof(float), 0, (size_t)g.width * sizeof(float),
+                                 g.out_rows, st));
   }
   if (ev_k0) HIP_TRY(hipEventRecord(ev_k0, st));
   int rc = launch_patches(p, d_img, d_out, g, kind, st, b, fused);

@@ -30,7 +30,16 @@ struct TileSum {
   uint32_t epoch;
   uint32_t* queue;           // fused: next position in the list (never reset: this launch owns [queue_base, queue_base + count))
   uint32_t queue_base;
+  // batches (frames that share the transfer kernel): the list has count = tiles x frames positions, position i = tile list entry
+  // i / n_frames of frame i % n_frames (the frames of one patch slot run side by side, so their tiles complete together);
+  // a list entry in flight is (frame << 24) | tile
+  int n_frames;              // 0 or 1: one frame
+  uint32_t n_tiles;          // done counters of frame f start at done + f * n_tiles
+  size_t planes_frame_floats, out_frame_floats;
 };
+__device__ __forceinline__ uint32_t sum_entry(const TileSum& p, uint32_t i) {
+  return p.n_frames > 1 ? ((i % (uint32_t)p.n_frames) << 24) | p.tiles[i / (uint32_t)p.n_frames] : p.tiles[i];
+}
 
 // 16-byte plane accesses of the fused mode: write-through stores and L1-bypassing loads (agent scope), so that a
 // workgroup on another XCD reads what the patch workgroups wrote (MI355X_MICROARCH.md, inter-workgroup visibility).
@@ -71,8 +80,13 @@ __device__ __forceinline__ void plane_store16_wt(__amdgpu_buffer_rsrc_t r, size_
   __builtin_amdgcn_raw_buffer_store_b128(q, r, (int)(RPSF_PLANE_OFF(float_offset) * sizeof(float)), 0, RPSF_DEV_PLANE_AUX);
 }
 
-__device__ __forceinline__ void sum_tile(const TileSum& p, uint32_t tile, int tid, int nthreads, bool known_complete = false) {
+__device__ __forceinline__ void sum_tile(const TileSum& p0, uint32_t entry, int tid, int nthreads, bool known_complete = false) {
   typedef float f4 __attribute__((ext_vector_type(4)));
+  const uint32_t tile = entry & 0xffffffu, frame = entry >> 24;
+  TileSum p = p0;  // this frame's planes, output and counters
+  p.planes += (size_t)frame * p0.planes_frame_floats;
+  p.out += (size_t)frame * p0.out_frame_floats;
+  if (p.done) p.done += (size_t)frame * p0.n_tiles;
   const int ti = tile / p.ntj, tj = tile % p.ntj;
   const int cov = p.cover[tile];
   const bool fused = p.done != nullptr;
@@ -159,9 +173,9 @@ __device__ __forceinline__ void sum_tiles_worker(const TileSum& p, int block, in
       uint32_t chosen = 0xffffffffu;
       for (;;) {
         for (int j = 0; j < npend; ++j) {
-          const uint32_t tile = pend[j];
-          const uint32_t want = p.epoch * (uint32_t)__builtin_popcount(p.cover[tile] & 15);
-          if (__hip_atomic_load(p.done + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want) {
+          const uint32_t tile = pend[j];  // (frame << 24) | tile
+          const uint32_t want = p.epoch * (uint32_t)__builtin_popcount(p.cover[tile & 0xffffffu] & 15);
+          if (__hip_atomic_load(p.done + (size_t)(tile >> 24) * p.n_tiles + (tile & 0xffffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want) {
             chosen = tile;
             for (int m = j + 1; m < npend; ++m) pend[m - 1] = pend[m];
             --npend;
@@ -171,7 +185,7 @@ __device__ __forceinline__ void sum_tiles_worker(const TileSum& p, int block, in
         if (chosen != 0xffffffffu) break;
         if (!exhausted && npend < SUM_LOOKAHEAD) {
           const uint32_t i = __hip_atomic_fetch_add(p.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.queue_base;
-          if (i >= (uint32_t)p.count) exhausted = true; else pend[npend++] = p.tiles[i];
+          if (i >= (uint32_t)p.count) exhausted = true; else pend[npend++] = sum_entry(p, i);
           continue;
         }
         if (npend == 0) break;  // every position drawn, nothing left to wait for
@@ -193,7 +207,7 @@ __device__ __forceinline__ void sum_tiles_worker(const TileSum& p, int block, in
     const uint32_t i = next;
     __syncthreads();
     if (i >= (uint32_t)p.count) return;
-    sum_tile(p, p.tiles[i], threadIdx.x, blockDim.x);
+    sum_tile(p, sum_entry(p, i), threadIdx.x, blockDim.x);
   }
 #endif
 }
