@@ -262,7 +262,11 @@ def run_batch(args, rank, world, device, comm):
     total_ms, kernel_ms = plan.apply_batch_device_timed(d_in.ptr, d_out.ptr, frames, stride, stride, geom, iters)
     kern_avg_ms = float(np.mean(kernel_ms))
     alg_bytes = plan.transfer_bytes + frames * 2 * h * w * 4  # K once per batch + every frame read and written once
-    achieved = alg_bytes / (kern_avg_ms * 1e-3) / 1e9
+    # the whole device-resident batch step (patch kernel + plane sum, fused or not), as for the single frames; the patch kernel
+    # alone is kept as a second figure (with the fused sum they coincide)
+    step_ms = ms_per_step if world == 1 else float(np.mean(total_ms))
+    achieved = alg_bytes / (step_ms * 1e-3) / 1e9
+    achieved_kernel = alg_bytes / (kern_avg_ms * 1e-3) / 1e9
     if args.verify:
         out = d_out.download((frames, h, w)).astype(np.float64)
         for f in (0, frames - 1):
@@ -296,7 +300,8 @@ def run_batch(args, rank, world, device, comm):
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "patch_kernel",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "patch_kernel2" if n in (128, 256) else "patch_kernel",
+            "whole_step_ms": round(step_ms, 4), "frac_patch_kernel_only": round(achieved_kernel / HBM_PEAK_GBS, 4),
             "kernel_avg_ms": round(kern_avg_ms, 4), "kernel_launches": iters, "algorithmic_bytes": int(alg_bytes),
             "bytes_model": "packed folded K read once per batch + every frame read once + every output written once",
             "apply_avg_ms_events": round(float(np.mean(total_ms)), 4),
