@@ -94,7 +94,7 @@ struct rpsf_plan {
   // overlap-add strategy: on regular half-overlap lattices direct accumulation through the XCD's L2 (three-stage
   // plans) or colour planes + plane sum (the small-patch plans); float atomics for any other corner list
   int overlap_mode = 0;  // 0 auto, 1 atomics, 2 planes, 3 direct
-  int stagger_us = -1, cu_count = 256;  // -1: automatic (12 us for persistent launches of four rounds and more, else none)
+  int stagger_us = -1, cu_count = 256;  // -1: automatic (12 us for persistent launches of 256 patches and more, else none)
   int round_capacity = 0;  // patches the chip holds at once (CUs x resident workgroups x patches per workgroup)
   bool lattice = false;
   bool direct_ok = false;  // lattice and one patch per workgroup
@@ -856,7 +856,8 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
             // persistent workgroups keep the phase they start with: holding the resident ones back by up to 10 us spreads the
             // store bursts of the chip over the patch period (profiles/r02ai, r02ak: -2..3 % from four rounds of patches on; with the
             // plane stores kept in the Infinity Cache, r02av: 0.210 / 0.208 / 0.193 / 0.190 / 0.189 / 0.191 / 0.195 ms at 0 / 5 / 8 / 10 / 12 / 15 / 20 us)
-            if (p->stagger_us < 0 && p->n_patches >= 1024) pp.stagger_ticks = 1200;
+            // (and smaller launches too: 2048^2 0.0811 -> 0.0787 ms, 3072^2 0.138 -> 0.131 ms, a band of 520 patches 128 -> 121 us)
+            if (p->stagger_us < 0 && p->n_patches >= 256) pp.stagger_ticks = 1200;
             for (int x = 0; x < 8; ++x) {
               pp.xq_base[x] = p->xq_base[x];
               p->xq_base[x] += (uint32_t)std::min(pp.chunk, std::max(0, p->n_patches - x * pp.chunk));  // draws of this launch
