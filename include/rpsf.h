@@ -74,7 +74,7 @@ int rpsf_plan_set_overlap_mode(rpsf_plan* plan, int mode);
 /* Start-up stagger of the patch kernel's first resident workgroups (microseconds, 0 = off): spreads
  * the gather / K-stream / store phases of different CUs in time so that HBM traffic overlaps compute.
  * Without this call the library decides: 12 us for the persistent launches of the 256-pixel plan from
- * 256 patches on, none otherwise. */
+ * 256 patches on (24 us from 2048 on), none otherwise. */
 int rpsf_plan_set_stagger(rpsf_plan* plan, int microseconds);
 /* The persistent launch of the 256-pixel plan keeps one workgroup on every CU until its patches are done, so a kernel
  * enqueued beside it on another stream - RCCL's send/recv of the seam rows (rpsf_comm_seam_exchange) - would wait for the

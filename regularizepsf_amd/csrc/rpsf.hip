@@ -857,7 +857,8 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
             // store bursts of the chip over the patch period (profiles/r02ai, r02ak: -2..3 % from four rounds of patches on; with the
             // plane stores kept in the Infinity Cache, r02av: 0.210 / 0.208 / 0.193 / 0.190 / 0.189 / 0.191 / 0.195 ms at 0 / 5 / 8 / 10 / 12 / 15 / 20 us)
             // (and smaller launches too: 2048^2 0.0811 -> 0.0787 ms, 3072^2 0.138 -> 0.131 ms, a band of 520 patches 128 -> 121 us)
-            if (p->stagger_us < 0 && p->n_patches >= 256) pp.stagger_ticks = 1200;
+            // (long launches take more: 8192^2 0.736 / 0.726 / 0.714 / 0.703 / 0.698 / 0.719 ms at 6 / 12 / 18 / 24 / 30 / 36 us)
+            if (p->stagger_us < 0 && p->n_patches >= 256) pp.stagger_ticks = p->n_patches >= 2048 ? 2400 : 1200;
             for (int x = 0; x < 8; ++x) {
               pp.xq_base[x] = p->xq_base[x];
               p->xq_base[x] += (uint32_t)std::min(pp.chunk, std::max(0, p->n_patches - x * pp.chunk));  // draws of this launch
