@@ -856,27 +856,36 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
         ts.lat_r0 = p->lat_r0 + g.origin_row, ts.lat_c0 = p->lat_c0 + g.origin_col, ts.half = p->N / 2, ts.ntj = p->ntj;
         ts.cover = p->d_cover, ts.tiles = p->d_sum_order, ts.count = n_tiles * b.frames;
         ts.done = p->d_tile_done, ts.epoch = p->done_epoch;
-        ts.n_frames = b.frames, ts.n_tiles = (uint32_t)n_tiles;
+        ts.n_frames = b.frames, ts.n_tiles = (uint32_t)n_tiles, ts.n_tiles_listed = (uint32_t)n_tiles;
+        // Persistent batches whose planes would not fit the Infinity Cache side by side run frame after frame in one launch: every
+        // frame keeps the cache behaviour of a single apply, and the next frame's patches take the CUs the previous one's last
+        // patches leave idle (RPSF_FRAME_MAJOR=0/1 overrides).
+        bool frame_major = std::is_same_v<C, Cfg256v2> && p->persist && b.frames > 1 && p->n_patches >= 1024 &&
+                           16.0 * (double)p->planes_floats * b.frames > 256.0 * 1048576.0;  // (8 x 2048^2: 0.056 ms per frame side by side, 0.061 in turn)
+        if (const char* e = std::getenv("RPSF_FRAME_MAJOR")) frame_major = frame_major && std::atoi(e) != 0;
+        pp.frame_major = ts.frame_major = frame_major ? 1 : 0;
+        const int tune_frames = b.frames;  // (the settings of a single apply measured worse here: 0.203 vs 0.186 ms per frame at 8 x 4096^2)
+        pp.sum_first = sum_first_for(p, tune_frames);
         ts.planes_frame_floats = 4 * p->planes_floats, ts.out_frame_floats = b.out_stride;
         int nsum = std::max(8, std::min(ts.count, p->round_capacity));  // at the tail: as many summing workgroups as the chip holds
-        pp.sum_first = sum_first_for(p, b.frames);
         ts.queue = p->d_sum_queue, ts.queue_base = p->sum_queue_base;
         if constexpr (std::is_same_v<C, Cfg256v2>) {
           // persistent form: as many patch workgroups as the chip holds beside the summing ones; each works through the slots
           // of its XCD's chunk and ends as a summing workgroup itself (no workgroups behind the patches)
           if (p->cosum) pp.sum_first = 0;  // the summing is done by waves beside the patch workgroups: every CU takes patches
-          const int rows = std::min(pp.chunk, std::max(1, (p->round_capacity - pp.sum_first - p->reserved_cus) / 8));
-          if (p->persist && rows > 0 && b.frames == 1) {
+          // (queue positions of an XCD: chunk slots x frames, the frames of a slot side by side)
+          const int rows = std::min(pp.chunk * b.frames, std::max(1, (p->round_capacity - pp.sum_first - p->reserved_cus) / 8));
+          if (p->persist && rows > 0) {
             pp.persist = rows, pp.xq = p->d_xq;
             // persistent workgroups keep the phase they start with: holding the resident ones back by up to 10 us spreads the
             // store bursts of the chip over the patch period (profiles/r02ai, r02ak: -2..3 % from four rounds of patches on; with the
             // plane stores kept in the Infinity Cache, r02av: 0.210 / 0.208 / 0.193 / 0.190 / 0.189 / 0.191 / 0.195 ms at 0 / 5 / 8 / 10 / 12 / 15 / 20 us)
             // (and smaller launches too: 2048^2 0.0811 -> 0.0787 ms, 3072^2 0.138 -> 0.131 ms, a band of 520 patches 128 -> 121 us)
             // (long launches take more: 8192^2 0.736 / 0.726 / 0.714 / 0.703 / 0.698 / 0.719 ms at 6 / 12 / 18 / 24 / 30 / 36 us)
-            if (p->stagger_us < 0 && p->n_patches >= 256) pp.stagger_ticks = p->n_patches >= 2048 ? 2400 : 1200;
+            if (p->stagger_us < 0 && (long)p->n_patches * tune_frames >= 256) pp.stagger_ticks = (long)p->n_patches * tune_frames >= 2048 ? 2400 : 1200;
             for (int x = 0; x < 8; ++x) {
               pp.xq_base[x] = p->xq_base[x];
-              p->xq_base[x] += (uint32_t)std::min(pp.chunk, std::max(0, p->n_patches - x * pp.chunk));  // draws of this launch
+              p->xq_base[x] += (uint32_t)(std::min(pp.chunk, std::max(0, p->n_patches - x * pp.chunk)) * b.frames);  // draws of this launch
             }
             const int wgs = pp.sum_first + 8 * rows;
             const int ncos = p->cosum ? p->cu_count : 0;  // one workgroup of summing waves per CU

@@ -36,9 +36,13 @@ struct TileSum {
   int n_frames;              // 0 or 1: one frame
   uint32_t n_tiles;          // done counters of frame f start at done + f * n_tiles
   size_t planes_frame_floats, out_frame_floats;
+  int frame_major;           // the list runs frame after frame (persistent batches of large frames) instead of tile after tile
+  uint32_t n_tiles_listed;   // entries of `tiles` (= count / frames)
 };
 __device__ __forceinline__ uint32_t sum_entry(const TileSum& p, uint32_t i) {
-  return p.n_frames > 1 ? ((i % (uint32_t)p.n_frames) << 24) | p.tiles[i / (uint32_t)p.n_frames] : p.tiles[i];
+  if (p.n_frames <= 1) return p.tiles[i];
+  if (p.frame_major) return ((i / p.n_tiles_listed) << 24) | p.tiles[i % p.n_tiles_listed];  // frame after frame
+  return ((i % (uint32_t)p.n_frames) << 24) | p.tiles[i / (uint32_t)p.n_frames];
 }
 
 // 16-byte plane accesses of the fused mode: write-through stores and L1-bypassing loads (agent scope), so that a
@@ -253,6 +257,7 @@ struct PatchParams {
   int orphan_mod;             // testing aid: workgroups with seq % orphan_mod == 1 behave as if they ran on a foreign XCD
   // persistent launch (patch_kernel2_256p): the grid is sum_first + 8 * persist workgroups; the resident ones start on
   // slots [0, persist) of their XCD's chunk and draw the later ones from xq[xcd * 32] (one counter per XCD on a line of its own)
+  int frame_major;  // batches: queue position = frame * (slots of the XCD) + slot instead of slot * frames + frame
   int persist;
   uint32_t* xq;
   uint32_t xq_base[8];

@@ -94,8 +94,14 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   if (patchy) {
     xrow = p.slot0 + (pb >> 3);
     if (p.n_frames > 1) {
-      frame = xrow % p.n_frames;
-      xrow /= p.n_frames;
+      if (p.frame_major) {  // persistent batches of large frames: one frame after the other (its planes stay in the Infinity Cache)
+        const int left = p.n_patches - (pb & 7) * p.chunk, mine = left < p.chunk ? (left > 0 ? left : 1) : p.chunk;  // slots of this XCD
+        frame = xrow / mine;
+        xrow = frame < p.n_frames ? xrow % mine : p.chunk;  // (past the last frame: no slot)
+      } else {  // the frames of one patch slot side by side: its K is fetched once and served from L2 to the others
+        frame = xrow % p.n_frames;
+        xrow /= p.n_frames;
+      }
     }
     seq = (pb & 7) * p.chunk + xrow;
     if (xrow >= p.chunk || seq >= p.n_patches) {  // workgroup-uniform
@@ -311,7 +317,7 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
     if constexpr (PERSIST) {
       if (t < 4) {  // (and the tiles this patch will be counted on: a load behind the stores would wait for them)
         const uint4 q4 = p.quads[p.seq_base + seq];
-        my_tile = quad_tile(t == 0 ? q4.x : t == 1 ? q4.y : t == 2 ? q4.z : q4.w);
+        my_tile = (unsigned)frame * p.n_tiles + quad_tile(t == 0 ? q4.x : t == 1 ? q4.y : t == 2 ? q4.z : q4.w);  // (this frame's counters)
       }
       if (t == 0)
         drawn = __hip_atomic_fetch_add(p.xq + (pb & 7) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.xq_base[pb & 7] + (unsigned)p.persist;
@@ -329,9 +335,9 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
       lds_barrier();
       STAMP(12);
       const unsigned nx = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const unsigned*>(park));
-      const int left = p.n_patches - (pb & 7) * p.chunk;  // slots of this XCD's chunk that hold a patch
+      const int left = p.n_patches - (pb & 7) * p.chunk;  // slots of this XCD's chunk that hold a patch (x frames: queue positions)
       // ... or, once the chunk is exhausted, a block index behind the patches: the workgroup sums tiles with the others
-      const bool more = (int)nx < (left < p.chunk ? left : p.chunk);
+      const bool more = (int)nx < (left < p.chunk ? left : p.chunk) * (p.n_frames > 1 ? p.n_frames : 1);
       reenter(0x40000000u | ((unsigned)p.sum_first + (more ? ((nx << 3) | (unsigned)(pb & 7)) : (unsigned)p.patch_blocks)), (unsigned)t);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

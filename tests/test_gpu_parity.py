@@ -780,6 +780,23 @@ def test_persistent_patch_workgroups_bit_identical(shape):
         del os.environ["RPSF_NO_PERSIST"]
 
 
+@pytest.mark.parametrize("shape,frames", [((1024, 1280), 5), ((4096, 4096), 3)])
+def test_batches_of_the_256_pixel_plan_bit_identical_to_the_loop(shape, frames):
+    """Batches of the persistent 256-pixel plan: the frames of a patch slot side by side (small frames) or frame after frame in one
+    launch (frames whose planes would not share the Infinity Cache) - either way the same bits as applying the frames one by one,
+    run after run, and the oracle's result."""
+    n = 256
+    rng = np.random.default_rng(4)
+    coords = [tuple(int(v) for v in c) for c in rp.calculate_covering(shape, n)]
+    k = (rng.standard_normal((len(coords), n, n)) + 1j * rng.standard_normal((len(coords), n, n))).astype(np.complex64)
+    t = rp.ArrayPSFTransform(rp.IndexedCube(coords, k))
+    stack = (rng.standard_normal((frames, *shape)) * 10 + 30).astype(np.float32)
+    out = t.apply_batch(stack)
+    assert all(np.array_equal(out[i], t.apply(stack[i])) for i in range(frames))
+    assert np.array_equal(out, t.apply_batch(stack))
+    check(out[frames - 1], orc.apply_transfer(stack[frames - 1], coords, k, workers=-1))
+
+
 def test_device_resident_psf_to_transform_chain():
     """ArrayPSF(device=0) leaves the spectra on the GPU, construct() builds and packs K there, apply() runs -
     nothing but the PSF samples and the image crosses PCIe.  The host copies appear only when somebody looks at them, and
