@@ -328,6 +328,10 @@ def main() -> None:
                          "multi-rank flow on a box with fewer GPUs than ranks")
     ap.add_argument("--verify", action="store_true", help="check every rank's owned rows against the CPU oracle")
     ap.add_argument("--frames", type=int, default=8, help="config 5: frames per GPU in one batch")
+    ap.add_argument("--rotate", type=int, default=1,
+                    help="N = 1 only: this many DIFFERENT device-resident frames (and output buffers) are corrected in rotation.  "
+                         "Default 1: the same frame every step, as in every earlier round - it then stays in the 256 MB Infinity "
+                         "Cache between steps, which a stream of new frames would not (DESIGN.md, Measurement)")
     ap.add_argument("--in-flight", type=int, default=1,
                     help="N = 1 only: this many plans (own stream, planes and output; the same K) take turns, so that the head of "
                          "one apply overlaps the tail of the previous one - the throughput of a frame pipeline.  Default 1: one "
@@ -429,6 +433,19 @@ def main() -> None:
     shard.upload_rows(band_image)
     plan, geom, d_img, d_out = shard.plan, shard.geometry, shard.d_img, shard.d_out
     run_step = shard.step
+    rotation = []  # --rotate > 1: further frames and outputs, corrected in turn by the same plan (world 1 only)
+    if world == 1 and args.rotate > 1 and args.in_flight <= 1:
+        for i in range(1, args.rotate):
+            frame = orc.starfield(h1, w, seed + 1000 * i)[band.image_row0:band.image_row0 + band.image_rows]
+            rotation.append((_native.DeviceBuffer(frame.nbytes, device).upload(np.ascontiguousarray(frame, np.float32)),
+                             _native.DeviceBuffer(band.out_rows * w * 4, device)))
+        pairs = [(d_img, d_out)] + rotation
+        spin = [0]
+
+        def run_step():  # noqa: F811
+            a, b = pairs[spin[0] % len(pairs)]
+            spin[0] += 1
+            plan.apply_device(a.ptr, b.ptr, geom)
     pipeline = []  # --in-flight > 1: further plans with their own streams, planes and outputs (world 1 only)
     if world == 1 and args.in_flight > 1:
         for _ in range(args.in_flight - 1):
@@ -512,7 +529,7 @@ def main() -> None:
                         f"coma PSF grid -> Gaussian target, alpha=3 eps=0.1, pad symmetric",
             "image": [height, w], "patch": n, "patches": len(coords), "device": name, "compute_units": cus,
             "resident": "image, output and packed transfer kernel in HBM before the timed region",
-            "in_flight": 1 + len(pipeline),
+            "in_flight": 1 + len(pipeline), "frames_in_rotation": 1 + len(rotation),
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
