@@ -569,10 +569,17 @@ extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int
     if (const char* e = std::getenv("RPSF_RESERVED_CUS")) p->reserved_cus = std::min(128, std::max(0, std::atoi(e)));
     // (until the plane stores were kept in the Infinity Cache the fused sum cost the 128-pixel plan 3 %; now it gains 3 ... 6 %)
     p->fuse_pays = N >= 128 || std::getenv("RPSF_FUSE_ALWAYS") != nullptr;
-    p->persist = N == 256 && std::getenv("RPSF_NO_PERSIST") == nullptr;  // (profiles/r02ag: -3.7 % per apply at 4096^2)
-    if (p->persist)
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_kernel2_256p), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)Launch2<Cfg256v2>::LDS_BYTES));
+    // (256-pixel plan: profiles/r02ag, -3.7 % per apply at 4096^2 from the re-entry alone; 128-pixel plan, whose four workgroups per CU
+    // hide one another's dispatch: 8 x 2048^2 0.334 vs 0.343 ms, single frames unchanged)
+    p->persist = (N == 256 || N == 128) && std::getenv("RPSF_NO_PERSIST") == nullptr;
+    if (p->persist) {
+      if (N == 256)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_kernel2_256p), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)Launch2<Cfg256v2>::LDS_BYTES));
+      else
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_kernel2_128p), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)Launch2<Cfg128v2>::LDS_BYTES));
+    }
 #if defined(RPSF_VGPR_CAP)  // (development builds only: the product's patch kernel takes all 512 registers of a SIMD lane)
     p->cosum = p->persist && std::getenv("RPSF_COSUM") != nullptr;
 #endif
@@ -869,7 +876,7 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
         ts.planes_frame_floats = 4 * p->planes_floats, ts.out_frame_floats = b.out_stride;
         int nsum = std::max(8, std::min(ts.count, p->round_capacity));  // at the tail: as many summing workgroups as the chip holds
         ts.queue = p->d_sum_queue, ts.queue_base = p->sum_queue_base;
-        if constexpr (std::is_same_v<C, Cfg256v2>) {
+        {
           // persistent form: as many patch workgroups as the chip holds beside the summing ones; each works through the slots
           // of its XCD's chunk and ends as a summing workgroup itself (no workgroups behind the patches)
           if (p->cosum) pp.sum_first = 0;  // the summing is done by waves beside the patch workgroups: every CU takes patches
@@ -894,7 +901,7 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
               HIP_TRY(hipEventRecord(p->ev_sum_go, st));
               HIP_TRY(hipStreamWaitEvent(p->st_sum, p->ev_sum_go, 0));
             }
-            patch_kernel2_256p<<<dim3((unsigned)wgs), dim3(Launch2<C>::WG), Launch2<C>::LDS_BYTES, st>>>(pp);
+            PersistentKernel2<C>::fn<<<dim3((unsigned)wgs), dim3(Launch2<C>::WG), Launch2<C>::LDS_BYTES, st>>>(pp);
             HIP_TRY(hipGetLastError());
             if (ncos) {  // ... and the apply is complete on `st` when they are
 #if defined(RPSF_VGPR_CAP)

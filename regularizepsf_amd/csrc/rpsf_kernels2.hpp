@@ -368,6 +368,19 @@ __global__ __launch_bounds__(Launch2<C>::WG, 2) void patch_kernel2(PatchParams p
 #define RPSF_VGPR_ATTR
 #endif
 extern "C" __global__ __launch_bounds__(512, 2) RPSF_VGPR_ATTR void patch_kernel2_256p(PatchParams p);
+// ... and of the 128-pixel plan (k2_128p.hip): four 128-thread workgroups per CU hide the dispatch of one another, but only
+// persistent ones keep the phase offsets of the start-up stagger
+extern "C" __global__ __launch_bounds__(128, 2) void patch_kernel2_128p(PatchParams p);
+template <class C>
+struct PersistentKernel2;
+template <>
+struct PersistentKernel2<Cfg256v2> {
+  static constexpr auto fn = &patch_kernel2_256p;
+};
+template <>
+struct PersistentKernel2<Cfg128v2> {
+  static constexpr auto fn = &patch_kernel2_128p;
+};
 
 // K pack: the caller's full complex64 K (n, N, N) -> folded pair words in the stream layout [word][thread], plus the
 // side array of the self-paired bin pairs
