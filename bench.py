@@ -300,7 +300,7 @@ def run_batch(args, rank, world, device, comm):
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "patch_kernel2" if n in (128, 256) else "patch_kernel",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "patch_kernel2_256p" if n == 256 else "patch_kernel2_128p" if n == 128 else "patch_kernel",
             "whole_step_ms": round(step_ms, 4), "frac_patch_kernel_only": round(achieved_kernel / HBM_PEAK_GBS, 4),
             "kernel_avg_ms": round(kern_avg_ms, 4), "kernel_launches": iters, "algorithmic_bytes": int(alg_bytes),
             "bytes_model": "packed folded K read once per batch + every frame read once + every output written once",
@@ -535,7 +535,7 @@ def main() -> None:
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
             "frac_of_measured_copy_ceiling": round(achieved / MEASURED_COPY_GBS, 4),
-            "kernel": "patch_kernel2_256p" if n == 256 else "patch_kernel2" if n == 128 else "patch_kernel",
+            "kernel": "patch_kernel2_256p" if n == 256 else "patch_kernel2_128p" if n == 128 else "patch_kernel",
             "whole_apply_ms": round(step_ms, 4), "kernel_avg_ms": round(kern_avg_ms, 4), "kernel_launches": iters,
             "frac_patch_kernel_only": round(achieved_kernel / HBM_PEAK_GBS, 4),
             "algorithmic_bytes": int(alg_bytes), "packed_k_bytes": int(plan.transfer_bytes),
