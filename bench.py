@@ -40,6 +40,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X spec peak, /opt/skills/guides/MI355X_MICROARCH.m
 MEASURED_COPY_GBS = 6290.0  # the same guide's measured device-copy ceiling (SURVEY.md 8d asks for both)
 
 CONFIGS = {  # name -> (height, width, patch, starfield seed)
+    1: (512, 512, 32, 1),      # BASELINE.json configs[0], the plumbing configuration: constant Gaussian PSF 1.8 -> 1.5 (its point is the cpu_baseline leg)
     2: (2048, 2048, 128, 2),
     3: (4096, 4096, 256, 3),
     4: (8192, 8192, 256, 4),   # BASELINE.json configs[3]: one 8192^2 frame, row bands over the ranks (strong scaling)
@@ -332,6 +333,10 @@ def main() -> None:
                     help="N = 1 only: this many DIFFERENT device-resident frames (and output buffers) are corrected in rotation.  "
                          "Default 1: the same frame every step, as in every earlier round - it then stays in the 256 MB Infinity "
                          "Cache between steps, which a stream of new frames would not (DESIGN.md, Measurement)")
+    ap.add_argument("--new-frames", type=int, default=8,
+                    help="N = 1: after the timed loop, a second timed loop of K steps over this many different resident frames and "
+                         "outputs in rotation; reported as roofline.frac_new_frames / ms_per_step_new_frames next to the headline "
+                         "(0 or 1: skip)")
     ap.add_argument("--in-flight", type=int, default=1,
                     help="N = 1 only: this many plans (own stream, planes and output; the same K) take turns, so that the head of "
                          "one apply overlaps the tail of the previous one - the throughput of a frame pipeline.  Default 1: one "
@@ -375,11 +380,14 @@ def main() -> None:
         if key in k_cache:
             return k_cache[key]
         out = k_cache[key] = np.empty((len(index), n, n), np.complex64)
-        tgt = orc.psf_fft(orc.gaussian_psf(n, 1.8))[None]
+        tgt = orc.psf_fft(orc.gaussian_psf(n, 1.5 if args.config == 1 else 1.8))[None]
         for first in range(0, len(index), 128):
             part = index[first:first + 128]
-            src = np.stack([orc.coma_psf(n, coords[i][0] % h1 if world > 1 and not strong else coords[i][0], coords[i][1], h1, w)
-                            for i in part])
+            if args.config == 1:  # constant Gaussian 1.8 -> 1.5
+                src = np.broadcast_to(orc.gaussian_psf(n, 1.8), (len(part), n, n))
+            else:
+                src = np.stack([orc.coma_psf(n, coords[i][0] % h1 if world > 1 and not strong else coords[i][0], coords[i][1], h1, w)
+                                for i in part])
             s_fft = orc.psf_fft(src, workers=-1)
             with np.errstate(all="ignore"):
                 kk = orc.construct_transfer(s_fft, np.broadcast_to(tgt, s_fft.shape), 3.0, 0.1)
@@ -480,6 +488,27 @@ def main() -> None:
         elapsed = comm.allreduce_max(elapsed)  # whole-job time = slowest rank
     ms_per_step = 1e3 * elapsed / args.steps
 
+    # ---------------- the same plan on a stream of NEW frames (N = 1): --new-frames different resident starfields and outputs in
+    # rotation.  The headline loop above corrects ONE frame K times (SURVEY.md 8d's timed region); that frame and part of its colour
+    # planes then sit in the 256 MB Infinity Cache from step to step, which a production stream of frames does not have.
+    new_frames_ms = None
+    if world == 1 and not rotation and not pipeline and args.new_frames > 1:
+        extra = []
+        for i in range(1, args.new_frames):
+            frame = orc.starfield(h1, w, seed + 1000 * i)[band.image_row0:band.image_row0 + band.image_rows]
+            extra.append((_native.DeviceBuffer(frame.nbytes, device).upload(np.ascontiguousarray(frame, np.float32)),
+                          _native.DeviceBuffer(band.out_rows * w * 4, device)))
+        ring = [(d_img, d_out)] + extra
+        for i in range(max(args.warmup, len(ring))):
+            plan.apply_device(ring[i % len(ring)][0].ptr, ring[i % len(ring)][1].ptr, geom)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            plan.apply_device(ring[i % len(ring)][0].ptr, ring[i % len(ring)][1].ptr, geom)
+        barrier()
+        new_frames_ms = 1e3 * (time.perf_counter() - t0) / args.steps
+        del extra, ring
+
     # ---------------- roofline: HIP events on the plan's stream, live ----------------
     # Algorithmic bytes: folded K read once (n N (N/2+1) complex64) + image read once + output written
     # once, over the whole device-resident apply of this rank (patch kernel + everything the overlap-add needs).  With
@@ -526,7 +555,7 @@ def main() -> None:
         "config": {
             "workload": f"{height}x{w} starfield, {n}x{n} patches, {len(coords)} patches "
                         f"({'whole image on one GPU' if world == 1 else f'{world} row bands, seam rows ' + ('recomputed by both neighbours (no data-path collective)' if args.seam == 'recompute' else f'exchanged over {args.comm.upper()}')}), "
-                        f"coma PSF grid -> Gaussian target, alpha=3 eps=0.1, pad symmetric",
+                        f"{'constant Gaussian PSF 1.8 -> 1.5' if args.config == 1 else 'coma PSF grid -> Gaussian target'}, alpha=3 eps=0.1, pad symmetric",
             "image": [height, w], "patch": n, "patches": len(coords), "device": name, "compute_units": cus,
             "resident": "image, output and packed transfer kernel in HBM before the timed region",
             "in_flight": 1 + len(pipeline), "frames_in_rotation": 1 + len(rotation),
@@ -544,6 +573,10 @@ def main() -> None:
             "apply_avg_ms_events": round(apply_avg_ms, 4), "patches_this_rank": my_patches,
         },
     }
+    if new_frames_ms is not None:  # same bytes, same plan, every step a frame the caches have not seen for args.new_frames - 1 applies
+        line["roofline"]["ms_per_step_new_frames"] = round(new_frames_ms, 4)
+        line["roofline"]["frac_new_frames"] = round(alg_bytes / (new_frames_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        line["roofline"]["new_frames_in_rotation"] = args.new_frames
     if pipeline:  # the overlapped steps priced on the same bytes (not roofline.frac: SURVEY 8d's t is one device-resident apply)
         line["roofline"]["frac_steps_in_flight"] = round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     traffic_file = ROOT / "profiles" / "traffic_latest.json"

@@ -106,6 +106,7 @@ struct rpsf_plan {
   uint32_t* d_sum_order = nullptr;   // all tiles, the ones whose contributors run first first
   uint32_t done_epoch = 0;
   size_t done_frames = 1;            // frames the tile counters are sized for (batches: one set per frame)
+  int done_last_frames = 1;          // frames of the last fused launch (the counters restart when the number changes)
   uint32_t* d_sum_queue = nullptr;   // position in d_sum_order, never reset
   uint32_t sum_queue_base = 0;
   bool no_fuse = false;
@@ -150,6 +151,8 @@ struct rpsf_plan {
   float* h_pin_out = nullptr;
   size_t pin_bytes = 0;
   hipEvent_t ev_chunk[16] = {};
+  float* d_carry = nullptr;  // persistent launches: one half patch of private scratch per workgroup
+  size_t carry_floats = 0;
   float* d_planes = nullptr;
   size_t planes_floats = 0;  // per plane
   size_t planes_frames = 0;  // frames the allocation holds (4 planes each)
@@ -665,6 +668,7 @@ extern "C" void rpsf_plan_destroy(rpsf_plan* p) {
   (void)hipFree(p->d_win_generic);
   if (p->fft_plan && g_hipfft.destroy) (void)g_hipfft.destroy(p->fft_plan);
   (void)hipFree(p->d_planes);
+  (void)hipFree(p->d_carry);
   (void)hipFree(p->d_quads);
   (void)hipFree(p->d_tile_info);
   (void)hipFree(p->d_flags);
@@ -878,7 +882,17 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
         ts.queue = p->d_sum_queue, ts.queue_base = p->sum_queue_base;
         {
           // persistent form: as many patch workgroups as the chip holds beside the summing ones; each works through the slots
-          // of its XCD's chunk and ends as a summing workgroup itself (no workgroups behind the patches)
+          // of its XCD's chunk and ends as a summing workgroup itself (no workgroups behind the patches).
+          // FORWARD PROGRESS.  HIP promises neither that a grid is resident as a whole nor an order of dispatch, and other launches
+          // (a second plan on another stream, RCCL's kernels) may hold CUs.  What this launch needs: (1) every patch slot is drawn
+          // from its chunk's queue - none is tied to a particular workgroup - so the slots of chunk x are worked off by whichever
+          // workgroups with blockIdx % 8 == x are resident, and a workgroup turns to summing only when its chunk's queue is empty,
+          // i.e. when every remaining patch of the chunk is in the hands of a resident workgroup that does not wait for anything;
+          // (2) summing workgroups wait (poll + s_sleep) only for tiles whose patches are drawn or will be drawn by (1).  So the
+          // launch completes as soon as, for every chunk, ONE patch workgroup gets a CU: in dispatch order the first sum_first + 8
+          // workgroups.  The only workgroups that hold a CU without progress of their own are the sum_first (<= 32) head summing
+          // ones; concurrent persistent launches therefore cannot starve one another unless their head summing workgroups alone
+          // fill the chip (tests: test_two_persistent_plans_on_two_streams).
           if (p->cosum) pp.sum_first = 0;  // the summing is done by waves beside the patch workgroups: every CU takes patches
           // (queue positions of an XCD: chunk slots x frames, the frames of a slot side by side)
           const int rows = std::min(pp.chunk * b.frames, std::max(1, (p->round_capacity - pp.sum_first - p->reserved_cus) / 8));
@@ -892,9 +906,22 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
             if (p->stagger_us < 0 && (long)p->n_patches * tune_frames >= 256) pp.stagger_ticks = (long)p->n_patches * tune_frames >= 2048 ? 2400 : 1200;
             for (int x = 0; x < 8; ++x) {
               pp.xq_base[x] = p->xq_base[x];
-              p->xq_base[x] += (uint32_t)(std::min(pp.chunk, std::max(0, p->n_patches - x * pp.chunk)) * b.frames);  // draws of this launch
+              // draws of this launch: one per slot and frame, plus the one past the end that tells each of the chunk's workgroups to stop
+              p->xq_base[x] += (uint32_t)(std::min(pp.chunk, std::max(0, p->n_patches - x * pp.chunk)) * b.frames + rows);
             }
             const int wgs = pp.sum_first + 8 * rows;
+#if defined(RPSF_DEV_CARRY)
+            const size_t carry_need = (size_t)std::max(wgs, 512) * C::T * 64;
+            if (carry_need > p->carry_floats) {
+              HIP_TRY(hipDeviceSynchronize());
+              (void)hipFree(p->d_carry);
+              p->d_carry = nullptr, p->carry_floats = 0;
+              HIP_TRY(hipMalloc(&p->d_carry, carry_need * sizeof(float)));
+              HIP_TRY(hipMemset(p->d_carry, 0, carry_need * sizeof(float)));
+              p->carry_floats = carry_need;
+            }
+            pp.carry = p->d_carry;
+#endif
             const int ncos = p->cosum ? p->cu_count : 0;  // one workgroup of summing waves per CU
             p->sum_queue_base += (uint32_t)(ts.count + wgs + ncos);  // every workgroup draws one position past the end
             if (ncos) {  // the summing waves may start once everything before this apply on `st` is done ...
@@ -1086,10 +1113,16 @@ static int launch_apply(rpsf_plan* p, const float* d_img, float* d_out, const rp
       HIP_TRY(hipMemset(p->d_tile_done, 0, n_tiles * b.frames * sizeof(uint32_t)));
       p->done_frames = (size_t)b.frames, p->done_epoch = 0;
     }
-    if (++p->done_epoch >= (1u << 29)) {  // the counters hold epoch * contributors
+    // A launch advances the counters of frames [0, b.frames) only, and a tile is complete at epoch x contributors: when the frame
+    // count differs from the previous fused launch's (batch -> single apply -> batch, or the short last group of a batch) the
+    // counters of the higher frames would lag behind the epoch for ever - and the summing workgroups would wait for ever.
+    // Start a new count whenever the frame count changes (and when the epoch would overflow the counters).
+    if (b.frames != p->done_last_frames || p->done_epoch + 1 >= (1u << 29)) {  // the counters hold epoch * contributors
       HIP_TRY(hipMemsetAsync(p->d_tile_done, 0, n_tiles * p->done_frames * sizeof(uint32_t), st));
-      p->done_epoch = 1;
+      p->done_epoch = 0;
     }
+    p->done_last_frames = b.frames;
+    ++p->done_epoch;
     // the tile sums write lattice tiles only: pixels of the window outside the tile grid are cleared here
     const int half = p->N / 2;
     if (tile_r0 > g.out_row0 || tile_r0 + (long)p->nti * half < (long)g.out_row0 + g.out_rows || tile_c0 > 0 ||

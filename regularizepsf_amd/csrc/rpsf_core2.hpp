@@ -587,6 +587,10 @@ RPSF_HD void store_patch2(int t, const cf* v, const OutView& pv, const OutView& 
         const cf a = v[2 * (R1 * NCOL + C1)], b = v[2 * (R1 * NCOL + C1) + 1];
         f32x4 val = {a.x * (w4.x * wr), a.y * (w4.y * wr), b.x * (w4.z * wr), b.y * (w4.w * wr)};
         if (!qw || quad_mode(qw[QD]) == QUAD_SIDE) {
+#if defined(RPSF_DEV_QUAD)  // timing experiment (results are wrong): the plane traffic of 2 x 2 patches whose overlaps were summed on chip -
+          // of the 16 quadrants of such a group 9 reach a plane
+          if (!(((plane == 0 ? 1 : plane == 1 ? 3 : plane == 2 ? 5 : 15) >> QD) & 1)) return;
+#endif
           pstore4(prow0 + (size_t)r * pv.ld + 4 * cp, val);
         } else if (quad_mode(qw[QD]) == QUAD_DIRECT) {
           val += old[U];
@@ -645,6 +649,48 @@ RPSF_HD void store_patch2(int t, const cf* v, const OutView& pv, const OutView& 
     }
   });
 }
+
+// Development (RPSF_DEV_CARRY, timing experiment): interior patches only.  carry: [R1][thread] 16-byte units, private to the workgroup.
+#if defined(RPSF_DEV_CARRY_AUX_LD) || defined(RPSF_DEV_CARRY)
+#if !defined(RPSF_DEV_CARRY_NT)
+#define RPSF_DEV_CARRY_NT 0
+#endif
+template <class C, class CLOAD, class PSTORE4>
+RPSF_HD void store_patch2_carry(int t, const cf* v, const OutView& pv, int plane, int pr, int pc, const float* __restrict__ win,
+                                const float* carry_in, float* carry_out, CLOAD&& cload, PSTORE4&& pstore4) {
+  ThreadPos2<C> tp(t);
+  constexpr int NR = 1 << C::A1, NCOL = 1 << C::B1;
+  static_assert(NCOL == 2, "left and right half");
+  float* prow0 = pv.out + (size_t)plane * pv.plane_stride + (size_t)(pr - pv.row0) * pv.ld + pc;
+  const f32x4* ci = reinterpret_cast<const f32x4*>(carry_in) + t;
+  f32x4* cb = reinterpret_cast<f32x4*>(carry_out) + t;
+  f32x4 cin[NR];
+  StaticFor<0, NR>::run([&]<int R1>() RPSF_AI {
+    cin[R1] = cload(ci + R1 * C::T);
+  });
+  StaticFor<0, NR>::run([&]<int R1>() RPSF_AI {
+    const int r = (R1 << (C::A2 + C::AL)) + tp.r_low, cp = (1 << C::B2) + tp.c2;
+    const float wr = win[r];
+    const f32x4 w4 = *reinterpret_cast<const f32x4*>(win + 4 * cp);
+    const cf a = v[2 * (R1 * NCOL + 1)], b = v[2 * (R1 * NCOL + 1) + 1];
+    const f32x4 val = {a.x * (w4.x * wr), a.y * (w4.y * wr), b.x * (w4.z * wr), b.y * (w4.w * wr)};
+#if RPSF_DEV_CARRY_NT & 2
+    __builtin_nontemporal_store(val, cb + R1 * C::T);
+#else
+    cb[R1 * C::T] = val;
+#endif
+  });
+  StaticFor<0, NR>::run([&]<int R1>() RPSF_AI {
+    const int r = (R1 << (C::A2 + C::AL)) + tp.r_low, cp = tp.c2;
+    const float wr = win[r];
+    const f32x4 w4 = *reinterpret_cast<const f32x4*>(win + 4 * cp);
+    const cf a = v[2 * (R1 * NCOL)], b = v[2 * (R1 * NCOL) + 1];
+    f32x4 val = {a.x * (w4.x * wr), a.y * (w4.y * wr), b.x * (w4.z * wr), b.y * (w4.w * wr)};
+    val += cin[R1];
+    pstore4(prow0 + (size_t)r * pv.ld + 4 * cp, val);
+  });
+}
+#endif
 
 // Plans compiled into the library
 using Cfg256v2 = Cfg2<8, 4, 0, 4, 1, 5>;

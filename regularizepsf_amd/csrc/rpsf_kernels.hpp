@@ -92,11 +92,19 @@ __device__ __forceinline__ void sum_tile(const TileSum& p0, uint32_t entry, int 
   p.out += (size_t)frame * p0.out_frame_floats;
   if (p.done) p.done += (size_t)frame * p0.n_tiles;
   const int ti = tile / p.ntj, tj = tile % p.ntj;
-  const int cov = p.cover[tile];
+  const int cov_all = p.cover[tile];
+#if defined(RPSF_DEV_CARRY)  // timing experiment: two planes by lattice-row parity (results are wrong)
+  const int cov = (cov_all | (cov_all >> 1)) & 5;
+#elif defined(RPSF_DEV_QUAD)  // timing experiment: the planes a tile would be read from if 2 x 2 groups of patches were pre-summed on chip
+  const int c0_ = ((ti & 1) << 1) | (tj & 1);
+  const int cov = cov_all & ((1 << c0_) | ((tj & 1) ? 0 : 1 << (c0_ ^ 1)) | ((ti & 1) ? 0 : 1 << (c0_ ^ 2)) | (((ti | tj) & 1) ? 0 : 1 << (c0_ ^ 3)));
+#else
+  const int cov = cov_all;
+#endif
   const bool fused = p.done != nullptr;
   if (fused && !known_complete) {  // wait until every contributor of the tile has published its stores
     if (tid == 0) {
-      const uint32_t want = p.epoch * (uint32_t)__builtin_popcount(cov & 15);
+      const uint32_t want = p.epoch * (uint32_t)__builtin_popcount(cov_all & 15);
       while (__hip_atomic_load(p.done + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) __builtin_amdgcn_s_sleep(4);
     }
     __syncthreads();
@@ -261,6 +269,7 @@ struct PatchParams {
   int persist;
   uint32_t* xq;
   uint32_t xq_base[8];
+  float* carry;  // development (RPSF_DEV_CARRY): one half patch of private scratch per persistent workgroup
 };
 
 template <class C>

@@ -93,6 +93,17 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   int frame = 0, xrow = 0, seq = 0;
   if (patchy) {
     xrow = p.slot0 + (pb >> 3);
+    if constexpr (PERSIST) {
+      // Every slot comes from the XCD chunk's queue, the first one included (position 0 = slot 0): no slot is tied to a workgroup
+      // that may not be resident yet, so whichever workgroups of a chunk ARE resident drain it (forward progress: rpsf.hip, launch_patches).
+      if (!again) {
+        unsigned* const word = reinterpret_cast<unsigned*>(reinterpret_cast<cf*>(smem + Launch2<C>::TABLE_FLOATS) + C::BUF_UNITS);
+        if (t == 0) *word = __hip_atomic_fetch_add(p.xq + (pb & 7) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.xq_base[pb & 7];
+        lds_barrier();
+        xrow = (int)__builtin_amdgcn_readfirstlane(*word);
+        if (xrow < 0 || xrow > 0x0fffffff) xrow = 0x0fffffff;  // (queue positions stay far below; keeps the frame arithmetic in range)
+      }
+    }
     if (p.n_frames > 1) {
       if (p.frame_major) {  // persistent batches of large frames: one frame after the other (its planes stay in the Infinity Cache)
         const int left = p.n_patches - (pb & 7) * p.chunk, mine = left < p.chunk ? (left > 0 ? left : 1) : p.chunk;  // slots of this XCD
@@ -143,7 +154,11 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   if (p.stagger_ticks > 0 && pb < p.stagger_blocks && !again) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     // evenly spaced delays in bit-reversed order of the chunk row (profiles/r02av: -1 % against hashed delays at 12 us)
+#if defined(RPSF_DEV_STAGGER_LINEAR)  // development: delays in chunk-row order (neighbours in the queue start next to each other in time)
+    const unsigned long long wait = (unsigned long long)((unsigned)(pb >> 3) & 31u) * p.stagger_ticks >> 5;
+#else
     const unsigned long long wait = (unsigned long long)(__brev((unsigned)pb >> 3) >> 22) * p.stagger_ticks >> 10;
+#endif
     while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
   }
   STAMP(0);
@@ -184,6 +199,9 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
     if (t < Launch2<C>::OT_WORDS) ot[t] = ot0;
   }
   lds_barrier();  // tables staged; the maps (which share LDS with the exchange buffer) are no longer needed
+#if defined(RPSF_DEV_CARRY)  // timing experiment: the workgroup's private carry slot, kept in an unused word of the bin-pair table
+  if (PERSIST && !again && t == 0) ot[Launch2<C>::OT_WORDS - 1] = blockIdx.x & 0x3fffffffu;
+#endif
   window_patch2<C>(t, v, win);
   STAMP(1);
   // ---- forward: the halves leapfrog through stage 1, X1 (wave-local) and stage 2 ----
@@ -312,7 +330,7 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
     const __amdgpu_buffer_rsrc_t rsrc = plane_rsrc(pbase);
     // persistent: the next slot of this XCD's chunk, drawn now so that the round trip hides under the stores (VMEM returns
     // in order: the value is back before the stores are acknowledged).  xq counters are never reset: this launch owns the
-    // positions from xq_base[xcd] on, position 0 = slot p.persist (the first p.persist slots went to the resident workgroups)
+    // positions from xq_base[xcd] on, position 0 = slot 0
     unsigned drawn = 0, my_tile = 0;
     if constexpr (PERSIST) {
       if (t < 4) {  // (and the tiles this patch will be counted on: a load behind the stores would wait for them)
@@ -320,8 +338,37 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
         my_tile = (unsigned)frame * p.n_tiles + quad_tile(t == 0 ? q4.x : t == 1 ? q4.y : t == 2 ? q4.z : q4.w);  // (this frame's counters)
       }
       if (t == 0)
-        drawn = __hip_atomic_fetch_add(p.xq + (pb & 7) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.xq_base[pb & 7] + (unsigned)p.persist;
+        drawn = __hip_atomic_fetch_add(p.xq + (pb & 7) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.xq_base[pb & 7];
     }
+#if defined(RPSF_DEV_CARRY)
+    // timing experiment (results are wrong): the right half of every patch goes to the workgroup's private carry buffer, what the
+    // previous patch left there is added to the left half, and only that reaches a colour plane (two planes, by lattice-row parity)
+    if (PERSIST && patch_inside<C>(pr, pc, ov.H, ov.W, ov.row0, ov.rows) && quads_aligned(ov.out, ov.ld, pc)) {
+#if RPSF_DEV_CARRY >= 2  // ring of hand-off buffers per XCD chunk: queue position q writes slot q % 64 and reads slot (q - 1) % 64 - what the
+                         // workgroup that drew the previous position (a neighbour on the same XCD, a moment ago) wrote (no flags: timing only)
+      float* const cw = p.carry + (size_t)((pb & 7) * 64 + (xrow & 63)) * (C::T * 64);
+      float* const cr = p.carry + (size_t)((pb & 7) * 64 + ((xrow + 63) & 63)) * (C::T * 64);
+#else
+      float* const cw = p.carry + (size_t)ot[Launch2<C>::OT_WORDS - 1] * (C::T * 64);
+      float* const cr = cw;
+#endif
+      const __amdgpu_buffer_rsrc_t crs = plane_rsrc(p.carry);
+      const float* const cbase = p.carry;
+      store_patch2_carry<C>(t, v, ov, plane & 2, pr, pc, win, cr, cw,
+                            [=](const f32x4* a) RPSF_AI {
+#if RPSF_DEV_CARRY_NT & 4  // L1-bypassing (agent-scope) loads: what a hand-off from another workgroup needs
+                              typedef int i32x4 __attribute__((ext_vector_type(4)));
+                              const i32x4 q = __builtin_amdgcn_raw_buffer_load_b128(crs, (int)((reinterpret_cast<const float*>(a) - cbase) * sizeof(float)), 0, /*sc1*/ 16);
+                              return f32x4{__int_as_float(q.x), __int_as_float(q.y), __int_as_float(q.z), __int_as_float(q.w)};
+#elif RPSF_DEV_CARRY_NT & 1
+                              return __builtin_nontemporal_load(a);
+#else
+                              return *a;
+#endif
+                            },
+                            [=](float* a, f32x4 val) RPSF_AI { plane_store16_wt(rsrc, (size_t)(a - pbase), val); });
+    } else
+#endif
     store_patch2<C>(
         t, v, ov, ov, plane, pr, pc, win, nullptr, add, []<int R1, int C1>(const float* a) RPSF_AI { return *reinterpret_cast<const f32x4*>(a); },
         [](const float* a) { return *a; }, [=](float* a, f32x4 val) RPSF_AI { plane_store16_wt(rsrc, (size_t)(a - pbase), val); },

@@ -139,8 +139,8 @@ class ShardedApply:
     """One rank's share of a row-band-sharded apply: local K1 launch(es), then the RCCL seam exchange.
 
     ``seam="exchange"`` with ``overlap=True`` (default) hides the transfer behind the band's own work: the spill rows depend
-    only on the band's LAST lattice row of patches, so those run first, as a plan of their own on a stream of their own,
-    straight into a spill buffer; the send (and the receive from the rank above) follows on that stream while the main plan -
+    only on the band's LAST lattice row of patches (in general: on every patch that reaches below the band's own rows), so
+    those run first, as a plan of their own on a stream of their own, straight into a spill buffer; the send (and the receive from the rank above) follows on that stream while the main plan -
     all patches of the band, output cropped to the rows the band owns - is still running on the other.  The received rows
     are added (K4) once both are done.  The last lattice row is computed twice (65 of 520 patches at eight bands of the
     8192-wide configuration; they fit into the band's partial last round).  ``overlap=False`` is the plain sequence
@@ -175,8 +175,10 @@ class ShardedApply:
                                              b.out_row0, b.own_rows, width)
             self.d_out = _native.DeviceBuffer(b.own_rows * width * 4, device)
             if b.send_rows > 0:
-                last_row = max(int(coordinates[i][0]) for i in b.patch_index)
-                seam_index = [i for i in b.patch_index if int(coordinates[i][0]) == last_row]
+                # every patch of the band that reaches below the rows the band owns (on the half-overlap lattice of
+                # calculate_covering: the band's last lattice row; with a finer or irregular row spacing earlier rows too)
+                own_end = b.out_row0 + b.own_rows
+                seam_index = [i for i in b.patch_index if int(coordinates[i][0]) + patch_size > own_end]
                 self.seam_plan = _native.Plan(patch_size, [tuple(int(v) for v in coordinates[i]) for i in seam_index], device=device)
                 self.seam_plan.set_transfer(kernel_for(seam_index))
                 self.seam_geometry = _native.Geometry(height, width, pm, 0.0, 0, 0, b.image_row0, b.image_rows, width,
@@ -202,6 +204,11 @@ class ShardedApply:
                                             self.d_recv.ptr, b.recv_rows * w, self.d_out.ptr, self.plan.stream)
             return
         xstream = self.seam_plan.stream if self.seam_plan is not None else (self.comm.stream if self.comm is not None else None)
+        if xstream is not None:
+            # the previous step's add (main stream) reads d_recv, and its main plan may still run: the next seam apply and
+            # the next receive must not start before both are done (they would overwrite d_recv under the add, and two
+            # persistent launches of consecutive steps would compete for the CUs)
+            _native.stream_wait(xstream, self.plan.stream, self.device)
         if self.seam_plan is not None:  # first in line: its workgroups are dispatched ahead of the main plan's
             self.seam_plan.apply_device(self.d_img.ptr, self.d_spill.ptr, self.seam_geometry)
         self.plan.apply_device(self.d_img.ptr, self.d_out.ptr, self.geometry)

@@ -72,8 +72,31 @@ def complex128_case(util, psf, transform) -> None:
     print("c128_n64", len(coords), expected.shape, float(np.abs(expected).max()))
 
 
+def config1_case(util, psf, transform) -> None:
+    """(vi) BASELINE.json configs[0] at full size: 512 x 512 starfield (seed 1), 32-px patches (1089 of them), constant Gaussian
+    PSF 1.8 -> 1.5, alpha 3, eps 0.1.  The inputs are regenerated from their seeds by the tests; stored are the reference's K
+    and output as SHA-256 (the oracle is bit-identical or it is wrong) plus every 8th output pixel for eyes and tolerances."""
+    h = w = 512
+    n, alpha, eps, seed = 32, 3.0, 0.1, 1
+    coords = [tuple(int(v) for v in t) for t in util.calculate_covering((h, w), n)]
+    src, tgt = make_psfs("gauss", coords, n, h, w)
+    s = psf.ArrayPSF(util.IndexedCube(coords, src))
+    t = psf.ArrayPSF(util.IndexedCube(coords, tgt))
+    k64 = transform.ArrayPSFTransform.construct(s, t, alpha, eps)._transfer_kernel.values.astype(np.complex64)
+    assert np.isfinite(k64).all() and len(coords) == 1089
+    image = orc.starfield(h, w, seed)
+    expected = transform.ArrayPSFTransform(util.IndexedCube(coords, k64)).apply(image)
+    np.savez_compressed(HERE / "config1_512_n32.npz", k_sha256=np.array(sha(k64)), out_sha256=np.array(sha(expected)),
+                        image_sha256=np.array(sha(image)), sample=expected[::8, ::8].copy(), meta=np.array([h, w, n]),
+                        alpha=np.array(alpha), eps=np.array(eps), seed=np.array(seed))
+    print("config1", len(coords), expected.shape, float(np.abs(expected).max()))
+
+
 def main() -> None:
     util, psf, transform = load_reference()
+    if "--only-config1" in sys.argv:  # added in round 3: leaves the other fixtures byte for byte as they are
+        config1_case(util, psf, transform)
+        return
     if "--only-c128" in sys.argv:  # added in round 2: leaves the other fixtures byte for byte as they are
         complex128_case(util, psf, transform)
         return
@@ -156,6 +179,7 @@ def main() -> None:
                                                    neighborhood_width=nbw)
     np.savez_compressed(HERE / "apply_saturation.npz", image=image, coords=np.array(coords, np.int64), **sat)
     complex128_case(util, psf, transform)
+    config1_case(util, psf, transform)
     print("done")
 
 

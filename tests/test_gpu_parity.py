@@ -114,6 +114,28 @@ def test_gpu_psf_fft_matches_scipy():
         assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
 
 
+def test_config1_512_n32_through_the_class_api():
+    """BASELINE.json configs[0] (the plumbing configuration: 512 x 512 starfield seed 1, 32-px patches, 1089 of them, constant
+    Gaussian PSF 1.8 -> 1.5) through ArrayPSF / ArrayPSFTransform.construct / apply on the GPU, against the reference's own output
+    (every 8th pixel stored in tests/golden/config1_512_n32.npz; the whole frame through the oracle, whose SHA-256 the CPU suite
+    pins to the reference's)."""
+    fx = np.load(GOLDEN / "config1_512_n32.npz")
+    h, w, n = (int(v) for v in fx["meta"])
+    coords = [tuple(int(v) for v in c) for c in rp.calculate_covering((h, w), n)]
+    assert len(coords) == 1089
+    src, tgt = make_psfs("gauss", coords, n, h, w)
+    transform = rp.ArrayPSFTransform.construct(rp.ArrayPSF(rp.IndexedCube(coords, src)), rp.ArrayPSF(rp.IndexedCube(coords, tgt)),
+                                               float(fx["alpha"]), float(fx["eps"]))
+    image = orc.starfield(h, w, int(fx["seed"]))
+    out = transform.apply(image)
+    assert out.dtype == np.float64 and out.shape == (h, w)
+    _, k = orc.synthetic_transfer(h, w, n, alpha=float(fx["alpha"]), epsilon=float(fx["eps"]), kind="gauss")
+    ref = orc.apply_transfer(image, coords, k)
+    check(out, ref)
+    assert np.abs(out[::8, ::8] - fx["sample"]).max() <= TOL * np.abs(ref).max()
+    assert np.array_equal(transform.apply(2 * image), 2 * out)  # linear; exactly so for a power of two
+
+
 def test_config2_2048_n128_against_oracle():
     """BASELINE.json configs[1]: 2048^2, 128-pixel patches, slowly varying coma PSF grid."""
     coords, k = orc.synthetic_transfer(2048, 2048, 128, alpha=3.0, epsilon=0.1)
@@ -622,6 +644,62 @@ def test_config4_8192_n256_eight_bands_both_seam_modes():
         assert np.abs(got - rows).max() <= TOL * np.abs(ref).max()
 
 
+@pytest.mark.timeout(1500, method="thread")
+def test_two_persistent_plans_on_two_streams():
+    """What ShardedApply(overlap=True) asks of the device at eight bands of the 8192-wide configuration: two persistent launches of
+    the 256-px plan in flight at once - the seam plan (65 patches: 72 workgroups) on its stream and the main plan (520 patches:
+    8 summing + 240 patch workgroups, 8 CUs left free) on the other, 320 workgroups for 256 CUs - with a third stream running K4
+    beside them (the stand-in for RCCL's send/recv kernels).  200 steps, two different frames; every step the same bits, the first
+    against the oracle.  (Forward progress of concurrent persistent launches: rpsf.hip, launch_patches.)"""
+    from regularizepsf_amd import _native
+    from regularizepsf_amd.sharding import ShardedApply
+
+    h = w = 8192
+    n, world, rank = 256, 8, 3
+    coords = [tuple(int(v) for v in t) for t in orc.calculate_covering((h, w), n)]
+    rng = np.random.default_rng(11)
+    k_of = {}
+
+    def kernel_for(index):
+        for i in index:
+            if i not in k_of:
+                k_of[i] = (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))).astype(np.complex64)
+        return np.stack([k_of[i] for i in index])
+
+    sh = ShardedApply(coords, kernel_for, n, h, w, rank, world, 0, None, overlap=True)
+    b = sh.band
+    assert sh.overlap and sh.seam_plan is not None and len(b.patch_index) == 520 and b.send_rows == 128
+    sh.plan.set_reserved_cus(8)  # as with a communicator attached
+    side = _native.Plan(16, [(0, 0)])  # a third stream
+    count = 8 * 256 * 4
+    d_a = _native.DeviceBuffer(count * 4).upload(np.zeros(count, np.float32))
+    d_b = _native.DeviceBuffer(count * 4).upload(np.ones(count, np.float32))
+    frames = [(rng.standard_normal((b.image_rows, w)) * 10 + 50 + 20 * f).astype(np.float32) for f in range(2)]
+    first = {}
+    steps = 0
+    for f in (0, 1, 0, 1):
+        sh.upload_rows(frames[f])
+        for _ in range(2):
+            for _ in range(25):
+                sh.step()
+                _native.add_rows(d_a.ptr, d_b.ptr, count, 0, side.stream)
+                steps += 1
+            got = (sh.owned_rows(), sh.spill_rows())
+            if f not in first:
+                first[f] = got
+            assert np.array_equal(got[0], first[f][0]) and np.array_equal(got[1], first[f][1]), (f, steps)
+    assert steps == 200
+    _native.check(_native.lib().rpsf_device_synchronize(0))
+    assert np.array_equal(d_a.download((count,)), np.full(count, float(steps), np.float32))
+    # the band's patches alone (nothing arrives from the band above in this test) against the oracle, frame 0
+    local = [(coords[i][0] - b.image_row0, coords[i][1]) for i in b.patch_index]
+    ref = orc.apply_transfer(frames[0], local, kernel_for(b.patch_index), workers=-1)
+    r0 = b.out_row0 - b.image_row0
+    scale = np.abs(ref).max()
+    assert np.abs(first[0][0] - ref[r0 : r0 + b.own_rows]).max() <= TOL * scale
+    assert np.abs(first[0][1] - ref[r0 + b.own_rows : r0 + b.own_rows + b.send_rows]).max() <= TOL * scale
+
+
 def test_config5_2048_frames_sharing_one_kernel():
     """BASELINE.json configs[4] at its real frame size: a batch of 2048^2 starfields, 128-px patches, one shared transfer
     kernel, corrected in one launch on the device; first and last frame against the CPU oracle."""
@@ -640,6 +718,41 @@ def test_config5_2048_frames_sharing_one_kernel():
     for f in (0, frames - 1):
         check(out[f].astype(np.float64), orc.apply_transfer(images[f], coords, k, workers=-1))
     assert np.array_equal(out[3], plan.apply(images[3], 1))  # the batch is the frame-by-frame loop, bit for bit
+
+
+@pytest.mark.timeout(300, method="thread")
+@pytest.mark.parametrize(("n", "size"), [(128, 768), (256, 1024)])
+def test_batches_and_single_applies_in_any_order_on_one_plan(n, size):
+    """The fused launches count finished patches on per-(frame, tile) counters that are never reset inside a run of equal
+    launches (a tile is complete at epoch x contributors).  Launches of different frame counts on ONE plan - batch(8) ->
+    apply -> batch(8), batch(8) -> batch(3) -> batch(8) - must restart the count (a launch advances only the counters of
+    its own frames); every result bit-identical to the first batch."""
+    from regularizepsf_amd import _native
+
+    frames = 8
+    rng = np.random.default_rng(n)
+    coords = [tuple(int(v) for v in c) for c in rp.calculate_covering((size, size), n)]
+    k = (rng.standard_normal((len(coords), n, n)) + 1j * rng.standard_normal((len(coords), n, n))).astype(np.complex64)
+    images = (rng.standard_normal((frames, size, size)) * 10 + 50).astype(np.float32)
+    plan = _native.Plan(n, coords)
+    plan.set_transfer(k)
+    d_in = _native.DeviceBuffer(images.nbytes).upload(images)
+    d_out = _native.DeviceBuffer(images.nbytes)
+    geom = _native.Geometry.whole(size, size, 1)
+
+    def batch(count):
+        d_out.upload(np.zeros_like(images))
+        plan.apply_batch_device(d_in.ptr, d_out.ptr, count, size * size, size * size, geom)
+        plan.synchronize()
+        return d_out.download((frames, size, size))[:count]
+
+    first = batch(frames)
+    check(first[frames - 1].astype(np.float64), orc.apply_transfer(images[frames - 1], coords, k))
+    for count in (1, frames, 3, frames, 1, 1, 5, frames):
+        if count == 1:
+            assert np.array_equal(plan.apply(images[2], 1), first[2])
+        else:
+            assert np.array_equal(batch(count), first[:count]), count
 
 
 def test_seam_add_kernel_adds():

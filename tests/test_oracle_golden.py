@@ -85,3 +85,34 @@ def test_apply_with_complex128_kernel_bit_identical_to_reference():
     fx, coords, k = load_c128_case()
     out = orc.apply_transfer(fx["image"], coords, k)
     assert np.array_equal(out, fx["expected"])
+
+
+def _config1():
+    """BASELINE.json configs[0]: 512 x 512 starfield (seed 1), 32-px patches, constant Gaussian PSF 1.8 -> 1.5, alpha 3, eps 0.1."""
+    fx = np.load(GOLDEN / "config1_512_n32.npz")
+    h, w, n = (int(v) for v in fx["meta"])
+    coords, k = orc.synthetic_transfer(h, w, n, alpha=float(fx["alpha"]), epsilon=float(fx["eps"]), kind="gauss")
+    image = orc.starfield(h, w, int(fx["seed"]))
+    return fx, coords, k, image
+
+
+def test_config1_512_n32_full_size_bit_identical_to_reference():
+    """The plumbing configuration at its real size (1089 patches): the oracle reproduces the reference's K and output to the bit
+    (SHA-256 recorded from the reference by tests/golden/make_golden.py), it is linear in the image, and with source == target
+    the transform is the identity within the reference test's own bound
+    (tests/test_transform.py:29-49: atol 1e-3 on a frame of 5s)."""
+    from tests.helpers import sha
+
+    fx, coords, k, image = _config1()
+    assert len(coords) == 1089 and sha(image) == str(fx["image_sha256"]) and sha(k) == str(fx["k_sha256"])
+    out = orc.apply_transfer(image, coords, k)
+    assert out.dtype == np.float64 and out.shape == image.shape
+    assert sha(out) == str(fx["out_sha256"])
+    assert np.array_equal(out[::8, ::8], fx["sample"])
+    assert np.array_equal(orc.apply_transfer(2 * image, coords, k), 2 * out)  # linear, and exactly so for a power of two
+    # identity-style bound, as upstream
+    s_fft = orc.psf_fft(np.broadcast_to(orc.gaussian_psf(32, 1.8), (len(coords), 32, 32)))
+    ident = orc.construct_transfer(s_fft, s_fft, 3.0, 0.1).astype(np.complex64)
+    flat = np.zeros((512, 512), np.float32)
+    flat[120:250, 50:100] = 5
+    assert np.allclose(orc.apply_transfer(flat, coords, ident), flat, atol=1e-3)
