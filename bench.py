@@ -7,9 +7,9 @@ kernel resident in HBM.
   N = 1: the headline workload, BASELINE.json configs[2]: 4096x4096 image, 256x256 patches, 1089-patch lattice, coma PSF
          grid -> Gaussian target, alpha=3, eps=0.1.
   N > 1 (launched by torch.distributed.run, one process per GPU): BASELINE.json configs[3], ONE 8192x8192 frame cut into
-         N row bands of the patch lattice (strong scaling); the rows a band's last lattice row spills into the next band are
-         sent to that rank with RCCL send/recv and added there, inside the timed region (`--seam exchange`, the default;
-         `--seam recompute` lets both neighbours compute the seam lattice row instead: no data-path collective).
+         N row bands of the patch lattice (strong scaling).  `--seam recompute` (default): both neighbours compute the lattice row
+         on their seam, no data-path collective; `--seam exchange`: the rows a band's last lattice row spills into the next band
+         are sent to that rank with RCCL send/recv and added there, inside the timed region.
          `--weak` keeps the per-GPU work fixed instead (a (4096 N) x 4096 image of config 3's recipe).
 torch is used here only for the launcher's rendezvous: a gloo group broadcasts the 128-byte RCCL unique id; the compute
 path, the barrier/max-reduction around the timed region and the seam exchange are ctypes -> librpsf_hip.so (RCCL is loaded
@@ -344,10 +344,13 @@ def main() -> None:
     ap.add_argument("--no-overlap", action="store_true",
                     help="--seam exchange: plain apply -> send/recv -> add on one stream instead of computing the spill rows "
                          "first and sending them beside the rest of the band")
-    ap.add_argument("--seam", choices=["recompute", "exchange"], default="exchange",
-                    help="N > 1: 'exchange' - the spill rows of a band are sent to the next rank with RCCL send/recv and added "
-                         "there (BASELINE's halo reduce); 'recompute' - every band also runs the lattice row above it that "
-                         "reaches into its rows (no data-path collective, more patches)")
+    ap.add_argument("--seam", choices=["recompute", "exchange"], default="recompute",
+                    help="N > 1: 'recompute' (default) - every band also runs the lattice row above it that reaches into its rows and "
+                         "the bands are cut so that own + recomputed patches balance (585 per rank at eight bands of the 8192-wide "
+                         "frame): no data-path collective, RCCL carries only the barrier and the max-reduction of the timed region; "
+                         "'exchange' - the spill rows of a band are sent to the next rank with RCCL send/recv and added there "
+                         "(BASELINE's halo reduce).  Measured band by band on one GPU with the product's own step (scripts/band_times.py, "
+                         "profiles/r03e_*): 5.8x against 5.1x at eight bands, which is why recompute is the default (DESIGN.md 7)")
     args = ap.parse_args()
     quiet_stdout()
 

@@ -30,6 +30,27 @@ def is_stale() -> bool:
     return any(p.stat().st_mtime > built for p in SOURCES + HEADERS)
 
 
+def llvm_bin_dir() -> pathlib.Path:
+    """Where llvm-objcopy and clang-offload-bundler of the ROCm install in use live (next to the hipcc that compiles)."""
+    tools = ("llvm-objcopy", "clang-offload-bundler")
+    roots = [os.environ.get(v) for v in ("ROCM_PATH", "HIP_PATH")]
+    hipcc = shutil.which("hipcc")
+    if hipcc:
+        roots.append(str(pathlib.Path(hipcc).resolve().parent.parent))
+    roots.append("/opt/rocm")
+    tried = []
+    for root in roots:
+        if not root:
+            continue
+        for sub in ("lib/llvm/bin", "llvm/bin", "bin"):
+            d = pathlib.Path(root) / sub
+            tried.append(str(d))
+            if all((d / t).exists() for t in tools):
+                return d
+    raise RuntimeError(f"llvm-objcopy / clang-offload-bundler not found (needed to check the persistent kernels' descriptors); "
+                       f"looked in {', '.join(tried)} - set ROCM_PATH")
+
+
 def check_reentry_contract(obj: pathlib.Path, kernel: str = "patch_kernel2_256p") -> None:
     """The persistent patch kernel jumps back to its own first instruction (RPSF_REENTER, csrc/rpsf_kernels2.hpp) and
     rebuilds the state a fresh workgroup starts with: s[0:1] = kernarg segment pointer, s2 = workgroup id x, v0 = workitem
@@ -38,17 +59,20 @@ def check_reentry_contract(obj: pathlib.Path, kernel: str = "patch_kernel2_256p"
     import struct
     import tempfile
 
-    llvm = pathlib.Path("/opt/rocm/lib/llvm/bin")
+    llvm = llvm_bin_dir()
     with tempfile.TemporaryDirectory() as tmp:
         fat, co = pathlib.Path(tmp) / "fat.bin", pathlib.Path(tmp) / "k.co"
-        subprocess.run([str(llvm / "llvm-objcopy"), "--dump-section", f".hip_fatbin={fat}", str(obj), str(pathlib.Path(tmp) / "x.o")], check=True)
-        subprocess.run([str(llvm / "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={fat}",
-                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
+        for cmd in ([str(llvm / "llvm-objcopy"), "--dump-section", f".hip_fatbin={fat}", str(obj), str(pathlib.Path(tmp) / "x.o")],
+                    [str(llvm / "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={fat}",
+                     "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"]):
+            done = subprocess.run(cmd, capture_output=True, text=True)
+            if done.returncode != 0:
+                raise RuntimeError(f"{kernel}: cannot read the code object back ({' '.join(cmd)}): {done.stderr.strip()}")
         elf = co.read_bytes()
     shoff, = struct.unpack_from("<Q", elf, 0x28)
     shentsize, shnum, _ = struct.unpack_from("<HHH", elf, 0x3A)
     secs = [struct.unpack_from("<IIQQQQIIQQ", elf, shoff + i * shentsize) for i in range(shnum)]
-    kd = None
+    kd, kd_addr, entry_addr = None, None, None
     for name_off, typ, _, addr, off, size, link, _, _, entsize in secs:
         if typ not in (2, 11):  # SHT_SYMTAB, SHT_DYNSYM
             continue
@@ -56,15 +80,29 @@ def check_reentry_contract(obj: pathlib.Path, kernel: str = "patch_kernel2_256p"
         for j in range(size // entsize):
             st_name, _, _, st_shndx, st_value, st_size = struct.unpack_from("<IBBHQQ", elf, off + j * entsize)
             end = elf.index(b"\0", str_off + st_name)
-            if elf[str_off + st_name:end].decode() == kernel + ".kd":
+            sym = elf[str_off + st_name:end].decode()
+            if sym == kernel + ".kd":
                 sec = secs[st_shndx]
                 kd = elf[sec[4] + st_value - sec[3]:sec[4] + st_value - sec[3] + 64]
-    if kd is None or len(kd) != 64:
-        raise RuntimeError(f"{kernel}.kd not found in {obj}")
-    rsrc2, props = struct.unpack_from("<IH", kd, 52)
+                kd_addr = st_value
+            elif sym == kernel:
+                entry_addr = st_value
+    if kd is None or len(kd) != 64 or entry_addr is None:
+        raise RuntimeError(f"{kernel} / {kernel}.kd not found in {obj}")
+    private_size, = struct.unpack_from("<I", kd, 4)
+    entry_off, = struct.unpack_from("<q", kd, 16)
+    rsrc2, props, preload = struct.unpack_from("<IHH", kd, 52)
     got = {"user_sgprs": (rsrc2 >> 1) & 31, "wg_id_x": (rsrc2 >> 7) & 1, "wg_id_y": (rsrc2 >> 8) & 1, "wg_id_z": (rsrc2 >> 9) & 1,
-           "wg_info": (rsrc2 >> 10) & 1, "workitem_id": (rsrc2 >> 11) & 3, "code_properties": props & 0x7F}
-    want = {"user_sgprs": 2, "wg_id_x": 1, "wg_id_y": 0, "wg_id_z": 0, "wg_info": 0, "workitem_id": 0, "code_properties": 0x08}
+           "wg_info": (rsrc2 >> 10) & 1, "workitem_id": (rsrc2 >> 11) & 3, "code_properties": props & 0x7F,
+           # scratch: gfx950 sets flat scratch up by itself (architected), so the hardware enable bit must simply follow "the
+           # kernel has scratch"; a compiler that wanted a scratch offset or buffer in SGPRs would show in user_sgprs /
+           # code_properties above, and one that set the bit without scratch (or the reverse) shows here
+           "private_segment_enable": rsrc2 & 1,
+           "kernarg_preload": preload,
+           # RPSF_REENTER jumps to the kernel's symbol: that must be the address the descriptor starts a fresh workgroup at
+           "entry_is_symbol": int(kd_addr + entry_off == entry_addr)}
+    want = {"user_sgprs": 2, "wg_id_x": 1, "wg_id_y": 0, "wg_id_z": 0, "wg_info": 0, "workitem_id": 0, "code_properties": 0x08,
+            "private_segment_enable": int(private_size > 0), "kernarg_preload": 0, "entry_is_symbol": 1}
     if got != want:
         raise RuntimeError(f"{kernel}: the kernel descriptor no longer matches what RPSF_REENTER restores: {got} != {want}")
 

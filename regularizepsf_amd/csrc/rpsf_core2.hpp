@@ -426,6 +426,52 @@ RPSF_HD void freq_b(int t, const GroupIds<C>& gids, cf* v, cf* k, const cf* __re
   });
 }
 
+// K staged through the exchange buffer (RPSF_KSTAGE2): the buffer is idle between the last forward and the first inverse exchange,
+// so the pair words of chunks 1 and 2 (2 x KCH words per thread: 128 KiB at N = 256) are requested by LDS-DMA as soon as the last
+// forward read is done - no registers needed for data in flight - and chunk 3 takes the registers chunk 0 frees.  One deep request
+// instead of three dependent round trips of one chunk each.  kst: the staged words, [word - KCH][thread] 16-byte units.
+template <class C>
+RPSF_HD void freq_b_staged(int t, const GroupIds<C>& gids, cf* v, cf* k, const cf* __restrict__ g, const cf* __restrict__ tw,
+                           const cf* park, const cf* kst) {
+  static_assert(C::NCHUNK == 4, "chunk 0 and 3 through registers, 1 and 2 through LDS");
+  StaticFor<0, C::NCHUNK>::run([&]<int CI>() RPSF_AI {
+    constexpr int S = CI * C::KCH / C::E, E0 = CI * C::KCH % C::E;
+    if constexpr (E0 == 0 && S > 0) {
+      stage3_rows<C, false, 0, S>(t, gids, v);
+      stage3_rows<C, false, 1, S>(t, gids, v);
+      stage3_cols<C, false, S>(v);
+    }
+    if constexpr (CI == 0 || CI == 3) {
+      pair_words<C, S, E0, C::KCH>(gids, v, k, tw);
+      if constexpr (CI == 0) {
+        load_k_chunk2<C, 3>(t, k, g);
+#if defined(__HIP_DEVICE_COMPILE__)
+        // the staged words were requested before these KCH loads and vector memory returns in order: at most KCH outstanding
+        // operations means the LDS-DMA of this wave has landed (a thread reads only words its own wave requested)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::KCH) : "memory");
+#endif
+      }
+    } else {
+      cf kk[2 * C::KCH];
+      StaticFor<0, C::KCH>::run([&]<int I>() RPSF_AI {
+        const cf2 w2 = *reinterpret_cast<const cf2*>(kst + ((size_t)((CI - 1) * C::KCH + I) * C::T + t) * 2);
+        kk[2 * I] = w2.a, kk[2 * I + 1] = w2.b;
+      });
+      pair_words<C, S, E0, C::KCH>(gids, v, kk, tw);
+    }
+    if constexpr (E0 + C::KCH == C::E) {
+      if constexpr (S == 0) {
+        if (t < 64) self_unpark<C>(t, v, park);
+      }
+      stage3_cols<C, true, S>(v);
+      if constexpr (!(C::SPLIT_ROWS && S == 0)) {
+        stage3_rows<C, true, 0, S>(t, gids, v);
+        stage3_rows<C, true, 1, S>(t, gids, v);
+      }
+    }
+  });
+}
+
 // Value of the packed K stream at (thread t, word w, side b)
 template <class C>
 RPSF_HD cf pack_value2(const cf* __restrict__ kfull, const uint16_t* __restrict__ tab, int t, int w, int b) {

@@ -244,6 +244,16 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   ABL_BAR();
   ABL_LDS(x2_last_read2<C, 1>(gids, v, lds));
   // no barrier: every X2 unit is read by exactly one thread, the same one that rewrites it below
+#if defined(RPSF_KSTAGE2)
+  ABL_BAR();  // ... unless the buffer takes the pair words of chunks 1 and 2 meanwhile (freq_b_staged): every read of the exchange is done
+  {
+    const int wave0 = t & ~63;
+    StaticFor<0, 2 * C::KCH>::run([&]<int I>() RPSF_AI {
+      __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(g + ((size_t)(C::KCH + I) * C::T + t) * 2),
+                                       (__attribute__((address_space(3))) float*)(lds + ((size_t)I * C::T + wave0) * 2), 16, 0, /*nt*/ 2);
+    });
+  }
+#endif
   STAMP(4);
   // ---- frequency step ----
   if constexpr (C::SPLIT_ROWS) ABL_VALU(stage3_rows<C, false, 1, 0>(t, gids, v));
@@ -263,7 +273,12 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   });
   v[0] = v[0] + k[0] + k[15];
 #else
+#if defined(RPSF_KSTAGE2)
+  freq_b_staged<C>(t, gids, v, k, g, tw, park, lds);
+  ABL_BAR();  // every staged word has been used: the inverse exchange may overwrite the buffer
+#else
   freq_b<C>(t, gids, v, k, g, tw, park);
+#endif
 #endif
   if constexpr (C::SPLIT_ROWS) ABL_VALU(stage3_rows<C, true, 0, 0>(t, gids, v));
   STAMP(6);

@@ -87,12 +87,34 @@ def make_band_plans(coordinates, patch_size: int, height: int, world: int, pad_m
         raise ValueError(msg)
     counts = np.array([(coords[:, 0] == r).sum() for r in lattice_rows])
     cum = np.concatenate([[0], np.cumsum(counts)])
-    cuts = [0]
-    for g in range(1, world):  # cut where the cumulative patch count is closest to g/world of the total
-        target = cum[-1] * g / world
-        j = int(np.argmin(np.abs(cum - target)))
-        cuts.append(min(max(j, cuts[-1] + 1), len(lattice_rows) - (world - g)))
-    cuts.append(len(lattice_rows))
+    nrows = len(lattice_rows)
+    if seam == "recompute" and world > 1:
+        # A band also runs the patches above it that reach into its rows, so what has to be balanced is own + recomputed patches:
+        # the cuts that minimise the largest band (dynamic programme over the lattice rows; 65 rows x 8 bands is nothing).  On the
+        # 8192-wide, 256-px lattice this gives 9 | 8 + 1 | ... | 8 + 1 rows = 585 patches on every rank instead of 520 ... 650.
+        def cost(a: int, b_: int) -> int:  # rows [a, b_) own; rows above whose footprint passes the band's first own row
+            lo = max(int(lattice_rows[a]), 0) if a > 0 else 0
+            above = int(sum(counts[j] for j in range(a) if lattice_rows[j] + n > lo)) if a > 0 else 0
+            return int(cum[b_] - cum[a]) + above
+
+        best = {(0, 0): (0, None)}  # (bands used, rows used) -> (largest band so far, previous cut)
+        for g in range(1, world + 1):
+            for b_ in range(g, nrows - (world - g) + 1):
+                cands = [(max(best[(g - 1, a)][0], cost(a, b_)), a) for a in range(g - 1, b_) if (g - 1, a) in best]
+                if cands:
+                    best[(g, b_)] = min(cands)
+        cuts, b_ = [nrows], nrows
+        for g in range(world, 0, -1):
+            b_ = best[(g, b_)][1]
+            cuts.append(b_)
+        cuts = cuts[::-1]
+    else:
+        cuts = [0]
+        for g in range(1, world):  # cut where the cumulative patch count is closest to g/world of the total
+            target = cum[-1] * g / world
+            j = int(np.argmin(np.abs(cum - target)))
+            cuts.append(min(max(j, cuts[-1] + 1), nrows - (world - g)))
+        cuts.append(nrows)
 
     first = [int(lattice_rows[cuts[g]]) for g in range(world)]
     last = [int(lattice_rows[cuts[g + 1] - 1]) for g in range(world)]
@@ -204,13 +226,16 @@ class ShardedApply:
                                             self.d_recv.ptr, b.recv_rows * w, self.d_out.ptr, self.plan.stream)
             return
         xstream = self.seam_plan.stream if self.seam_plan is not None else (self.comm.stream if self.comm is not None else None)
-        if xstream is not None:
-            # the previous step's add (main stream) reads d_recv, and its main plan may still run: the next seam apply and
-            # the next receive must not start before both are done (they would overwrite d_recv under the add, and two
-            # persistent launches of consecutive steps would compete for the CUs)
-            _native.stream_wait(xstream, self.plan.stream, self.device)
-        if self.seam_plan is not None:  # first in line: its workgroups are dispatched ahead of the main plan's
+        if self.seam_plan is not None:
+            # First in line, and not ordered against the main stream: the spill buffer is only ever touched on this stream (the
+            # previous step's send has read it by the time this apply runs), so the seam patches of step k + 1 may start while the
+            # main plan of step k still runs - they take the CUs it leaves free.  Two persistent launches side by side are safe:
+            # every slot of both is drawn from a queue by whichever workgroups are resident (rpsf.hip, launch_patches).
             self.seam_plan.apply_device(self.d_img.ptr, self.d_spill.ptr, self.seam_geometry)
+        if xstream is not None and self.comm is not None and b.recv_rows > 0:
+            # ... but the receive must not land before the previous step's add has read d_recv: the exchange waits for
+            # everything enqueued on the main stream so far (its tail is that add; this step's main apply comes after this line)
+            _native.stream_wait(xstream, self.plan.stream, self.device)
         self.plan.apply_device(self.d_img.ptr, self.d_out.ptr, self.geometry)
         if self.comm is None:
             return

@@ -13,6 +13,7 @@ import math
 import numbers
 import pathlib
 import threading
+import weakref
 
 import numpy as np
 
@@ -89,7 +90,15 @@ class ArrayPSFTransform:
             raise InvalidCoordinateError(msg)
         n_patch = source.sample_shape[0] if len(source) else 0
         dev_s, dev_t = getattr(source, "_fft_dev", None), getattr(target, "_fft_dev", None)
-        if (dev_s is not None and dev_t is not None and dev_s[1] == dev_t[1] == device and len(source) == len(target) > 0
+
+        def pristine(psf) -> bool:
+            # the device copy of the spectra is what the reference would use only while nobody has fetched the cube (a fetched
+            # array can be edited in place: transform.py:78-82 reads fft_evaluations as they are at the time of the call)
+            cube = getattr(psf, "_fft_cube", None)
+            return cube is not None and getattr(cube, "_loader", None) is not None and cube._edits == 0
+
+        if (dev_s is not None and dev_t is not None and pristine(source) and pristine(target)
+                and dev_s[1] == dev_t[1] == device and len(source) == len(target) > 0
                 and source.sample_shape == target.sample_shape and n_patch in _native.SUPPORTED_PATCH_SIZES
                 and all(isinstance(v, numbers.Integral) for c in source.coordinates for v in c)):
             # Both spectra were computed on this GPU (ArrayPSF(device=...)) and are still there: K2 -> pack -> plan without
@@ -110,6 +119,15 @@ class ArrayPSFTransform:
             cube = IndexedCube._deferred(source.coordinates, shape, fetch)
             out = cls(cube, device=device)
             out._plan, out._plan_stamp = plan, _kernel_stamp(cube)
+            ref = weakref.ref(out)
+
+            def fetched(c, stamp=out._plan_stamp):
+                # looking at K must not cost a re-upload: the values that just arrived ARE the device copy
+                t = ref()
+                if t is not None and t._plan_stamp == stamp:
+                    t._plan_stamp = _kernel_stamp(c)
+
+            cube._load_hook = fetched
             return out
         s_fft, t_fft = source.fft_evaluations, target.fft_evaluations
         resident = (np.result_type(s_fft.dtype, t_fft.dtype) == np.complex64 and s_fft.ndim == 3 and len(source) > 0

@@ -62,6 +62,7 @@ class IndexedCube:
         self._coordinates = coordinates
         self._values_array = None
         self._loader = loader
+        self._load_hook = None  # called once with the cube right after the values have arrived, before anybody can edit them
         self._shape = tuple(shape)
         self._where = {tuple(c): layer for layer, c in enumerate(coordinates)}
         self._edits = 0
@@ -72,6 +73,9 @@ class IndexedCube:
         if self._values_array is None:
             self._values_array = self._loader()
             self._loader = None
+            hook, self._load_hook = getattr(self, "_load_hook", None), None
+            if hook is not None:
+                hook(self)
         return self._values_array
 
     @property

@@ -1,44 +1,89 @@
-"""Development aid: device time of every row band of BASELINE config 4 (8192^2 / 256) at world 1/2/4/8, one band at a time on
-one GPU (no seam transport: the local apply only), and of 3968^2 vs 4096^2 frames (whole rounds vs a partial last round).
-    python scripts/band_times.py [reserved CUs]   (as ShardedApply reserves them for the seam exchange when it has a communicator)"""
-import json, pathlib, sys
+"""Strong-scaling projection of BASELINE config 4 (one 8192^2 frame, 256-px patches) from ONE GPU: every row band of a world of
+1 / 2 / 4 / 8 ranks runs the product's own sharded step - ShardedApply.step(): the seam plan (the band's last lattice row, on
+its stream) beside the main plan (8 CUs left free, as with a communicator attached), the 128 spill rows moved on the seam
+stream, the receiver's stream waiting for them, K4 adding them - one band at a time, back to back, after a 100 ms prewarm.
+The link is replaced by a device-to-device hipMemcpyAsync of the same 4 MiB on the seam stream (`LocalLink`; what arrives is not
+what a neighbour would send - this script times, it does not verify).  Time per step = wall clock over the steps between two device
+synchronisations.  speedup = (world 1, same process, same clocks) / (slowest band).
+
+    python scripts/band_times.py [--steps 60] [--no-overlap] [--seam recompute]
+"""
+import argparse
+import ctypes
+import json
+import pathlib
+import sys
+import time
+
 import numpy as np
+
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
-from regularizepsf_amd import _native, calculate_covering
-from regularizepsf_amd.sharding import ShardedApply
+from regularizepsf_amd import _native, calculate_covering  # noqa: E402
+from regularizepsf_amd.sharding import ShardedApply  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--steps", type=int, default=60)
+ap.add_argument("--no-overlap", action="store_true")
+ap.add_argument("--worlds", default="1,2,4,8")
+ap.add_argument("--seam", choices=["exchange", "recompute"], default="exchange")
+args = ap.parse_args()
+
+hip = ctypes.CDLL("libamdhip64.so")
+hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+hip.hipMemcpyAsync.restype = ctypes.c_int
+
+
+class LocalLink:
+    """Timing stand-in for _native.Comm: the seam rows are copied device-to-device on the stream the exchange would use."""
+
+    def __init__(self, floats):
+        self.scratch = _native.DeviceBuffer(max(1, floats) * 4)
+        self._plan = _native.Plan(16, [(0, 0)])  # owns a stream for bands that have no seam plan
+        self.stream = self._plan.stream
+
+    def seam_exchange(self, send_ptr, send_count, recv_ptr, recv_count, stream=None):
+        st = stream if stream is not None else self.stream
+        if send_count:
+            assert hip.hipMemcpyAsync(self.scratch.ptr, send_ptr, send_count * 4, 3, st) == 0
+        if recv_count:
+            assert hip.hipMemcpyAsync(recv_ptr, self.scratch.ptr, recv_count * 4, 3, st) == 0
+
+    def seam_exchange_add(self, send_ptr, send_count, recv_ptr, recv_count, accum_ptr, stream=None):
+        self.seam_exchange(send_ptr, send_count, recv_ptr, recv_count, stream)
+        if recv_count:
+            _native.add_rows(accum_ptr, recv_ptr, recv_count, 0, stream)
+
 
 rng = np.random.default_rng(0)
-n = 256
-for size in (3968, 4096):
-    coords = [tuple(int(v) for v in t) for t in calculate_covering((size, size), n)]
-    plan = _native.Plan(n, coords)
-    k = (rng.standard_normal((len(coords), n, n), dtype=np.float32) + 1j * rng.standard_normal((len(coords), n, n), dtype=np.float32)).astype(np.complex64)
-    plan.set_transfer(k)
-    img = rng.standard_normal((size, size), dtype=np.float32)
-    d_img = _native.DeviceBuffer(img.nbytes).upload(img); d_out = _native.DeviceBuffer(img.nbytes)
-    geom = _native.Geometry.whole(size, size, 1)
-    plan.apply_device_timed(d_img.ptr, d_out.ptr, geom, 5)
-    tot, ker = plan.apply_device_timed(d_img.ptr, d_out.ptr, geom, 40)
-    print(json.dumps({"frame": size, "patches": len(coords), "apply_us": round(float(np.median(ker)) * 1e3, 1)}))
-    plan.close(); d_img.free(); d_out.free()
-
-h = w = 8192
+n, h, w = 256, 8192, 8192
 coords = [tuple(int(v) for v in t) for t in calculate_covering((h, w), n)]
 kk = (rng.standard_normal((585, n, n), dtype=np.float32) + 1j * rng.standard_normal((585, n, n), dtype=np.float32)).astype(np.complex64)
 image = rng.standard_normal((h, w), dtype=np.float32)
+link = LocalLink(128 * w)
 base = None
-for world in (1, 2, 4, 8):
+for world in [int(v) for v in args.worlds.split(",")]:
     times = []
     for rank in range(world):
-        sh = ShardedApply(coords, lambda idx: np.resize(kk, (len(idx), n, n)), n, h, w, rank, world, 0, None)
-        if len(sys.argv) > 1:
-            sh.plan.set_reserved_cus(int(sys.argv[1]))
+        sh = ShardedApply(coords, lambda idx: np.resize(kk, (len(idx), n, n)), n, h, w, rank, world, 0, link if world > 1 else None,
+                          seam=args.seam, overlap=not args.no_overlap)
         b = sh.band
         sh.upload_rows(image[b.image_row0:b.image_row0 + b.image_rows])
-        sh.plan.apply_device_timed(sh.d_img.ptr, sh.d_out.ptr, sh.geometry, 3)
-        tot, ker = sh.plan.apply_device_timed(sh.d_img.ptr, sh.d_out.ptr, sh.geometry, 20)
-        times.append((len(b.patch_index), round(float(np.median(ker)) * 1e3, 1)))
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.1:  # prewarm: steady clocks
+            for _ in range(8):
+                sh.step()
+            sh.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            sh.step()
+        sh.synchronize()
+        us = (time.perf_counter() - t0) / args.steps * 1e6
+        times.append((len(b.patch_index), sh.seam_plan.n_patches if sh.seam_plan is not None else 0, round(us, 1)))
+        if sh.seam_plan is not None:
+            sh.seam_plan.close()
+            sh.d_spill.free()
         sh.plan.close(); sh.d_img.free(); sh.d_out.free(); sh.d_recv.free()
-    slowest = max(t for _, t in times)
+    slowest = max(t for _, _, t in times)
     base = base or slowest
-    print(json.dumps({"world": world, "bands (patches, us)": times, "slowest_us": slowest, "speedup_vs_1": round(base / slowest, 2)}))
+    print(json.dumps({"world": world, "seam": args.seam, "overlap": not args.no_overlap and args.seam == "exchange", "bands (patches, seam patches, us per step)": times,
+                      "slowest_us": slowest, "speedup_vs_world_1": round(base / slowest, 2)}), flush=True)

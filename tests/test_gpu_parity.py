@@ -935,8 +935,16 @@ def test_device_resident_psf_to_transform_chain():
     ref_s = orc.psf_fft(src.astype(np.float32))
     assert np.abs(got_s - ref_s).max() <= 1e-5 * np.abs(ref_s).max()
     for alpha, eps, tr, out in sweep:
+        plan_before = tr._plan
         k = tr._transfer_kernel.values  # fetched now: the same K the host route builds from the same spectra
         assert k.dtype == np.complex64 and np.array_equal(k, _native.build_transfer(got_s, got_t, alpha, eps), equal_nan=True)
         check(out, orc.apply_transfer(image, coords, k))
+        assert np.array_equal(tr.apply(image), out) and tr._plan is plan_before  # looking at K did not cost a re-upload
         tr._transfer_kernel[coords[0]] = np.zeros((n, n), np.complex64)  # edits after the fetch are still noticed
         assert not np.array_equal(tr.apply(image), out)
+    # The spectra have been fetched by now, so a caller may have edited them in place: construct reads them as they are
+    # (transform.py:78-82) instead of the copy it left on the GPU.
+    got_s *= 2
+    edited = rp.ArrayPSFTransform.construct(s, t, 3.0, 0.1)
+    assert np.array_equal(edited._transfer_kernel.values, _native.build_transfer(got_s, got_t, 3.0, 0.1), equal_nan=True)
+    assert not np.array_equal(edited._transfer_kernel.values, sweep[0][2]._transfer_kernel.values)

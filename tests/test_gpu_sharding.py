@@ -74,7 +74,7 @@ def _worker(rank, world, port, transport, overlap, queue):
 
 
 def _run(transport, overlap):
-    import torch.multiprocessing as mp
+    import multiprocessing as mp  # (not torch.multiprocessing: torch brings its own HIP runtime, and this process may have loaded librpsf_hip.so)
 
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
