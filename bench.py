@@ -369,7 +369,7 @@ def main() -> None:
     h1, w, n, seed = CONFIGS[args.config]
     strong = args.config == 4 or not args.weak  # one frame cut into `world` bands; --weak: the image grows with the ranks
     height = h1 if strong else h1 * world
-    device = local_rank % max(1, _native.device_count()) if args.comm == "gloo" else local_rank
+    device = local_rank % max(1, _native.device_count())  # (one process per GPU; on a box with fewer GPUs than ranks - debugging - ranks share devices)
     pad = "symmetric"
 
     # ---------------- inputs: synthetic, same recipe on every rank, each rank builds only its band ----------
@@ -427,12 +427,27 @@ def main() -> None:
                 box = [None]
                 print(f"[bench] RCCL unavailable on rank 0 ({e})", file=sys.stderr, flush=True)
             dist.broadcast_object_list(box, src=0)
+            no_exchange = args.seam == "recompute" or args.config == 5  # no data-path collective: gloo can carry the barrier
+            err = None
             if box[0] is not None:
-                comm = _native.Comm(device, rank, world, bytes(box[0]))
-            elif args.seam == "recompute" or args.config == 5:  # no data-path exchange: gloo can carry the barrier
-                comm = GlooSeam(rank, world, device)
+                try:
+                    comm = _native.Comm(device, rank, world, bytes(box[0]))
+                except _native.NativeError as e:
+                    err = str(e)
             else:
-                raise SystemExit("--seam exchange needs RCCL")
+                err = "no unique id"
+            # every rank must end up on the same transport: agree on whether RCCL came up everywhere
+            flags = [None] * world
+            dist.all_gather_object(flags, err)
+            bad = [f"rank {r}: {f}" for r, f in enumerate(flags) if f is not None]
+            if bad:
+                if comm is not None:
+                    comm.close()
+                if not no_exchange:
+                    raise SystemExit("--seam exchange needs RCCL on every rank (" + "; ".join(bad) + ")")
+                if rank == 0:
+                    print(f"[bench] RCCL did not come up ({'; '.join(bad)}): barrier and max-reduction over gloo", file=sys.stderr, flush=True)
+                comm = GlooSeam(rank, world, device)
         else:
             comm = GlooSeam(rank, world, device)
     if args.config == 5:
@@ -562,6 +577,7 @@ def main() -> None:
             "image": [height, w], "patch": n, "patches": len(coords), "device": name, "compute_units": cus,
             "resident": "image, output and packed transfer kernel in HBM before the timed region",
             "in_flight": 1 + len(pipeline), "frames_in_rotation": 1 + len(rotation),
+            "sync": "none (one rank)" if comm is None else ("gloo" if isinstance(comm, GlooSeam) else "rccl"),
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -111,6 +111,7 @@ struct rpsf_plan {
   uint32_t sum_queue_base = 0;
   bool no_fuse = false;
   int sum_first = -1;                // RPSF_SUM_FIRST override of sum_first_for(), -1 = none
+  int head_patches = 0;              // (measured neutral, profiles/r03i: off) persistent launches: patches a head summing workgroup computes before it sums (RPSF_HEAD_PATCHES)
   bool fuse_pays = false;            // the second-generation plans (N = 128, 256)
   // Persistent patch workgroups (patch_kernel2_256p; fused launches of the 256-pixel plan): per-XCD slot queues, never reset
   bool persist = false;
@@ -568,6 +569,7 @@ extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int
     // (measured, profiles/r02u, r02v: 32 of them are worth -1 % at 4096^2 and -2.5 % at 8192^2; 48 cost more patch time than they hide)
     p->sum_first = -1;  // decided per launch (sum_first_for) unless the environment pins it
     if (const char* e = std::getenv("RPSF_SUM_FIRST")) p->sum_first = std::max(0, std::atoi(e)) / 8 * 8;
+    if (const char* e = std::getenv("RPSF_HEAD_PATCHES")) p->head_patches = std::atoi(e) > 0 ? 1 : 0;
     if (const char* e = std::getenv("RPSF_STAGGER_US")) p->stagger_us = std::max(0, std::atoi(e));  // development sweeps
     if (const char* e = std::getenv("RPSF_RESERVED_CUS")) p->reserved_cus = std::min(128, std::max(0, std::atoi(e)));
     // (until the plane stores were kept in the Infinity Cache the fused sum cost the 128-pixel plan 3 %; now it gains 3 ... 6 %)
@@ -898,6 +900,9 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
           const int rows = std::min(pp.chunk * b.frames, std::max(1, (p->round_capacity - pp.sum_first - p->reserved_cus) / 8));
           if (p->persist && rows > 0) {
             pp.persist = rows, pp.xq = p->d_xq;
+            // a head summing workgroup would idle through the first patch period (no tile is complete before that): it computes one patch
+            // of its XCD's chunk first (RPSF_HEAD_PATCHES=0: off)
+            pp.head_patches = p->head_patches;
             // persistent workgroups keep the phase they start with: holding the resident ones back by up to 10 us spreads the
             // store bursts of the chip over the patch period (profiles/r02ai, r02ak: -2..3 % from four rounds of patches on; with the
             // plane stores kept in the Infinity Cache, r02av: 0.210 / 0.208 / 0.193 / 0.190 / 0.189 / 0.191 / 0.195 ms at 0 / 5 / 8 / 10 / 12 / 15 / 20 us)
@@ -907,7 +912,9 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
             for (int x = 0; x < 8; ++x) {
               pp.xq_base[x] = p->xq_base[x];
               // draws of this launch: one per slot and frame, plus the one past the end that tells each of the chunk's workgroups to stop
-              p->xq_base[x] += (uint32_t)(std::min(pp.chunk, std::max(0, p->n_patches - x * pp.chunk)) * b.frames + rows);
+              // (the first sum_first / 8 positions of a chunk go to the head summing workgroups without a draw when those compute a patch first)
+              const int slots_x = std::min(pp.chunk, std::max(0, p->n_patches - x * pp.chunk)) * b.frames;
+              p->xq_base[x] += (uint32_t)(std::max(0, slots_x - (pp.head_patches ? pp.sum_first / 8 : 0)) + rows);
             }
             const int wgs = pp.sum_first + 8 * rows;
 #if defined(RPSF_DEV_CARRY)

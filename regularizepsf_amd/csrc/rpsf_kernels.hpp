@@ -269,6 +269,7 @@ struct PatchParams {
   int persist;
   uint32_t* xq;
   uint32_t xq_base[8];
+  int head_patches;  // persistent launches: the summing workgroups at the head of the grid compute this many (0 or 1) patches before they turn to summing
   float* carry;  // development (RPSF_DEV_CARRY): one half patch of private scratch per persistent workgroup
 };
 

@@ -88,7 +88,11 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   // (persistent form: bit 30 of the block index says that this is a re-entry - the tables are in LDS already and the park
   // words hold the tiles of the previous patch, still to be counted)
   const bool again = PERSIST && ((blockIdx.x >> 30) & 1u);
-  const int pb = (int)(blockIdx.x & 0x3fffffffu) - p.sum_first;  // workgroup-uniform
+  // (persistent form: a summing workgroup at the head of the grid has nothing to sum while the first patches are still being
+  // computed - no tile is complete before a full patch period - so it computes ONE patch of its XCD's chunk first)
+  const int blk = (int)(blockIdx.x & 0x3fffffffu);
+  const bool head_patch = PERSIST && !again && blk < p.sum_first && p.head_patches > 0;  // workgroup-uniform
+  const int pb = head_patch ? (blk & 7) : blk - p.sum_first;                             // workgroup-uniform
   bool patchy = pb >= 0 && pb < p.patch_blocks;
   int frame = 0, xrow = 0, seq = 0;
   if (patchy) {
@@ -96,12 +100,17 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
     if constexpr (PERSIST) {
       // Every slot comes from the XCD chunk's queue, the first one included (position 0 = slot 0): no slot is tied to a workgroup
       // that may not be resident yet, so whichever workgroups of a chunk ARE resident drain it (forward progress: rpsf.hip, launch_patches).
-      if (!again) {
+      // (the head summing workgroups - the first of the grid to be dispatched - take the first positions of their chunks without a draw,
+      // so that the number of draws of a launch, which the never-reset queue counters are accounted by, does not depend on a race)
+      if (head_patch) {
+        xrow = blk >> 3;
+      } else if (!again) {
         unsigned* const word = reinterpret_cast<unsigned*>(reinterpret_cast<cf*>(smem + Launch2<C>::TABLE_FLOATS) + C::BUF_UNITS);
         if (t == 0) *word = __hip_atomic_fetch_add(p.xq + (pb & 7) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.xq_base[pb & 7];
         lds_barrier();
         xrow = (int)__builtin_amdgcn_readfirstlane(*word);
         if (xrow < 0 || xrow > 0x0fffffff) xrow = 0x0fffffff;  // (queue positions stay far below; keeps the frame arithmetic in range)
+        xrow += p.head_patches ? p.sum_first >> 3 : 0;
       }
     }
     if (p.n_frames > 1) {
@@ -151,7 +160,7 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   // Start-up stagger.  The workgroups of one round move in lock step otherwise - all CUs stream K at one moment, store at
   // another, and the memory system alternates between idle and saturated.  The first resident workgroup of each CU is
   // held back by a different fraction of stagger_ticks (later workgroups inherit the offset of the one they replace).
-  if (p.stagger_ticks > 0 && pb < p.stagger_blocks && !again) {
+  if (p.stagger_ticks > 0 && pb < p.stagger_blocks && !again && !head_patch) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     // evenly spaced delays in bit-reversed order of the chunk row (profiles/r02av: -1 % against hashed delays at 12 us)
 #if defined(RPSF_DEV_STAGGER_LINEAR)  // development: delays in chunk-row order (neighbours in the queue start next to each other in time)
@@ -203,6 +212,10 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   if (PERSIST && !again && t == 0) ot[Launch2<C>::OT_WORDS - 1] = blockIdx.x & 0x3fffffffu;
 #endif
   window_patch2<C>(t, v, win);
+#if defined(RPSF_DEV_SKEW)  // development: the second wave of every SIMD (waves w and w + WAVES/2 share one) starts the barrier-free stage-1 / X1 region late,
+                            // so that its butterflies fall under its partner's LDS bursts instead of competing with its butterflies
+  if (C::WAVES >= 2 && t >= C::T / 2) __builtin_amdgcn_s_sleep(RPSF_DEV_SKEW);
+#endif
   STAMP(1);
   // ---- forward: the halves leapfrog through stage 1, X1 (wave-local) and stage 2 ----
   ABL_VALU(stage1h<C, 0, false>(t, v, tw));
@@ -293,6 +306,9 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   ABL_BAR();
   ABL_LDS(x2_mid_read2<C, 1>(t, v, lds));
   ABL_BAR();  // X1 regions alias the X2 image
+#if defined(RPSF_DEV_SKEW)
+  if (C::WAVES >= 2 && t >= C::T / 2) __builtin_amdgcn_s_sleep(RPSF_DEV_SKEW);
+#endif
   STAMP(7);
   ABL_LDS(x1_write2<C, 0>(t, v, lds));
   ABL_VALU(stage2h<C, 1, true>(t, v, tw));
@@ -352,8 +368,9 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
         const uint4 q4 = p.quads[p.seq_base + seq];
         my_tile = (unsigned)frame * p.n_tiles + quad_tile(t == 0 ? q4.x : t == 1 ? q4.y : t == 2 ? q4.z : q4.w);  // (this frame's counters)
       }
-      if (t == 0)
-        drawn = __hip_atomic_fetch_add(p.xq + (pb & 7) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.xq_base[pb & 7];
+      if (t == 0 && !head_patch)
+        drawn = __hip_atomic_fetch_add(p.xq + (pb & 7) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.xq_base[pb & 7] +
+                (p.head_patches ? (unsigned)(p.sum_first >> 3) : 0u);
     }
 #if defined(RPSF_DEV_CARRY)
     // timing experiment (results are wrong): the right half of every patch goes to the workgroup's private carry buffer, what the
@@ -400,7 +417,9 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
       const int left = p.n_patches - (pb & 7) * p.chunk;  // slots of this XCD's chunk that hold a patch (x frames: queue positions)
       // ... or, once the chunk is exhausted, a block index behind the patches: the workgroup sums tiles with the others
       const bool more = (int)nx < (left < p.chunk ? left : p.chunk) * (p.n_frames > 1 ? p.n_frames : 1);
-      reenter(0x40000000u | ((unsigned)p.sum_first + (more ? ((nx << 3) | (unsigned)(pb & 7)) : (unsigned)p.patch_blocks)), (unsigned)t);
+      // (a head summing workgroup has had its patch: it re-enters under its own block index and sums from now on)
+      reenter(0x40000000u | (head_patch ? (unsigned)blk : (unsigned)p.sum_first + (more ? ((nx << 3) | (unsigned)(pb & 7)) : (unsigned)p.patch_blocks)),
+              (unsigned)t);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
