@@ -10,7 +10,13 @@
  *   - host pointers are borrowed for the duration of the call only; a plan owns all of its device
  *     memory; nothing returned by the library is freed by the caller except through *_destroy/_free;
  *   - a plan is bound to one device and is not re-entrant; distinct plans may be used from
- *     distinct threads.
+ *     distinct threads;
+ *   - applies of distinct plans on distinct streams may run on the device at the same time.  The launches of the
+ *     128- and 256-pixel plans are persistent (workgroups that stay resident and draw patches from queues) and contain
+ *     workgroups that wait for others of the same launch; they need no particular number of resident workgroups to
+ *     finish - every patch is drawn from a queue by whichever workgroups are resident - as long as the few (<= 128)
+ *     summing workgroups at the head of all concurrent launches together leave one compute unit free
+ *     (csrc/rpsf.hip, launch_patches, "FORWARD PROGRESS").
  */
 #ifndef RPSF_H
 #define RPSF_H

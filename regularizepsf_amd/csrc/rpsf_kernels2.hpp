@@ -87,7 +87,14 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   // round of patches leaves idle.  All of them draw tiles from one queue.
   // (persistent form: bit 30 of the block index says that this is a re-entry - the tables are in LDS already and the park
   // words hold the tiles of the previous patch, still to be counted)
+#if defined(RPSF_STAMPS)  // diagnostic builds: when did this pass reach the kernel's first instructions (stamp 14, through an LDS word)
+  if (threadIdx.x == 0) *reinterpret_cast<unsigned long long*>(reinterpret_cast<cf*>(smem + Launch2<C>::TABLE_FLOATS) + C::BUF_UNITS + 4) = __builtin_amdgcn_s_memrealtime();
+#endif
   const bool again = PERSIST && ((blockIdx.x >> 30) & 1u);
+#if defined(RPSF_STAMPS)  // ... and which workgroup this is (its block index at dispatch, kept in LDS across re-entries: stamp 15)
+  // (an unused word of the bin-pair table: bit 31 clear, so the walk of the self-paired bins ignores it; written again behind the table staging below)
+  if (threadIdx.x == 0 && !again) reinterpret_cast<uint32_t*>(smem + 3 * C::N)[Launch2<C>::OT_WORDS - 1] = blockIdx.x;
+#endif
   // (persistent form: a summing workgroup at the head of the grid has nothing to sum while the first patches are still being
   // computed - no tile is complete before a full patch period - so it computes ONE patch of its XCD's chunk first)
   const int blk = (int)(blockIdx.x & 0x3fffffffu);
@@ -171,6 +178,10 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
     while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
   }
   STAMP(0);
+#if defined(RPSF_STAMPS)
+  if (threadIdx.x == 0) p.stamps[(size_t)patch * 16 + 14] = *reinterpret_cast<const unsigned long long*>(reinterpret_cast<cf*>(smem + Launch2<C>::TABLE_FLOATS) + C::BUF_UNITS + 4);
+  if (threadIdx.x == 0) p.stamps[(size_t)patch * 16 + 15] = 1 + (again ? reinterpret_cast<const uint32_t*>(smem + 3 * C::N)[Launch2<C>::OT_WORDS - 1] : blockIdx.x);
+#endif
   const int pr = dsc.x + p.origin_row, pc = dsc.y + p.origin_col;
   const cf* g = p.g + (size_t)patch * C::G_PER_PATCH;
   cf* tw = reinterpret_cast<cf*>(smem);
@@ -208,7 +219,7 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
     if (t < Launch2<C>::OT_WORDS) ot[t] = ot0;
   }
   lds_barrier();  // tables staged; the maps (which share LDS with the exchange buffer) are no longer needed
-#if defined(RPSF_DEV_CARRY)  // timing experiment: the workgroup's private carry slot, kept in an unused word of the bin-pair table
+#if defined(RPSF_DEV_CARRY) || defined(RPSF_STAMPS)  // the workgroup's block index at dispatch, kept in an unused word of the bin-pair table
   if (PERSIST && !again && t == 0) ot[Launch2<C>::OT_WORDS - 1] = blockIdx.x & 0x3fffffffu;
 #endif
   window_patch2<C>(t, v, win);

@@ -35,3 +35,18 @@ cap = 256 if len(st) > 256 else len(st)
 gaps = start[cap:] - end[: len(start) - cap]
 print(f"gap between an end stamp and the start stamp that takes its place: mean {gaps.mean():.2f}  p10 {np.percentile(gaps,10):.2f}  p90 {np.percentile(gaps,90):.2f} us")
 print("last end", end[-1].round(1), "us")
+if (st[:, 14] > 0).all():  # entry stamp (kernel's first instructions of the pass) -> stamp 0 (slot descriptor known, stagger done)
+    e0 = (st[:, 0] - st[:, 14]) * 0.01
+    print(f"entry -> stamp 0 (kernel arguments, queue draw of a first pass, slot descriptor): mean {e0.mean():.2f}  p10 {np.percentile(e0,10):.2f}  p50 {np.percentile(e0,50):.2f}  p90 {np.percentile(e0,90):.2f} us")
+    # exact chains: stamp 15 = the workgroup (block index at dispatch); consecutive patches of one workgroup
+    gaps2, e2e = [], []
+    for wg in np.unique(st[:, 15]):
+        rows = st[st[:, 15] == wg]
+        rows = rows[np.argsort(rows[:, 0])]
+        for a_, b_ in zip(rows[:-1], rows[1:]):
+            gaps2.append((b_[14] - a_[last]) * 0.01)
+            e2e.append((b_[0] - a_[0]) * 0.01)
+    gaps2, e2e = np.array(gaps2), np.array(e2e)
+    print(f"workgroups {len(np.unique(st[:, 15]))}; end stamp -> entry stamp of the same workgroup's next pass (barrier, jump, first instruction fetch): "
+          f"mean {gaps2.mean():.2f}  p10 {np.percentile(gaps2,10):.2f}  p50 {np.percentile(gaps2,50):.2f}  p90 {np.percentile(gaps2,90):.2f} us")
+    print(f"period of a workgroup (start stamp to start stamp): mean {e2e.mean():.2f}  p10 {np.percentile(e2e,10):.2f}  p90 {np.percentile(e2e,90):.2f} us")
