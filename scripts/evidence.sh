@@ -9,10 +9,10 @@ python bench.py --config 4 --steps 20 --warmup 3 > gpurun_out/$R/bench_config4_8
 python bench.py --config 5 --steps 20 --warmup 3 > gpurun_out/$R/bench_config5_batch.json 2>/dev/null
 for f in config2 config4_8192 config5_batch; do cut -c1-200 gpurun_out/$R/bench_$f.json; done
 REPO=$(pwd)
-(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/$R/stats -- python3 $REPO/bench.py --steps 100 --warmup 5 --no-cpu > $REPO/gpurun_out/$R/stats.log 2>&1)
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/$R/stats -- python3 $REPO/bench.py --steps 100 --warmup 5 --no-cpu --new-frames 0 > $REPO/gpurun_out/$R/stats.log 2>&1)
 find gpurun_out/$R/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/$R/bench_kernel_stats.csv
 head -4 gpurun_out/$R/bench_kernel_stats.csv
-bash scripts/pmc_passes.sh gpurun_out/$R/pmc -- python3 $REPO/bench.py --steps 10 --warmup 2 --no-cpu > gpurun_out/$R/pmc.log 2>&1
+bash scripts/pmc_passes.sh gpurun_out/$R/pmc -- python3 $REPO/bench.py --steps 10 --warmup 2 --no-cpu --new-frames 0 > gpurun_out/$R/pmc.log 2>&1
 cp gpurun_out/$R/pmc/summary.txt gpurun_out/$R/bench_pmc_summary.txt; head -30 gpurun_out/$R/bench_pmc_summary.txt
 python3 scripts/traffic.py gpurun_out/$R/bench_pmc_summary.txt "profiles/${R}_bench_pmc_summary.txt" > gpurun_out/$R/traffic.json; cat gpurun_out/$R/traffic.json
 rm -rf gpurun_out/$R/stats gpurun_out/$R/pmc/pass*

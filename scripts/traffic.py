@@ -21,7 +21,7 @@ for line in text.splitlines():
         m = re.match(r"\s+(\S+)\s+n=\s*(\d+)\s+mean=(\S+)", line)
         if m and cur:
             kernels[cur][m.group(1)] = float(m.group(3))
-out = {"source": f"{sys.argv[2]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, `python3 bench.py --steps 10 --warmup 2 --no-cpu` via "
+out = {"source": f"{sys.argv[2]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, `python3 bench.py --steps 10 --warmup 2 --no-cpu --new-frames 0` via "
                  "scripts/evidence.sh; mean over the dispatches of each kernel, prewarm included)",
        "workload": "4096x4096 / 256-px patches, 1 GPU", "kernels": {}}
 total = 0

@@ -159,3 +159,8 @@ def test_band_plan_of_config4(world):
     recompute = make_band_plans(coords, 256, 8192, world, seam="recompute")
     assert all(b.send_rows == 0 and b.recv_rows == 0 and b.out_rows == b.own_rows for b in recompute)
     assert sum(len(b.patch_index) for b in recompute) == 4225 + 65 * (world - 1)  # one shared lattice row per seam
+    # ... and the bands are cut so that own + recomputed patches balance: the largest band is as small as whole lattice rows allow
+    sizes = [len(b.patch_index) for b in recompute]
+    assert max(sizes) == -(-(65 + world - 1) // world) * 65 and sum(b.own_rows for b in recompute) == 8192
+    if world == 8:
+        assert sizes == [585] * 8 and [b.own_rows for b in recompute] == [1024] * 8
