@@ -92,20 +92,24 @@ def make_band_plans(coordinates, patch_size: int, height: int, world: int, pad_m
         # A band also runs the patches above it that reach into its rows, so what has to be balanced is own + recomputed patches:
         # the cuts that minimise the largest band (dynamic programme over the lattice rows; 65 rows x 8 bands is nothing).  On the
         # 8192-wide, 256-px lattice this gives 9 | 8 + 1 | ... | 8 + 1 rows = 585 patches on every rank instead of 520 ... 650.
-        def cost(a: int, b_: int) -> int:  # rows [a, b_) own; rows above whose footprint passes the band's first own row
-            lo = max(int(lattice_rows[a]), 0) if a > 0 else 0
-            above = int(sum(counts[j] for j in range(a) if lattice_rows[j] + n > lo)) if a > 0 else 0
-            return int(cum[b_] - cum[a]) + above
-
-        best = {(0, 0): (0, None)}  # (bands used, rows used) -> (largest band so far, previous cut)
+        lo = np.maximum(lattice_rows, 0)                               # first own output row of a band that starts at lattice row a
+        first_above = np.searchsorted(lattice_rows, lo - n, side="right")  # rows j < a with lattice_rows[j] + n > lo[a] start here
+        above = cum[np.arange(nrows)] - cum[np.minimum(first_above, np.arange(nrows))]
+        above[0] = 0
+        a_idx, b_idx = np.arange(nrows)[:, None], np.arange(nrows + 1)[None, :]
+        cost = np.where(b_idx > a_idx, cum[None, :] - cum[:nrows, None] + above[:, None], np.iinfo(np.int64).max)  # [a, b]: band = rows [a, b)
+        inf = np.iinfo(np.int64).max
+        best = np.full((world + 1, nrows + 1), inf, dtype=np.int64)  # [bands used, rows used] -> largest band so far
+        prev = np.zeros((world + 1, nrows + 1), dtype=np.int64)
+        best[0, 0] = 0
         for g in range(1, world + 1):
-            for b_ in range(g, nrows - (world - g) + 1):
-                cands = [(max(best[(g - 1, a)][0], cost(a, b_)), a) for a in range(g - 1, b_) if (g - 1, a) in best]
-                if cands:
-                    best[(g, b_)] = min(cands)
+            cand = np.maximum(best[g - 1, :nrows, None], cost)       # [a, b]
+            cand[best[g - 1, :nrows] == inf, :] = inf
+            prev[g] = np.argmin(cand, axis=0)
+            best[g] = cand[prev[g], np.arange(nrows + 1)]
         cuts, b_ = [nrows], nrows
         for g in range(world, 0, -1):
-            b_ = best[(g, b_)][1]
+            b_ = int(prev[g, b_])
             cuts.append(b_)
         cuts = cuts[::-1]
     else:
