@@ -509,7 +509,7 @@ def main() -> None:
     # ---------------- the same plan on a stream of NEW frames (N = 1): --new-frames different resident starfields and outputs in
     # rotation.  The headline loop above corrects ONE frame K times (SURVEY.md 8d's timed region); that frame and part of its colour
     # planes then sit in the 256 MB Infinity Cache from step to step, which a production stream of frames does not have.
-    new_frames_ms = None
+    new_frames_ms = new_frames_prefetch_ms = None
     if world == 1 and not rotation and not pipeline and args.new_frames > 1:
         extra = []
         for i in range(1, args.new_frames):
@@ -527,6 +527,17 @@ def main() -> None:
             plan.apply_device(ring[i % len(ring)][0].ptr, ring[i % len(ring)][1].ptr, geom)
         barrier()
         new_frames_ms = 1e3 * (time.perf_counter() - t0) / args.steps
+        if n == 256:  # the same stream of frames with the opt-in image prefetch (rpsf_plan_set_image_prefetch), then back to the default
+            plan.set_image_prefetch(True)
+            for i in range(len(ring)):
+                plan.apply_device(ring[i][0].ptr, ring[i][1].ptr, geom)
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                plan.apply_device(ring[i % len(ring)][0].ptr, ring[i % len(ring)][1].ptr, geom)
+            barrier()
+            new_frames_prefetch_ms = 1e3 * (time.perf_counter() - t0) / args.steps
+            plan.set_image_prefetch(False)
         del extra, ring
 
     # ---------------- roofline: HIP events on the plan's stream, live ----------------
@@ -598,6 +609,8 @@ def main() -> None:
         line["roofline"]["ms_per_step_new_frames"] = round(new_frames_ms, 4)
         line["roofline"]["frac_new_frames"] = round(alg_bytes / (new_frames_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         line["roofline"]["new_frames_in_rotation"] = args.new_frames
+        if new_frames_prefetch_ms is not None:  # opt-in, not the default: it costs frames that are larger than the cache
+            line["roofline"]["ms_per_step_new_frames_with_image_prefetch"] = round(new_frames_prefetch_ms, 4)
     if pipeline:  # the overlapped steps priced on the same bytes (not roofline.frac: SURVEY 8d's t is one device-resident apply)
         line["roofline"]["frac_steps_in_flight"] = round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     traffic_file = ROOT / "profiles" / "traffic_latest.json"

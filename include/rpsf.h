@@ -86,6 +86,12 @@ int rpsf_plan_set_stagger(rpsf_plan* plan, int microseconds);
  * enqueued beside it on another stream - RCCL's send/recv of the seam rows (rpsf_comm_seam_exchange) - would wait for the
  * first of them to finish.  `cus` CUs (0..128; 8 is what the sharded apply asks for) are left without a patch workgroup. */
 int rpsf_plan_set_reserved_cus(rpsf_plan* plan, int cus);
+/* Opt-in image prefetch for streams of NEW frames (256-pixel plan, single-frame applies; ignored elsewhere): the summing workgroups at
+ * the head of the persistent launch touch the image tile by tile, in the order in which the patches will gather it, as a paced side
+ * job.  A frame that was not corrected a moment ago is not in the memory-side cache, and its first gathers pay the HBM latency
+ * (transform.py:157-162 is the gather): -4 % per apply on a stream of different 4096^2 frames, nothing on a repeated one; frames
+ * larger than the cache (8192^2) lose 8 %, which is why the library does not decide this by itself. */
+int rpsf_plan_set_image_prefetch(rpsf_plan* plan, int on);
 /* Development aid: in builds compiled with -DRPSF_STAMPS the patch kernel records 16 phase
  * timestamps per patch (10 ns ticks); this copies them out.  All zeros in a normal build. */
 int rpsf_plan_debug_stamps(rpsf_plan* plan, unsigned long long* host, size_t count);

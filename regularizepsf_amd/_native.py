@@ -58,6 +58,7 @@ _PROTOTYPES = {
     "rpsf_plan_transfer_bytes": (c_int, [c_void_p, POINTER(c_size_t)]),
     "rpsf_plan_set_overlap_mode": (c_int, [c_void_p, c_int]),
     "rpsf_plan_set_stagger": (c_int, [c_void_p, c_int]),
+    "rpsf_plan_set_image_prefetch": (c_int, [c_void_p, c_int]),
     "rpsf_plan_set_reserved_cus": (c_int, [c_void_p, c_int]),
     "rpsf_plan_debug_stamps": (c_int, [c_void_p, c_void_p, c_size_t]),
     "rpsf_apply": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
@@ -208,6 +209,10 @@ class Plan:
 
     def set_stagger(self, microseconds: int) -> None:
         check(lib().rpsf_plan_set_stagger(self._handle, int(microseconds)))
+
+    def set_image_prefetch(self, on: bool) -> None:
+        """Opt-in for streams of new frames (256-pixel plan): the launch's head summing workgroups touch the image ahead of the gathers."""
+        check(lib().rpsf_plan_set_image_prefetch(self._handle, 1 if on else 0))
 
     def set_reserved_cus(self, cus: int) -> None:
         """Persistent launches leave ``cus`` CUs free for kernels enqueued beside them (the RCCL seam exchange)."""

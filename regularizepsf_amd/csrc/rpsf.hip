@@ -111,6 +111,9 @@ struct rpsf_plan {
   uint32_t sum_queue_base = 0;
   bool no_fuse = false;
   int sum_first = -1;                // RPSF_SUM_FIRST override of sum_first_for(), -1 = none
+  bool prefetch = false;             // persistent launches: head summing workgroups touch the image first (RPSF_PREFETCH)
+  uint32_t* d_prefetch_tiles = nullptr;  // per chunk: lattice tiles in the order the chunk's patches first need them
+  uint32_t prefetch_first[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   int head_patches = 0;              // (measured neutral, profiles/r03i: off) persistent launches: patches a head summing workgroup computes before it sums (RPSF_HEAD_PATCHES)
   bool fuse_pays = false;            // the second-generation plans (N = 128, 256)
   // Persistent patch workgroups (patch_kernel2_256p; fused launches of the 256-pixel plan): per-XCD slot queues, never reset
@@ -341,6 +344,25 @@ static int setup_lattice(rpsf_plan* p) {
     HIP_TRY(hipMemset(p->d_sum_queue, 0, sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&p->d_xq, 8 * 32 * sizeof(uint32_t)));
     HIP_TRY(hipMemset(p->d_xq, 0, 8 * 32 * sizeof(uint32_t)));
+    {  // image prefetch lists: for every chunk, each lattice tile once, in the order the chunk's slots first touch it
+      std::vector<uint32_t> tiles;
+      for (int x = 0; x < 8; ++x) {
+        p->prefetch_first[x] = (uint32_t)tiles.size();
+        std::vector<char> seen((size_t)nti * ntj, 0);
+        for (int s2 = std::min(n, x * chunk); s2 < std::min(n, (x + 1) * chunk); ++s2) {
+          const int i = p->h_order[s2];
+          const int li = (p->h_coords[2 * i] - r0) / half, lj = (p->h_coords[2 * i + 1] - c0) / half;
+          for (int q = 0; q < 4; ++q) {
+            const size_t tile = (size_t)(li + (q >> 1)) * ntj + (lj + (q & 1));
+            if (!seen[tile]) seen[tile] = 1, tiles.push_back((uint32_t)tile);
+          }
+        }
+      }
+
+      p->prefetch_first[8] = (uint32_t)tiles.size();
+      HIP_TRY(hipMalloc(&p->d_prefetch_tiles, std::max<size_t>(1, tiles.size()) * sizeof(uint32_t)));
+      HIP_TRY(hipMemcpy(p->d_prefetch_tiles, tiles.data(), tiles.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
   }
   if (p->direct_ok) {
     std::vector<uint4> quads(n);
@@ -570,6 +592,7 @@ extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int
     p->sum_first = -1;  // decided per launch (sum_first_for) unless the environment pins it
     if (const char* e = std::getenv("RPSF_SUM_FIRST")) p->sum_first = std::max(0, std::atoi(e)) / 8 * 8;
     if (const char* e = std::getenv("RPSF_HEAD_PATCHES")) p->head_patches = std::atoi(e) > 0 ? 1 : 0;
+    if (const char* e = std::getenv("RPSF_PREFETCH")) p->prefetch = std::atoi(e) != 0;
     if (const char* e = std::getenv("RPSF_STAGGER_US")) p->stagger_us = std::max(0, std::atoi(e));  // development sweeps
     if (const char* e = std::getenv("RPSF_RESERVED_CUS")) p->reserved_cus = std::min(128, std::max(0, std::atoi(e)));
     // (until the plane stores were kept in the Infinity Cache the fused sum cost the 128-pixel plan 3 %; now it gains 3 ... 6 %)
@@ -671,6 +694,7 @@ extern "C" void rpsf_plan_destroy(rpsf_plan* p) {
   if (p->fft_plan && g_hipfft.destroy) (void)g_hipfft.destroy(p->fft_plan);
   (void)hipFree(p->d_planes);
   (void)hipFree(p->d_carry);
+  (void)hipFree(p->d_prefetch_tiles);
   (void)hipFree(p->d_quads);
   (void)hipFree(p->d_tile_info);
   (void)hipFree(p->d_flags);
@@ -903,6 +927,9 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
             // a head summing workgroup would idle through the first patch period (no tile is complete before that): it computes one patch
             // of its XCD's chunk first (RPSF_HEAD_PATCHES=0: off)
             pp.head_patches = p->head_patches;
+            pp.prefetch = p->prefetch && p->d_prefetch_tiles ? 1 : 0;
+            pp.prefetch_tiles = p->d_prefetch_tiles;
+            for (int x = 0; x < 9; ++x) pp.prefetch_first[x] = p->prefetch_first[x];
             // persistent workgroups keep the phase they start with: holding the resident ones back by up to 10 us spreads the
             // store bursts of the chip over the patch period (profiles/r02ai, r02ak: -2..3 % from four rounds of patches on; with the
             // plane stores kept in the Infinity Cache, r02av: 0.210 / 0.208 / 0.193 / 0.190 / 0.189 / 0.191 / 0.195 ms at 0 / 5 / 8 / 10 / 12 / 15 / 20 us)
@@ -1196,6 +1223,12 @@ extern "C" int rpsf_dev_probe(int device, int blocks, int spin_us, void* out_dev
 extern "C" int rpsf_plan_set_reserved_cus(rpsf_plan* p, int cus) {
   if (!p || cus < 0 || cus > 128) return fail(RPSF_E_BADARG, "reserved CUs must be 0..128");
   p->reserved_cus = cus;
+  return RPSF_OK;
+}
+
+extern "C" int rpsf_plan_set_image_prefetch(rpsf_plan* p, int on) {
+  if (!p) return fail(RPSF_E_BADARG, "null plan");
+  p->prefetch = on != 0;
   return RPSF_OK;
 }
 

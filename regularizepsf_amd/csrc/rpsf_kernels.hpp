@@ -163,7 +163,14 @@ __device__ __forceinline__ void sum_tile(const TileSum& p0, uint32_t entry, int 
 }
 // workgroup `block` of `nblocks` co-operating ones works through the list: in fixed strides, or - fused mode, where the
 // workgroups start at different times (most while the last patches still run, the rest after them) - from a queue
-__device__ __forceinline__ void sum_tiles_worker(const TileSum& p, int block, int nblocks) {
+// BETWEEN: a side job of the calling workgroup (the image prefetch of the head summing workgroups, rpsf_kernels2.hpp), called by every thread
+// at the top of each round of the queue loop and whenever no drawn tile is complete yet; returns whether it has steps left.  It must not
+// contain a workgroup barrier (waves may disagree by a round about when a step is due).
+struct NoSideJob {
+  __device__ __forceinline__ bool operator()() const { return false; }
+};
+template <class BETWEEN = NoSideJob>
+__device__ __forceinline__ void sum_tiles_worker(const TileSum& p, int block, int nblocks, BETWEEN&& between = BETWEEN()) {
   if (!p.queue) {
     for (int i = block; i < p.count; i += nblocks) sum_tile(p, p.tiles[i], threadIdx.x, blockDim.x);
     return;
@@ -180,7 +187,9 @@ __device__ __forceinline__ void sum_tiles_worker(const TileSum& p, int block, in
   __shared__ uint32_t pick;
   int npend = 0;
   bool exhausted = false;
+  bool side_job = true;
   for (;;) {
+    if (side_job) side_job = between();
     if (threadIdx.x == 0) {
       uint32_t chosen = 0xffffffffu;
       for (;;) {
@@ -201,6 +210,10 @@ __device__ __forceinline__ void sum_tiles_worker(const TileSum& p, int block, in
           continue;
         }
         if (npend == 0) break;  // every position drawn, nothing left to wait for
+        if (side_job) {         // nothing complete yet: a step of the side job instead of a nap
+          chosen = 0xfffffffeu;
+          break;
+        }
         __builtin_amdgcn_s_sleep(4);
       }
       pick = chosen;
@@ -209,6 +222,7 @@ __device__ __forceinline__ void sum_tiles_worker(const TileSum& p, int block, in
     const uint32_t tile = pick;
     __syncthreads();
     if (tile == 0xffffffffu) return;
+    if (tile == 0xfffffffeu) continue;
     sum_tile(p, tile, threadIdx.x, blockDim.x, true);
   }
 #else
@@ -269,6 +283,9 @@ struct PatchParams {
   int persist;
   uint32_t* xq;
   uint32_t xq_base[8];
+  int prefetch;      // persistent launches: the head summing workgroups first touch the image in processing order (rpsf_kernels2.hpp, prefetch_chunk)
+  const uint32_t* prefetch_tiles;  // per chunk: the lattice tiles of the image in the order the chunk's patches first need them ...
+  uint32_t prefetch_first[9];      // ... chunk x owns entries [prefetch_first[x], prefetch_first[x + 1])
   int head_patches;  // persistent launches: the summing workgroups at the head of the grid compute this many (0 or 1) patches before they turn to summing
   float* carry;  // development (RPSF_DEV_CARRY): one half patch of private scratch per persistent workgroup
 };

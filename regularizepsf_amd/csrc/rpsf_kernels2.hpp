@@ -76,6 +76,68 @@ struct NoReenter {
   __device__ __forceinline__ void operator()(unsigned, unsigned) const {}
 };
 
+// Image prefetch by the head summing workgroups of a persistent launch (256-pixel plan).  A frame that was not corrected a moment ago is
+// not in the Infinity Cache: every first touch of a pixel by a gather then pays the HBM latency on the patch's critical path (8 different
+// frames in rotation: +10 % per apply, all of it the image - scripts/distinct_frames.py).  Head workgroup h walks the entries h / 8,
+// h / 8 + sum_first / 8, ... of chunk h % 8's tile list - the lattice tiles (N/2 x N/2 pixels) in the order in which the patch workgroups
+// of that XCD first gather them, every tile once - and touches one dword per 128-byte line, one line per thread and tile, PF_TILES tiles
+// per step and a step every PF_GAP_TICKS (10 ns ticks), as the side job of its summing loop (sum_tiles_worker): paced like this the lines
+// arrive in the memory-side cache (and the XCD's L2) ahead of the gathers of every round but the first without a burst at the start of the
+// launch (all tiles at once: profiles/r03v, +3 % on a frame that is cached anyway).  OPT-IN (rpsf_plan_set_image_prefetch): worth -4 % per
+// apply on a stream of new 4096^2 frames and nothing on a repeated one, but +8 % at 8192^2 - that frame is larger than the cache, with or
+// without a limit on how far the prefetch may run ahead of the chunk's queue - and +3 % on a band of 585 patches (profiles/r03w).  Nobody
+// needs the values: a step's loads are consumed
+// (added to a sink) at the beginning of the next step, when they have long arrived, so no wave stalls on them.
+template <class C>
+struct ImagePrefetch {
+  static constexpr int HALF = C::N / 2, LPR = HALF / 32;  // 128-byte lines per tile row
+  static constexpr int PF_TILES = 4;
+  static constexpr unsigned long long PF_GAP_TICKS = 200;
+  const PatchParams& p;
+  uint32_t first, count, e;
+  int x, slots, step, dr, dc;
+  unsigned long long last = 0;
+  float d[PF_TILES] = {};
+  float sink = 0.f;
+  __device__ __forceinline__ ImagePrefetch(const PatchParams& pp, int blk, bool on) : p(pp) {
+    static_assert(HALF * LPR == C::T, "one line per thread and tile");
+    x = blk & 7;
+    const int left = p.n_patches - x * p.chunk;
+    slots = left < p.chunk ? (left > 0 ? left : 0) : p.chunk;
+    first = on ? p.prefetch_first[x] : 0, count = on && slots > 0 ? p.prefetch_first[x + 1] - first : 0;
+    e = (uint32_t)(blk >> 3), step = p.sum_first >> 3;
+    dr = (int)threadIdx.x / LPR, dc = ((int)threadIdx.x % LPR) * 32;
+  }
+  __device__ __forceinline__ void land() {  // the previous step's loads have arrived: their registers may go
+    StaticFor<0, PF_TILES>::run([&]<int U>() RPSF_AI { sink += d[U], d[U] = 0.f; });
+  }
+  __device__ __forceinline__ void finish() {
+    land();
+    asm volatile("" ::"v"(sink));  // (the loads must happen; their values do not matter)
+  }
+  __device__ __forceinline__ bool operator()() {
+    if (e >= count) {
+      land();
+      return false;
+    }
+    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+    if (now - last < PF_GAP_TICKS) return true;
+    last = now;
+    land();
+    const ImageView& im = p.im;
+    StaticFor<0, PF_TILES>::run([&]<int U>() RPSF_AI {
+      if (e < count) {
+        const uint32_t tile = p.prefetch_tiles[first + e];
+        const int r = p.ts.lat_r0 + (int)(tile / (uint32_t)p.ts.ntj) * HALF + dr, c = p.ts.lat_c0 + (int)(tile % (uint32_t)p.ts.ntj) * HALF + dc;
+        if (r >= 0 && r < im.H && r >= im.row0 && r < im.row0 + im.rows && c >= 0 && c < im.W)
+          d[U] = *reinterpret_cast<const volatile float*>(im.img + (size_t)(r - im.row0) * im.ld + c);  // (plain policy: the line is to stay)
+      }
+      e += (uint32_t)step;
+    });
+    return true;
+  }
+};
+
 template <class C, class REENTER>
 __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reenter) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -148,6 +210,14 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_barrier();
         count_previous();
+      }
+    }
+    if constexpr (PERSIST && C::T == 512) {
+      if (!again && blk < p.sum_first) {  // a head summing workgroup: the image prefetch is its side job
+        ImagePrefetch<C> prefetch(p, blk, p.prefetch && p.n_frames <= 1);
+        sum_tiles_worker(p.ts, 0, 1, prefetch);
+        prefetch.finish();
+        return;
       }
     }
     sum_tiles_worker(p.ts, 0, 1);

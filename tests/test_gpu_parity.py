@@ -893,6 +893,29 @@ def test_persistent_patch_workgroups_bit_identical(shape):
         del os.environ["RPSF_NO_PERSIST"]
 
 
+def test_image_prefetch_changes_nothing_but_the_timing():
+    """rpsf_plan_set_image_prefetch (opt-in, for streams of new frames): the head summing workgroups of the persistent launch touch the
+    image ahead of the gathers as a side job of their summing loop.  Same bits with and without, repeated applies, two frames in turn;
+    ignored by plans it does not apply to (128-pixel patches)."""
+    from regularizepsf_amd import _native
+
+    rng = np.random.default_rng(8)
+    for n, shape in ((256, (2048, 2304)), (256, (768, 1024)), (128, (768, 1024))):
+        coords = [tuple(int(v) for v in c) for c in rp.calculate_covering(shape, n)]
+        k = (rng.standard_normal((len(coords), n, n)) + 1j * rng.standard_normal((len(coords), n, n))).astype(np.complex64)
+        images = [(rng.standard_normal(shape) * 10 + 30 + 7 * f).astype(np.float32) for f in range(2)]
+        plan = _native.Plan(n, coords)
+        plan.set_transfer(k)
+        plain = [plan.apply(im, 1) for im in images]
+        plan.set_image_prefetch(True)
+        for _ in range(3):
+            for im, ref in zip(images, plain):
+                assert np.array_equal(plan.apply(im, 1), ref)
+        plan.set_image_prefetch(False)
+        assert np.array_equal(plan.apply(images[0], 1), plain[0])
+        check(plain[1].astype(np.float64), orc.apply_transfer(images[1], coords, k, workers=-1))
+
+
 @pytest.mark.parametrize("shape,frames", [((1024, 1280), 5), ((4096, 4096), 3)])
 def test_batches_of_the_256_pixel_plan_bit_identical_to_the_loop(shape, frames):
     """Batches of the persistent 256-pixel plan: the frames of a patch slot side by side (small frames) or frame after frame in one
