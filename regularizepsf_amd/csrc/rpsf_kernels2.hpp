@@ -212,6 +212,7 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
         count_previous();
       }
     }
+#if !defined(RPSF_DEV_NO_SIDE_JOB)  // (development: A/B of the summing loop with and without the hook)
     if constexpr (PERSIST && C::T == 512) {
       if (!again && blk < p.sum_first) {  // a head summing workgroup: the image prefetch is its side job
         ImagePrefetch<C> prefetch(p, blk, p.prefetch && p.n_frames <= 1);
@@ -220,6 +221,7 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
         return;
       }
     }
+#endif
     sum_tiles_worker(p.ts, 0, 1);
     return;
   }
