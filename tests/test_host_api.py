@@ -139,3 +139,25 @@ def test_empty_transform_raises_like_the_reference():
     assert len(t) == 0
     with pytest.raises(ValueError):
         t.apply(np.zeros((8, 8)))
+
+
+def test_deferred_cube_fetches_once_and_tells_its_owner():
+    """IndexedCube._deferred (regularizepsf_amd extension: values that stay on the GPU until somebody looks at them): the loader runs once,
+    on first access, and a one-shot hook fires right after the values have arrived - before the caller can edit them - which is how a
+    transform keeps the stamp of its device-resident kernel in step (looking at K must not cost a re-upload)."""
+    calls = []
+    data = np.arange(2 * 3 * 3, dtype=np.float32).reshape(2, 3, 3)
+
+    def loader():
+        calls.append("load")
+        return data.copy()
+
+    cube = rp.IndexedCube._deferred([(0, 0), (3, 0)], (2, 3, 3), loader)
+    cube._load_hook = lambda c: calls.append(("hook", c._loader is None, c._values_array is not None))
+    assert cube.sample_shape == (3, 3) and len(cube) == 2 and cube.coordinates == [(0, 0), (3, 0)] and calls == []
+    assert np.array_equal(cube[(3, 0)], data[1])
+    assert calls == ["load", ("hook", True, True)]
+    cube[(0, 0)] = np.zeros((3, 3), np.float32)
+    assert np.array_equal(cube.values[0], np.zeros((3, 3))) and calls == ["load", ("hook", True, True)] and cube._edits == 1
+    with pytest.raises(rp.exceptions.IncorrectShapeError):
+        rp.IndexedCube._deferred([(0, 0)], (2, 3, 3), loader)
