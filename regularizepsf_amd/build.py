@@ -15,7 +15,7 @@ import sys
 
 PKG = pathlib.Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
-SOURCES = [CSRC / n for n in ("rpsf.hip", "k1_256.hip", "k1_128.hip", "k1_small.hip", "k2_256.hip", "k2_256p.hip", "k2_128.hip", "k2_128p.hip")]
+SOURCES = [CSRC / n for n in ("rpsf.hip", "k1_256.hip", "k1_128.hip", "k1_small.hip", "k2_256.hip", "k2_256p.hip", "k2_128.hip", "k2_128p.hip", "k2_256s.hip")]
 HEADERS = [CSRC / n for n in ("rpsf_core.hpp", "rpsf_core2.hpp", "rpsf_kernels.hpp", "rpsf_kernels2.hpp", "rpsf_device.hpp")] + [
     PKG.parent / "include" / "rpsf.h"]
 TARGET = PKG / "librpsf_hip.so"
@@ -107,10 +107,13 @@ def check_reentry_contract(obj: pathlib.Path, kernel: str = "patch_kernel2_256p"
         raise RuntimeError(f"{kernel}: the kernel descriptor no longer matches what RPSF_REENTER restores: {got} != {want}")
 
 
-def build(force: bool = False, verbose: bool = True, defines: tuple[str, ...] = (), target: pathlib.Path | None = None) -> pathlib.Path:
+def build(force: bool = False, verbose: bool = True, defines: tuple[str, ...] = (), target: pathlib.Path | None = None,
+          only: tuple[str, ...] = ()) -> pathlib.Path:
     """Compile every HIP kernel and the C ABI into one shared library (no GPU needed: cross-compiles).
 
-    ``defines`` (e.g. ("-DRPSF_STAMPS",)) and ``target`` select a development variant built next to the product library.
+    ``defines`` (e.g. ("-DRPSF_STAMPS",)) and ``target`` select a development variant built next to the product library;
+    ``only`` (source stems, e.g. ("k2_256p",)) compiles just those translation units with the variant's defines and takes the
+    product's objects for the rest (a variant that touches one kernel builds in seconds).
     """
     out = pathlib.Path(target) if target else TARGET
     if not force and not defines and target is None and not is_stale():
@@ -121,6 +124,11 @@ def build(force: bool = False, verbose: bool = True, defines: tuple[str, ...] = 
     newest_header = max(p.stat().st_mtime for p in HEADERS)
 
     def compile_one(src: pathlib.Path) -> pathlib.Path:
+        if only and src.stem not in only:
+            obj = OBJDIR / "product" / (src.stem + ".o")
+            if not obj.exists():
+                raise RuntimeError(f"{obj} missing: build the product library first")
+            return obj
         obj = objdir / (src.stem + ".o")
         if not force and obj.exists() and obj.stat().st_mtime > max(src.stat().st_mtime, newest_header):
             return obj
@@ -135,6 +143,8 @@ def build(force: bool = False, verbose: bool = True, defines: tuple[str, ...] = 
         objs = list(pool.map(compile_one, SOURCES))
     check_reentry_contract(next(o for o in objs if o.stem == "k2_256p"), "patch_kernel2_256p")
     check_reentry_contract(next(o for o in objs if o.stem == "k2_128p"), "patch_kernel2_128p")
+    if "-DRPSF_DEV_SPLIT" in defines:
+        check_reentry_contract(next(o for o in objs if o.stem == "k2_256s"), "patch_kernel2_256s")
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(out), *[str(o) for o in objs], "-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
@@ -145,4 +155,5 @@ def build(force: bool = False, verbose: bool = True, defines: tuple[str, ...] = 
 if __name__ == "__main__":
     defs = tuple(a for a in sys.argv[1:] if a.startswith("-D"))
     tgt = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--target=")), None)
-    build(force="--force" in sys.argv, defines=defs, target=pathlib.Path(tgt) if tgt else None)
+    only = next((tuple(a.split("=", 1)[1].split(",")) for a in sys.argv[1:] if a.startswith("--only=")), ())
+    build(force="--force" in sys.argv, defines=defs, target=pathlib.Path(tgt) if tgt else None, only=only)

@@ -6,4 +6,4 @@ struct Reenter128p {
   __device__ __forceinline__ void operator()(unsigned block, unsigned tid) const { RPSF_REENTER(patch_kernel2_128p, block, tid); }
 };
 
-extern "C" __global__ __launch_bounds__(128, 2) void patch_kernel2_128p(PatchParams p) { patch_body2<Cfg128v2>(p, Reenter128p()); }
+extern "C" __global__ __launch_bounds__(128, 2) void patch_kernel2_128p(PatchParams p) { patch_body2<Cfg128v2, Reenter128p, /*HOT*/ true>(p, Reenter128p()); }

@@ -6,4 +6,4 @@ struct Reenter256p {
   __device__ __forceinline__ void operator()(unsigned block, unsigned tid) const { RPSF_REENTER(patch_kernel2_256p, block, tid); }
 };
 
-extern "C" __global__ __launch_bounds__(512, 2) RPSF_VGPR_ATTR void patch_kernel2_256p(PatchParams p) { patch_body2<Cfg256v2>(p, Reenter256p()); }
+extern "C" __global__ __launch_bounds__(512, 2) RPSF_VGPR_ATTR void patch_kernel2_256p(PatchParams p) { patch_body2<Cfg256v2, Reenter256p, /*HOT*/ true>(p, Reenter256p()); }

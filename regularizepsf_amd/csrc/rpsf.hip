@@ -118,6 +118,13 @@ struct rpsf_plan {
   bool fuse_pays = false;            // the second-generation plans (N = 128, 256)
   // Persistent patch workgroups (patch_kernel2_256p; fused launches of the 256-pixel plan): per-XCD slot queues, never reset
   bool persist = false;
+#if defined(RPSF_DEV_SPLIT)  // development: the split-patch timing skeleton (k2_256s.hip) and its tables
+  bool dev_split = false;
+  uint16_t* d_tab_s = nullptr;
+  uint32_t* d_ot_s = nullptr;
+  cf* d_tw_s = nullptr;
+  float* d_win_s = nullptr;
+#endif
   // Co-resident summing waves (sum_waves_kernel): a second stream and the events that tie it to the apply's stream
   bool cosum = false;
   hipStream_t st_sum = nullptr;
@@ -611,6 +618,18 @@ extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int
 #if defined(RPSF_VGPR_CAP)  // (development builds only: the product's patch kernel takes all 512 registers of a SIMD lane)
     p->cosum = p->persist && std::getenv("RPSF_COSUM") != nullptr;
 #endif
+#if defined(RPSF_DEV_SPLIT)
+    if (p->persist && N == 256 && !(std::getenv("RPSF_DEV_SPLIT") && std::atoi(std::getenv("RPSF_DEV_SPLIT")) == 0)) {
+      p->dev_split = true;
+      int r3 = upload_tables2<Cfg256half>(device, &p->d_tab_s, &p->d_tw_s, &p->d_win_s, &p->d_ot_s);
+      if (r3 != RPSF_OK) return r3;
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_kernel2_256s), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)Launch2<Cfg256half>::LDS_BYTES));
+      int per_cu = 0;
+      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, patch_kernel2_256s, 256, Launch2<Cfg256half>::LDS_BYTES));
+      if (per_cu < 2) return fail(RPSF_E_STATE, "split skeleton: two workgroups per CU do not fit (" + std::to_string(per_cu) + ")");
+    }
+#endif
     if (p->cosum) {
       HIP_TRY(hipStreamCreateWithFlags(&p->st_sum, hipStreamNonBlocking));
       HIP_TRY(hipEventCreateWithFlags(&p->ev_sum_go, hipEventDisableTiming));
@@ -849,6 +868,15 @@ static int sum_first_for(const rpsf_plan* p, int frames) {
   return work >= 2048 ? 32 : work >= 1024 ? 16 : work >= 512 ? 8 : 0;
 }
 
+// What the persistent kernels are compiled for (patch_body2's HOT instantiation has no pixel-by-pixel rim paths): every 16-byte unit
+// of a patch - four pixels of one row starting at a column that is a multiple of 4 - maps under np.pad's index map to four consecutive
+// image columns (ascending or descending) or to the fill.  True for 'constant', 'symmetric' and 'wrap' when the width is a multiple of
+// 4 (no unit straddles an image edge or a reflection); 'reflect' and 'edge' tear units apart.  Other launches take patch_kernel2.
+static bool hot_geometry(const float* d_img, const rpsf_geometry& g, size_t im_stride) {
+  return (g.pad_mode == RPSF_PAD_CONSTANT || g.pad_mode == RPSF_PAD_SYMMETRIC || g.pad_mode == RPSF_PAD_WRAP) && g.width % 4 == 0 &&
+         g.ld_image % 4 == 0 && g.origin_col % 4 == 0 && im_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(d_img) & 15) == 0;
+}
+
 // fused: the plane sum runs in this launch (see rpsf_plan::d_tile_done)
 static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const rpsf_geometry& g, OverlapKind kind,
                           hipStream_t st, Batch b = Batch(), bool fused = false) {
@@ -922,7 +950,29 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
           if (p->cosum) pp.sum_first = 0;  // the summing is done by waves beside the patch workgroups: every CU takes patches
           // (queue positions of an XCD: chunk slots x frames, the frames of a slot side by side)
           const int rows = std::min(pp.chunk * b.frames, std::max(1, (p->round_capacity - pp.sum_first - p->reserved_cus) / 8));
-          if (p->persist && rows > 0) {
+#if defined(RPSF_DEV_SPLIT)
+          if constexpr (std::is_same_v<C, Cfg256v2>)
+            if (p->dev_split && p->persist && rows > 0 && b.frames == 1 && hot_geometry(d_img, g, b.im_stride)) {
+              // queue positions are half patches, two 256-thread workgroups per CU (head summing workgroups are half the size too)
+              const int cap2 = 2 * p->round_capacity;
+              pp.sum_first *= 2;
+              const int rows2 = std::min(2 * pp.chunk, std::max(1, (cap2 - pp.sum_first - 2 * p->reserved_cus) / 8));
+              pp.persist = rows2, pp.xq = p->d_xq, pp.patch_blocks = 2 * (int)blocks, pp.stagger_blocks = cap2;
+              pp.tab = p->d_tab_s, pp.pairtab = p->d_ot_s, pp.head_patches = 0, pp.prefetch = 0;
+              if (p->stagger_us < 0 && p->n_patches >= 256) pp.stagger_ticks = 1200;
+              for (int x = 0; x < 8; ++x) {
+                pp.xq_base[x] = p->xq_base[x];
+                const int slots_x = 2 * std::min(pp.chunk, std::max(0, p->n_patches - x * pp.chunk));
+                p->xq_base[x] += (uint32_t)(slots_x + rows2);
+              }
+              const int wgs = pp.sum_first + 8 * rows2;
+              p->sum_queue_base += (uint32_t)(ts.count + wgs);
+              patch_kernel2_256s<<<dim3((unsigned)wgs), dim3(256), Launch2<Cfg256half>::LDS_BYTES, st>>>(pp);
+              HIP_TRY(hipGetLastError());
+              return RPSF_OK;
+            }
+#endif
+          if (p->persist && rows > 0 && hot_geometry(d_img, g, b.im_stride)) {
             pp.persist = rows, pp.xq = p->d_xq;
             // a head summing workgroup would idle through the first patch period (no tile is complete before that): it computes one patch
             // of its XCD's chunk first (RPSF_HEAD_PATCHES=0: off)

@@ -30,16 +30,19 @@ struct alignas(16) cf2 {
   cf a, b;
 };
 
-template <int LOGN_, int A1_, int A2_, int AL_, int B1_, int B2_>
+// LOGR_ < LOGN_ (development, RPSF_DEV_SPLIT): a patch of 2^LOGR_ rows x N columns - the work unit of the split-patch timing skeleton
+// (two 256-thread workgroups per CU, each on half a 256-pixel patch; results are wrong by design, see rpsf_kernels2.hpp).
+template <int LOGN_, int A1_, int A2_, int AL_, int B1_, int B2_, int LOGR_ = LOGN_>
 struct Cfg2 {
-  static constexpr int LOGN = LOGN_, N = 1 << LOGN_, NC = N / 2;
+  static constexpr int LOGN = LOGN_, N = 1 << LOGN_, NC = N / 2, LOGR = LOGR_, ROWS = 1 << LOGR_;
+  static constexpr bool HALF = LOGR_ != LOGN_;
   static constexpr int A1 = A1_, A2 = A2_, AL = AL_, B1 = B1_, B2 = B2_, BL = 1;
   static_assert(A1_ + B1_ == 5 && A2_ + B2_ == 5, "32 values per thread, half and stage");
-  static_assert(A1_ + A2_ + AL_ == LOGN_ && B1_ + B2_ + 1 == LOGN_ - 1, "digits must cover the index");
+  static_assert(A1_ + A2_ + AL_ == LOGR_ && B1_ + B2_ + 1 == LOGN_ - 1, "digits must cover the index");
   static_assert(A1_ >= 1 && B1_ >= 1, "the top row / column bits must be stage-1 register digits (quadrants)");
   static constexpr bool S3 = true;
   static constexpr int EA = 1 << AL_, EB = 2, E = EA * EB, P = 64 / E, NSLOT = P / 2;
-  static constexpr int T = N * NC / 64, WAVES = T / 64;
+  static constexpr int T = ROWS * NC / 64, WAVES = T / 64;
   static_assert(WAVES * 2 == EA, "r3 = 2 wave + hb");
   static constexpr int LQ = A1_ + A2_, Q = 1 << LQ, M = 1 << (B1_ + B2_), G = Q * M;
   static_assert(G == 1024, "32 x 32 groups");
@@ -496,12 +499,18 @@ RPSF_HD cf pack_orbit2(const cf* __restrict__ kfull, const uint16_t* __restrict_
 // ------------------------------------------------------------------------------------------
 // Image side.  Unit (R1, C1) of a thread: row r = (R1 << (A2+AL)) + r_low, pixels 4c' .. 4c'+3, c' = (C1 << B2) + c2.
 // ------------------------------------------------------------------------------------------
+template <class C>
+RPSF_HD bool patch_inside2(int pr, int pc, int H, int W, int row0, int rows) {
+  return pr >= 0 && pc >= 0 && pr + C::ROWS <= H && pc + C::N <= W && pr >= row0 && pr + C::ROWS <= row0 + rows;
+}
 RPSF_HD bool quads_aligned(const void* base, int ld, int pc) { return ((ld | pc) & 3) == 0 && (reinterpret_cast<uintptr_t>(base) & 15) == 0; }
 
 // Gather in two steps so that a persistent workgroup can request the next patch's pixels while the stores of the
 // current one drain: load_raw2 issues the loads (np.pad index maps from LDS for patches that hang over the edge),
 // window_patch2 applies the sine window (transform.py:151-155,163) once the values are needed.
-template <class C>
+// HOT (the specialised persistent kernels, rpsf_kernels2.hpp): the launcher has checked that every unit of a rim patch maps to four
+// consecutive image columns or to the fill (hot_geometry in rpsf.hip), so the pixel-by-pixel path is not compiled in.
+template <class C, bool HOT = false>
 RPSF_HD void load_raw2(int t, cf* v, const ImageView& im, int pr, int pc, bool fast, const int* maps) {
   ThreadPos2<C> tp(t);
   constexpr int NR = 1 << C::A1, NCOL = 1 << C::B1;
@@ -527,7 +536,7 @@ RPSF_HD void load_raw2(int t, cf* v, const ImageView& im, int pr, int pc, bool f
     // registers); only units the map tears apart ('reflect', 'edge', widths that are no multiple of 4) go pixel by pixel.
     int xq[NCOL];
     bool rev[NCOL], cst[NCOL];
-    bool quad = quads_aligned(im.img, im.ld, 0);
+    bool quad = HOT || quads_aligned(im.img, im.ld, 0);
     StaticFor<0, NCOL>::run([&]<int C1>() RPSF_AI {
       const int* m = maps + C::N + 4 * ((C1 << C::B2) + tp.c2);
       const int m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3];
@@ -536,9 +545,9 @@ RPSF_HD void load_raw2(int t, cf* v, const ImageView& im, int pr, int pc, bool f
       cst[C1] = (m0 & m1 & m2 & m3) < 0;  // all four are "constant value"
       rev[C1] = dn;
       xq[C1] = up ? m0 : dn ? m3 : 0;
-      quad = quad && (up || dn || cst[C1]);
+      quad = HOT || (quad && (up || dn || cst[C1]));
     });
-    if (quad) {
+    if (HOT || quad) {
       StaticFor<0, NR>::run([&]<int R1>() RPSF_AI {
         const int r = (R1 << (C::A2 + C::AL)) + tp.r_low;
         const int yl = maps[r];
@@ -553,6 +562,7 @@ RPSF_HD void load_raw2(int t, cf* v, const ImageView& im, int pr, int pc, bool f
       });
       return;
     }
+    if constexpr (!HOT)
     StaticFor<0, NR>::run([&]<int R1>() RPSF_AI {
       const int r = (R1 << (C::A2 + C::AL)) + tp.r_low;
       const int yl = maps[r];
@@ -601,16 +611,18 @@ RPSF_HD void load_patch2(int t, cf* v, const ImageView& im, int pr, int pc, cons
 //   LOAD1 = L1-bypassing loads), QUAD_SIDE quadrants into the colour plane.
 // PSTORE4 / PSTORE1: 16- and 4-byte stores into the colour plane (streaming, or write-through when the plane sum runs
 // in the same launch).
-template <class C, class ADD, class LOAD4, class LOAD1, class PSTORE4, class PSTORE1>
+// HOT: colour planes whose geometry the launcher has checked (whole units inside or outside the image): interior patches and the
+// 16-byte rim path only.
+template <class C, bool HOT = false, class ADD, class LOAD4, class LOAD1, class PSTORE4, class PSTORE1>
 RPSF_HD void store_patch2(int t, const cf* v, const OutView& pv, const OutView& dv, int plane, int pr, int pc,
                           const float* __restrict__ win, const uint32_t* qw, ADD&& add, LOAD4&& load4, LOAD1&& load1,
                           PSTORE4&& pstore4, PSTORE1&& pstore1) {
   ThreadPos2<C> tp(t);
   constexpr int NR = 1 << C::A1, NCOL = 1 << C::B1;
-  const bool planes = pv.plane_stride != 0;
+  const bool planes = HOT || pv.plane_stride != 0;
   float* pbase = pv.out + (size_t)plane * pv.plane_stride;
-  const bool fast = patch_inside<C>(pr, pc, pv.H, pv.W, pv.row0, pv.rows) && quads_aligned(pbase, pv.ld, pc) &&
-                    (planes || qw) && (!qw || quads_aligned(dv.out, dv.ld, pc));
+  const bool fast = patch_inside2<C>(pr, pc, pv.H, pv.W, pv.row0, pv.rows) && (HOT || (quads_aligned(pbase, pv.ld, pc) &&
+                    (planes || qw) && (!qw || quads_aligned(dv.out, dv.ld, pc))));
   if (__builtin_expect(fast, 1)) {
     float* prow0 = pbase + (size_t)(pr - pv.row0) * pv.ld + pc;
     float* drow0 = qw ? dv.out + (size_t)(pr - dv.row0) * dv.ld + pc : nullptr;
@@ -646,7 +658,7 @@ RPSF_HD void store_patch2(int t, const cf* v, const OutView& pv, const OutView& 
     });
     return;
   }
-  if (planes && !qw && quads_aligned(pbase, pv.ld, pc) && (pv.W & 3) == 0) {
+  if (HOT || (planes && !qw && quads_aligned(pbase, pv.ld, pc) && (pv.W & 3) == 0)) {
     // Rim patches in plane mode: with the corner column and the image width multiples of 4 a unit lies wholly inside or
     // wholly outside the image, so the part of the patch that is inside still goes out in 16-byte stores (and a 128-byte
     // line is still written whole by one store instruction whenever the image edges are line-aligned, which is what
@@ -667,6 +679,7 @@ RPSF_HD void store_patch2(int t, const cf* v, const OutView& pv, const OutView& 
     });
     return;
   }
+  if constexpr (!HOT)
   StaticFor<0, NR>::run([&]<int R1>() RPSF_AI {
     const int r = (R1 << (C::A2 + C::AL)) + tp.r_low;
     const float wr = win[r];
@@ -741,5 +754,6 @@ RPSF_HD void store_patch2_carry(int t, const cf* v, const OutView& pv, int plane
 // Plans compiled into the library
 using Cfg256v2 = Cfg2<8, 4, 0, 4, 1, 5>;
 using Cfg128v2 = Cfg2<7, 4, 1, 2, 1, 4>;
+using Cfg256half = Cfg2<8, 4, 0, 3, 1, 5, 7>;  // development (RPSF_DEV_SPLIT): 128 rows x 256 columns, 256 threads
 
 }  // namespace rpsf

@@ -138,7 +138,10 @@ struct ImagePrefetch {
   }
 };
 
-template <class C, class REENTER>
+// HOT: the instantiation the persistent kernels are compiled from - a fused launch on colour planes whose geometry the launcher has
+// checked (hot_geometry, rpsf.hip): no float atomics, no direct mode, no pixel-by-pixel rim paths in the code (they cost the 256-pixel
+// kernel 29 spilled SGPRs and half of its 200 KB).  Everything else runs the one-patch-per-workgroup kernel patch_kernel2.
+template <class C, class REENTER, bool HOT = false>
 __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reenter) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int T = C::T, N = C::N;
@@ -164,6 +167,7 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   const int pb = head_patch ? (blk & 7) : blk - p.sum_first;                             // workgroup-uniform
   bool patchy = pb >= 0 && pb < p.patch_blocks;
   int frame = 0, xrow = 0, seq = 0;
+  [[maybe_unused]] int half = 0;  // (RPSF_DEV_SPLIT skeleton, C::HALF: a queue position is half a patch - rows [half ROWS, (half + 1) ROWS))
   if (patchy) {
     xrow = p.slot0 + (pb >> 3);
     if constexpr (PERSIST) {
@@ -182,6 +186,7 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
         xrow += p.head_patches ? p.sum_first >> 3 : 0;
       }
     }
+    if constexpr (C::HALF) half = xrow & 1, xrow >>= 1;
     if (p.n_frames > 1) {
       if (p.frame_major) {  // persistent batches of large frames: one frame after the other (its planes stay in the Infinity Cache)
         const int left = p.n_patches - (pb & 7) * p.chunk, mine = left < p.chunk ? (left > 0 ? left : 1) : p.chunk;  // slots of this XCD
@@ -202,7 +207,7 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   cf* const park = lds + C::BUF_UNITS;
   // persistent form: the previous patch of this workgroup is counted on its tiles once its plane stores have drained
   [[maybe_unused]] auto count_previous = [&]() RPSF_AI {
-    if (t < 4) __hip_atomic_fetch_add(p.tile_done + reinterpret_cast<const unsigned*>(park)[1 + t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t < (C::HALF ? 2 : 4)) __hip_atomic_fetch_add(p.tile_done + reinterpret_cast<const unsigned*>(park)[1 + t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   if (!patchy) {
     if constexpr (PERSIST) {
@@ -254,8 +259,9 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   if (threadIdx.x == 0) p.stamps[(size_t)patch * 16 + 14] = *reinterpret_cast<const unsigned long long*>(reinterpret_cast<cf*>(smem + Launch2<C>::TABLE_FLOATS) + C::BUF_UNITS + 4);
   if (threadIdx.x == 0) p.stamps[(size_t)patch * 16 + 15] = 1 + (again ? reinterpret_cast<const uint32_t*>(smem + 3 * C::N)[Launch2<C>::OT_WORDS - 1] : blockIdx.x);
 #endif
-  const int pr = dsc.x + p.origin_row, pc = dsc.y + p.origin_col;
-  const cf* g = p.g + (size_t)patch * C::G_PER_PATCH;
+  const int pr = dsc.x + p.origin_row + (C::HALF ? half * C::ROWS : 0), pc = dsc.y + p.origin_col;
+  const int kpatch = C::HALF ? 2 * patch + half : patch;  // (skeleton: the two halves share the patch's K bytes between them)
+  const cf* g = p.g + (size_t)kpatch * C::G_PER_PATCH;
   cf* tw = reinterpret_cast<cf*>(smem);
   float* win = smem + 2 * N;
   uint32_t* ot = reinterpret_cast<uint32_t*>(smem + 3 * N);
@@ -273,7 +279,7 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   GroupIds<C> gids;
   gids.load(p.tab, t);
   cf v[64];
-  const bool fast = patch_inside<C>(pr, pc, im.H, im.W, im.row0, im.rows) && quads_aligned(im.img, im.ld, pc);
+  const bool fast = patch_inside2<C>(pr, pc, im.H, im.W, im.row0, im.rows) && quads_aligned(im.img, im.ld, pc);
   int* maps = reinterpret_cast<int*>(lds);
   if (!fast) {
     build_pad_maps<C>(t, maps, im, pr, pc);
@@ -283,7 +289,7 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
 #pragma unroll
   for (int j = 0; j < 64; ++j) v[j] = cf{(float)(t + j), (float)(t - j)};
 #else
-  load_raw2<C>(t, v, im, pr, pc, fast, maps);
+  load_raw2<C, HOT>(t, v, im, pr, pc, fast, maps);
 #endif
   if (!again) {
     if (t < N) tw[t] = tw0, win[t] = wn0;
@@ -321,7 +327,7 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
 #endif
   cf ko[2 * C::ORBIT_ROUNDS];
   if (t < 64) {
-    const cf* gs = p.gs + (size_t)patch * C::GS_PER_PATCH;
+    const cf* gs = p.gs + (size_t)kpatch * C::GS_PER_PATCH;
     StaticFor<0, C::ORBIT_ROUNDS>::run([&]<int R>() RPSF_AI { load_stream16(gs + (size_t)(R * 64 + t) * 2, ko[2 * R], ko[2 * R + 1]); });
   }
   ABL_BAR();  // every wave has left its X1 region (X2 uses the whole buffer)
@@ -406,15 +412,15 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   STAMP(9);
   // ---- overlap-add ----
 #if defined(RPSF2_ABL_NOSTORE)
-  {  // keep every value live but store (almost) nothing
+  if (!p.tile_done) {  // keep every value live but store (almost) nothing
     float acc = 0.f;
 #pragma unroll
     for (int j = 0; j < 64; ++j) acc += v[j].x * v[j].y;
     if (acc == 123456.789f) ov.out[threadIdx.x] = acc;
     return;
-  }
+  }  // (fused / persistent launches keep their protocol: the plane stores below become no-ops that keep the values live)
 #endif
-  const int plane = ov.plane_stride ? dsc.w : 0;
+  const int plane = HOT || ov.plane_stride ? dsc.w : 0;
   auto add = [](float* a, float val) { unsafeAtomicAdd(a, val); };
 #if defined(RPSF_DEV_PSTORE_PLAIN)  // development: plane stores of the non-fused path without the streaming hint
   auto pstore4 = [](float* a, f32x4 val) RPSF_AI { *reinterpret_cast<f32x4*>(a) = val; };
@@ -422,7 +428,7 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   auto pstore4 = [](float* a, f32x4 val) RPSF_AI { __builtin_nontemporal_store(val, reinterpret_cast<f32x4*>(a)); };
 #endif
   auto pstore1 = [](float* a, float val) RPSF_AI { *a = val; };
-  if (p.dv.out) {  // direct overlap-add (opt-in; moves as many bytes as the planes do and waits on top - DESIGN.md)
+  if (!HOT && p.dv.out) {  // direct overlap-add (opt-in; moves as many bytes as the planes do and waits on top - DESIGN.md)
     OutView dv = p.dv;
     dv.out += (size_t)frame * p.dv_frame_floats;
     uint32_t qw[4];
@@ -437,7 +443,7 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
     STAMP(11);
     direct_end(p, frame, plane, qw);
     STAMP(12);
-  } else if (p.tile_done) {
+  } else if (HOT || p.tile_done) {
     // Plane sum fused into this launch: the plane stores are write-through, and once they have drained the patch is
     // counted on its four tiles; the workgroups behind the patches in the grid sum a tile as soon as its count is complete.
     const float* pbase = ov.out;
@@ -449,6 +455,8 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
     if constexpr (PERSIST) {
       if (t < 4) {  // (and the tiles this patch will be counted on: a load behind the stores would wait for them)
         const uint4 q4 = p.quads[p.seq_base + seq];
+        if constexpr (C::HALF) my_tile = quad_tile(half ? (t == 0 ? q4.z : q4.w) : (t == 0 ? q4.x : q4.y));  // the two tiles under this half
+        else
         my_tile = (unsigned)frame * p.n_tiles + quad_tile(t == 0 ? q4.x : t == 1 ? q4.y : t == 2 ? q4.z : q4.w);  // (this frame's counters)
       }
       if (t == 0 && !head_patch)
@@ -458,7 +466,7 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
 #if defined(RPSF_DEV_CARRY)
     // timing experiment (results are wrong): the right half of every patch goes to the workgroup's private carry buffer, what the
     // previous patch left there is added to the left half, and only that reaches a colour plane (two planes, by lattice-row parity)
-    if (PERSIST && patch_inside<C>(pr, pc, ov.H, ov.W, ov.row0, ov.rows) && quads_aligned(ov.out, ov.ld, pc)) {
+    if (PERSIST && patch_inside2<C>(pr, pc, ov.H, ov.W, ov.row0, ov.rows) && quads_aligned(ov.out, ov.ld, pc)) {
 #if RPSF_DEV_CARRY >= 2  // ring of hand-off buffers per XCD chunk: queue position q writes slot q % 64 and reads slot (q - 1) % 64 - what the
                          // workgroup that drew the previous position (a neighbour on the same XCD, a moment ago) wrote (no flags: timing only)
       float* const cw = p.carry + (size_t)((pb & 7) * 64 + (xrow & 63)) * (C::T * 64);
@@ -484,9 +492,14 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
                             [=](float* a, f32x4 val) RPSF_AI { plane_store16_wt(rsrc, (size_t)(a - pbase), val); });
     } else
 #endif
-    store_patch2<C>(
+    store_patch2<C, HOT>(
         t, v, ov, ov, plane, pr, pc, win, nullptr, add, []<int R1, int C1>(const float* a) RPSF_AI { return *reinterpret_cast<const f32x4*>(a); },
-        [](const float* a) { return *a; }, [=](float* a, f32x4 val) RPSF_AI { plane_store16_wt(rsrc, (size_t)(a - pbase), val); },
+        [](const float* a) { return *a; },
+#if defined(RPSF2_ABL_NOSTORE)
+        [=](float* a, f32x4 val) RPSF_AI { asm volatile("" ::"v"(val.x), "v"(val.y), "v"(val.z), "v"(val.w), "v"(a)); },
+#else
+        [=](float* a, f32x4 val) RPSF_AI { plane_store16_wt(rsrc, (size_t)(a - pbase), val); },
+#endif
         [](float* a, float val) RPSF_AI { __hip_atomic_store(reinterpret_cast<unsigned*>(a), __float_as_uint(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); });
     STAMP(10);
     if constexpr (PERSIST) {
@@ -499,7 +512,7 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
       const unsigned nx = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const unsigned*>(park));
       const int left = p.n_patches - (pb & 7) * p.chunk;  // slots of this XCD's chunk that hold a patch (x frames: queue positions)
       // ... or, once the chunk is exhausted, a block index behind the patches: the workgroup sums tiles with the others
-      const bool more = (int)nx < (left < p.chunk ? left : p.chunk) * (p.n_frames > 1 ? p.n_frames : 1);
+      const bool more = (int)nx < (left < p.chunk ? left : p.chunk) * (p.n_frames > 1 ? p.n_frames : 1) * (C::HALF ? 2 : 1);
       // (a head summing workgroup has had its patch: it re-enters under its own block index and sums from now on)
       reenter(0x40000000u | (head_patch ? (unsigned)blk : (unsigned)p.sum_first + (more ? ((nx << 3) | (unsigned)(pb & 7)) : (unsigned)p.patch_blocks)),
               (unsigned)t);
@@ -535,6 +548,11 @@ extern "C" __global__ __launch_bounds__(512, 2) RPSF_VGPR_ATTR void patch_kernel
 // ... and of the 128-pixel plan (k2_128p.hip): four 128-thread workgroups per CU hide the dispatch of one another, but only
 // persistent ones keep the phase offsets of the start-up stagger
 extern "C" __global__ __launch_bounds__(128, 2) void patch_kernel2_128p(PatchParams p);
+#if defined(RPSF_DEV_SPLIT)
+// Development: the split-patch timing skeleton (k2_256s.hip) - half patches (128 rows x 256 columns) on 256-thread workgroups, two per CU,
+// the same phases, K bytes, LDS traffic and plane stores per pixel as patch_kernel2_256p; results are wrong by design.
+extern "C" __global__ __launch_bounds__(256, 2) void patch_kernel2_256s(PatchParams p);
+#endif
 template <class C>
 struct PersistentKernel2;
 template <>
