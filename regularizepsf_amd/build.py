@@ -145,6 +145,8 @@ def build(force: bool = False, verbose: bool = True, defines: tuple[str, ...] = 
     check_reentry_contract(next(o for o in objs if o.stem == "k2_128p"), "patch_kernel2_128p")
     if "-DRPSF_DEV_SPLIT" in defines:
         check_reentry_contract(next(o for o in objs if o.stem == "k2_256s"), "patch_kernel2_256s")
+    if "-DRPSF_DEV_WIDE" in defines:
+        check_reentry_contract(next(o for o in objs if o.stem == "k2_256s"), "patch_kernel2_256w")
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(out), *[str(o) for o in objs], "-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)

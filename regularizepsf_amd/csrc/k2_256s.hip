@@ -10,3 +10,13 @@ struct Reenter256s {
 
 extern "C" __global__ __launch_bounds__(256, 2) void patch_kernel2_256s(PatchParams p) { patch_body2<Cfg256half, Reenter256s, /*HOT*/ true>(p, Reenter256s()); }
 #endif
+
+#if defined(RPSF_DEV_WIDE)
+// ... and of VERDICT round 2's 1024-thread layout: one workgroup of 16 waves per CU, 32 values per thread, 128 registers (Cfg256wide)
+struct Reenter256w {
+  static constexpr bool enabled = true;
+  __device__ __forceinline__ void operator()(unsigned block, unsigned tid) const { RPSF_REENTER(patch_kernel2_256w, block, tid); }
+};
+
+extern "C" __global__ __launch_bounds__(1024, 4) void patch_kernel2_256w(PatchParams p) { patch_body2<Cfg256wide, Reenter256w, /*HOT*/ true>(p, Reenter256w()); }
+#endif

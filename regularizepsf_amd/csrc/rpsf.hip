@@ -618,6 +618,11 @@ extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int
 #if defined(RPSF_VGPR_CAP)  // (development builds only: the product's patch kernel takes all 512 registers of a SIMD lane)
     p->cosum = p->persist && std::getenv("RPSF_COSUM") != nullptr;
 #endif
+#if defined(RPSF_DEV_WIDE)
+    if (p->persist && N == 256)
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_kernel2_256w), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)Launch2<Cfg256v2>::LDS_BYTES));
+#endif
 #if defined(RPSF_DEV_SPLIT)
     if (p->persist && N == 256 && !(std::getenv("RPSF_DEV_SPLIT") && std::atoi(std::getenv("RPSF_DEV_SPLIT")) == 0)) {
       p->dev_split = true;
@@ -1012,6 +1017,12 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
               HIP_TRY(hipEventRecord(p->ev_sum_go, st));
               HIP_TRY(hipStreamWaitEvent(p->st_sum, p->ev_sum_go, 0));
             }
+#if defined(RPSF_DEV_WIDE)  // development: the 1024-thread timing skeleton in place of the persistent 256-pixel kernel
+            if (std::is_same_v<C, Cfg256v2> && b.frames == 1 && !(std::getenv("RPSF_DEV_WIDE") && std::atoi(std::getenv("RPSF_DEV_WIDE")) == 0)) {
+              pp.prefetch = 0;
+              patch_kernel2_256w<<<dim3((unsigned)wgs), dim3(1024), Launch2<Cfg256v2>::LDS_BYTES, st>>>(pp);
+            } else
+#endif
             PersistentKernel2<C>::fn<<<dim3((unsigned)wgs), dim3(Launch2<C>::WG), Launch2<C>::LDS_BYTES, st>>>(pp);
             HIP_TRY(hipGetLastError());
             if (ncos) {  // ... and the apply is complete on `st` when they are

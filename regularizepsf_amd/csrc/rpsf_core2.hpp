@@ -36,6 +36,7 @@ template <int LOGN_, int A1_, int A2_, int AL_, int B1_, int B2_, int LOGR_ = LO
 struct Cfg2 {
   static constexpr int LOGN = LOGN_, N = 1 << LOGN_, NC = N / 2, LOGR = LOGR_, ROWS = 1 << LOGR_;
   static constexpr bool HALF = LOGR_ != LOGN_;
+  static constexpr bool WIDE = false;  // (development, RPSF_DEV_WIDE: see Cfg256wide)
   static constexpr int A1 = A1_, A2 = A2_, AL = AL_, B1 = B1_, B2 = B2_, BL = 1;
   static_assert(A1_ + B1_ == 5 && A2_ + B2_ == 5, "32 values per thread, half and stage");
   static_assert(A1_ + A2_ + AL_ == LOGR_ && B1_ + B2_ + 1 == LOGN_ - 1, "digits must cover the index");
@@ -754,6 +755,11 @@ RPSF_HD void store_patch2_carry(int t, const cf* v, const OutView& pv, int plane
 // Plans compiled into the library
 using Cfg256v2 = Cfg2<8, 4, 0, 4, 1, 5>;
 using Cfg128v2 = Cfg2<7, 4, 1, 2, 1, 4>;
-using Cfg256half = Cfg2<8, 4, 0, 3, 1, 5, 7>;  // development (RPSF_DEV_SPLIT): 128 rows x 256 columns, 256 threads
+using Cfg256half = Cfg2<8, 4, 0, 3, 1, 5, 7>;
+// development (RPSF_DEV_WIDE): the timing skeleton of a 1024-thread / 32-values-per-thread layout of the 256-pixel plan - four waves per SIMD
+// at 128 registers.  Thread tu and thread tu + 512 both stand in for thread tu % 512 of Cfg256v2 and each does half of its work.
+struct Cfg256wide : Cfg2<8, 4, 0, 4, 1, 5> {
+  static constexpr bool WIDE = true;
+};  // development (RPSF_DEV_SPLIT): 128 rows x 256 columns, 256 threads
 
 }  // namespace rpsf

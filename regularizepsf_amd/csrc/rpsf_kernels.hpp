@@ -84,6 +84,7 @@ __device__ __forceinline__ void plane_store16_wt(__amdgpu_buffer_rsrc_t r, size_
   __builtin_amdgcn_raw_buffer_store_b128(q, r, (int)(RPSF_PLANE_OFF(float_offset) * sizeof(float)), 0, RPSF_DEV_PLANE_AUX);
 }
 
+template <int UN = 8>  // groups in flight per thread: 4 x UN sixteen-byte loads
 __device__ __forceinline__ void sum_tile(const TileSum& p0, uint32_t entry, int tid, int nthreads, bool known_complete = false) {
   typedef float f4 __attribute__((ext_vector_type(4)));
   const uint32_t tile = entry & 0xffffffu, frame = entry >> 24;
@@ -117,7 +118,7 @@ __device__ __forceinline__ void sum_tile(const TileSum& p0, uint32_t entry, int 
   if (vec) {
     const __amdgpu_buffer_rsrc_t rsrc = plane_rsrc(p.planes);
     const int gw = (x1 - x0) >> 2, total = gw * (y1 - y0);
-    constexpr int UN = 8;  // groups in flight per thread: 32 sixteen-byte loads - a whole tile per pass for the patch kernels' workgroup sizes
+    // (UN = 8: 32 sixteen-byte loads per thread - a whole tile per pass for the patch kernels' workgroup sizes)
     for (int i0 = tid; i0 < total; i0 += UN * nthreads) {
       f4 v[UN][4];
 #pragma unroll
@@ -169,10 +170,10 @@ __device__ __forceinline__ void sum_tile(const TileSum& p0, uint32_t entry, int 
 struct NoSideJob {
   __device__ __forceinline__ bool operator()() const { return false; }
 };
-template <class BETWEEN = NoSideJob>
+template <class BETWEEN = NoSideJob, int UN = 8>
 __device__ __forceinline__ void sum_tiles_worker(const TileSum& p, int block, int nblocks, BETWEEN&& between = BETWEEN()) {
   if (!p.queue) {
-    for (int i = block; i < p.count; i += nblocks) sum_tile(p, p.tiles[i], threadIdx.x, blockDim.x);
+    for (int i = block; i < p.count; i += nblocks) sum_tile<UN>(p, p.tiles[i], threadIdx.x, blockDim.x);
     return;
   }
 #if !defined(RPSF_DEV_SUM_BLOCKING)
@@ -223,7 +224,7 @@ __device__ __forceinline__ void sum_tiles_worker(const TileSum& p, int block, in
     __syncthreads();
     if (tile == 0xffffffffu) return;
     if (tile == 0xfffffffeu) continue;
-    sum_tile(p, tile, threadIdx.x, blockDim.x, true);
+    sum_tile<UN>(p, tile, threadIdx.x, blockDim.x, true);
   }
 #else
   __shared__ uint32_t next;
@@ -233,7 +234,7 @@ __device__ __forceinline__ void sum_tiles_worker(const TileSum& p, int block, in
     const uint32_t i = next;
     __syncthreads();
     if (i >= (uint32_t)p.count) return;
-    sum_tile(p, sum_entry(p, i), threadIdx.x, blockDim.x);
+    sum_tile<UN>(p, sum_entry(p, i), threadIdx.x, blockDim.x);
   }
 #endif
 }

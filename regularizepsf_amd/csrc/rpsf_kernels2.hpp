@@ -141,12 +141,188 @@ struct ImagePrefetch {
 // HOT: the instantiation the persistent kernels are compiled from - a fused launch on colour planes whose geometry the launcher has
 // checked (hot_geometry, rpsf.hip): no float atomics, no direct mode, no pixel-by-pixel rim paths in the code (they cost the 256-pixel
 // kernel 29 spilled SGPRs and half of its 200 KB).  Everything else runs the one-patch-per-workgroup kernel patch_kernel2.
+
+#if defined(RPSF_DEV_WIDE)
+// ------------------------------------------------------------------------------------------------
+// Development: timing skeleton of a 1024-thread / 32-values-per-thread layout of the 256-pixel plan (Cfg256wide, patch_kernel2_256w):
+// 16 waves per CU, four per SIMD, 128 registers each.  Threads tu and tu + 512 both stand in for thread t = tu % 512 of Cfg256v2 and
+// each does HALF of its work with the same per-thread phase functions: the butterflies, twiddles and LDS exchanges of column parity 0
+// only (so two threads x one parity = the arithmetic and the LDS bytes of one thread x two parities), half of the pixel units, half
+// of the pair words (chunks of four words instead of eight: a quarter of the K registers), half of the stores - plus the 32 lane swaps
+// per direction that turn 16-byte global units into per-lane column parities in such a layout.  LDS holds one parity at a time
+// (128 KiB) as in the product, so the two halves of the workgroup (dup = tu / 512, wave-uniform) take turns in every exchange.
+// Same bytes, same arithmetic, same LDS traffic per patch; RESULTS ARE WRONG BY DESIGN.
+// ------------------------------------------------------------------------------------------------
+template <class C>
+__device__ __forceinline__ void wide_gather(int t, int dup, cf* v, const ImageView& im, int pr, int pc) {
+  ThreadPos2<C> tp(t);
+  // (rim patches: the skeleton reads a patch-sized block that lies inside the image)
+  const int prc = min(max(pr, im.row0), im.row0 + im.rows - C::N), pcc = min(max(pc, 0), im.W - C::N);
+  const float* base = im.img + (size_t)(prc - im.row0) * im.ld + pcc;
+  StaticFor<0, 8>::run([&]<int I>() RPSF_AI {
+    const int r = ((2 * I + dup) << (C::A2 + C::AL)) + tp.r_low;
+    StaticFor<0, 2>::run([&]<int C1>() RPSF_AI {
+      const int cp = (C1 << C::B2) + tp.c2;
+      const f32x4 q = *reinterpret_cast<const f32x4*>(base + (size_t)r * im.ld + 4 * cp);
+      v[2 * (4 * I + 2 * C1)] = cf{q.x, q.y};
+      v[2 * (4 * I + 2 * C1 + 1)] = cf{q.z, q.w};
+    });
+  });
+}
+// what re-sorting 16-byte units into per-lane column parities costs: one v_permlane32_swap per register pair
+template <class C>
+__device__ __forceinline__ void wide_swap(cf* v) {
+  StaticFor<0, 16>::run([&]<int I>() RPSF_AI {
+    auto sw = [](float& a, float& b) RPSF_AI {
+      const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+      a = __uint_as_float(r[0]), b = __uint_as_float(r[1]);
+    };
+    sw(v[2 * (2 * I)].x, v[2 * (2 * I + 1)].x);
+    sw(v[2 * (2 * I)].y, v[2 * (2 * I + 1)].y);
+  });
+}
+template <class C>
+__device__ __forceinline__ void wide_window(int t, int dup, cf* v, const float* __restrict__ win) {
+  ThreadPos2<C> tp(t);
+  StaticFor<0, 8>::run([&]<int I>() RPSF_AI {
+    const float wr = win[((2 * I + dup) << (C::A2 + C::AL)) + tp.r_low];
+    StaticFor<0, 2>::run([&]<int C1>() RPSF_AI {
+      const f32x4 w4 = *reinterpret_cast<const f32x4*>(win + 4 * ((C1 << C::B2) + tp.c2));
+      cf& a = v[2 * (4 * I + 2 * C1)];
+      cf& b = v[2 * (4 * I + 2 * C1 + 1)];
+      a = cf{a.x * (w4.x * wr), a.y * (w4.y * wr)};
+      b = cf{b.x * (w4.z * wr), b.y * (w4.w * wr)};
+    });
+  });
+}
+template <class C, class PSTORE4>
+__device__ __forceinline__ void wide_store(int t, int dup, const cf* v, const OutView& pv, int plane, int pr, int pc, const float* __restrict__ win,
+                                           PSTORE4&& pstore4) {
+  ThreadPos2<C> tp(t);
+  float* pbase = pv.out + (size_t)plane * pv.plane_stride;
+  StaticFor<0, 8>::run([&]<int I>() RPSF_AI {
+    const int r = ((2 * I + dup) << (C::A2 + C::AL)) + tp.r_low;
+    const float wr = win[r];
+    const int y = pr + r, yl = y - pv.row0;
+    const bool row_ok = y >= 0 && y < pv.H && yl >= 0 && yl < pv.rows;
+    StaticFor<0, 2>::run([&]<int C1>() RPSF_AI {
+      const int cp = (C1 << C::B2) + tp.c2, x = pc + 4 * cp;
+      if (row_ok && x >= 0 && x + 4 <= pv.W) {
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(win + 4 * cp);
+        const cf a = v[2 * (4 * I + 2 * C1)], b = v[2 * (4 * I + 2 * C1 + 1)];
+        pstore4(pbase + (size_t)yl * pv.ld + x, f32x4{a.x * (w4.x * wr), a.y * (w4.y * wr), b.x * (w4.z * wr), b.y * (w4.w * wr)});
+      }
+    });
+  });
+}
+template <class C, int CI>
+__device__ __forceinline__ void wide_load_k(int tu, cf* k, const cf* __restrict__ g) {
+  StaticFor<0, 4>::run([&]<int I>() RPSF_AI {
+#if defined(RPSF2_ABL_NOK)
+    k[2 * I] = cf{1.0f + (float)I, 0.5f};
+    k[2 * I + 1] = cf{0.25f, (float)tu};
+    return;
+#endif
+    load_stream16(g + ((size_t)(CI * 4 + I) * (2 * C::T) + tu) * 2, k[2 * I], k[2 * I + 1]);
+  });
+}
+// the transform of one patch: forward, pair words, inverse (v[2 j]: the 32 values of this thread)
+template <class C, class COUNT>
+__device__ __forceinline__ void wide_transform(int t, int tu, int dup, const GroupIds<C>& gids, cf* v, const cf* tw, cf* lds, const cf* g, COUNT&& count_previous) {
+  // ---- forward ----
+  ABL_VALU(stage1h<C, 0, false>(t, v, tw));
+  if (dup == 0) {
+    ABL_LDS(x1_write2<C, 0>(t, v, lds));
+    wave_lds_sync();
+    ABL_LDS(x1_read2<C, 0>(t, v, lds));
+  }
+  ABL_BAR();  // the X1 regions change hands
+  if (dup == 1) {
+    ABL_LDS(x1_write2<C, 0>(t, v, lds));
+    wave_lds_sync();
+    ABL_LDS(x1_read2<C, 0>(t, v, lds));
+  }
+  ABL_VALU(stage2h<C, 0, false>(t, v, tw));
+  cf k[8];
+  wide_load_k<C, 0>(tu, k, g);
+  ABL_BAR();  // every wave has left its X1 region
+  count_previous();
+  if (dup == 0) ABL_LDS(x2_mid_write2<C, 0>(t, v, lds));
+  ABL_BAR();
+  if (dup == 0) ABL_LDS(x2_last_read2<C, 0>(gids, v, lds));
+  ABL_BAR();
+  if (dup == 1) ABL_LDS(x2_mid_write2<C, 0>(t, v, lds));
+  if (dup == 0) ABL_VALU(stage3_rows<C, false, 0, 0>(t, gids, v));
+  ABL_BAR();
+  if (dup == 1) {
+    ABL_LDS(x2_last_read2<C, 0>(gids, v, lds));
+    ABL_VALU(stage3_rows<C, false, 0, 0>(t, gids, v));
+  }
+  // ---- frequency step: the 2-point column DFTs of 32 values, 16 pair words in chunks of 4 ----
+  ABL_VALU(fft_axis<1, 2, 16, 4, false, 0>(v));
+#if !defined(RPSF2_ABL_NOVALU)
+  {
+    int qa, ma;
+    gid_to_qm2<C>(gids[0], qa, ma);
+    const cf w0 = tw[ma], w1 = tw[ma + C::M];
+    StaticFor<0, 4>::run([&]<int CI>() RPSF_AI {
+      StaticFor<0, 4>::run([&]<int I>() RPSF_AI {
+        constexpr int EE = CI * 4 + I;
+        const PairOut o = pair_op(v[2 * EE], v[62 - 2 * EE], k[2 * I], k[2 * I + 1], (EE & 1) ? w1 : w0);
+        v[2 * EE] = o.a, v[62 - 2 * EE] = o.b;
+      });
+      if constexpr (CI + 1 < 4) wide_load_k<C, CI + 1>(tu, k, g);
+    });
+  }
+#else
+  StaticFor<1, 4>::run([&]<int CI>() RPSF_AI {
+    cf acc = k[0];
+    StaticFor<1, 8>::run([&]<int I>() RPSF_AI { acc = acc + k[I]; });
+    v[2 * CI] = v[2 * CI] + acc;
+    wide_load_k<C, CI>(tu, k, g);
+  });
+  v[0] = v[0] + k[0] + k[7];
+#endif
+  ABL_VALU(fft_axis<1, 2, 16, 4, true, 0>(v));
+  // ---- inverse ----
+  ABL_VALU(stage3_rows<C, true, 0, 0>(t, gids, v));
+  ABL_BAR();  // (the second half's forward reads are done)
+  if (dup == 0) ABL_LDS(x2_last_write2<C, 0>(gids, v, lds));
+  ABL_BAR();
+  if (dup == 0) ABL_LDS(x2_mid_read2<C, 0>(t, v, lds));
+  ABL_BAR();
+  if (dup == 1) ABL_LDS(x2_last_write2<C, 0>(gids, v, lds));
+  if (dup == 0) ABL_VALU(stage2h<C, 0, true>(t, v, tw));
+  ABL_BAR();
+  if (dup == 1) {
+    ABL_LDS(x2_mid_read2<C, 0>(t, v, lds));
+    ABL_VALU(stage2h<C, 0, true>(t, v, tw));
+  }
+  ABL_BAR();  // X1 regions alias the X2 image
+  if (dup == 0) {
+    ABL_LDS(x1_write2<C, 0>(t, v, lds));
+    wave_lds_sync();
+    ABL_LDS(x1_read2<C, 0>(t, v, lds));
+  }
+  ABL_BAR();
+  if (dup == 1) {
+    ABL_LDS(x1_write2<C, 0>(t, v, lds));
+    wave_lds_sync();
+    ABL_LDS(x1_read2<C, 0>(t, v, lds));
+  }
+  ABL_VALU(stage1h<C, 0, true>(t, v, tw));
+}
+#endif  // RPSF_DEV_WIDE
+
 template <class C, class REENTER, bool HOT = false>
 __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reenter) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int T = C::T, N = C::N;
   constexpr bool PERSIST = std::remove_reference_t<REENTER>::enabled;
-  const int t = threadIdx.x;
+  // (tu: the thread's id in the workgroup - protocol duties; t: the thread of the plan it computes as - the same except in the 1024-thread skeleton)
+  const int tu = threadIdx.x;
+  const int t = C::WIDE ? (tu & (T - 1)) : tu;
+  [[maybe_unused]] const int dup = C::WIDE ? tu / T : 0;
   // Fused plane sum: a few workgroups at the head of the grid sum finished tiles beside the patches for the whole
   // launch (the patches leave half of the HBM bandwidth unused), the ones at its tail take the CUs the partial last
   // round of patches leaves idle.  All of them draw tiles from one queue.
@@ -179,7 +355,7 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
         xrow = blk >> 3;
       } else if (!again) {
         unsigned* const word = reinterpret_cast<unsigned*>(reinterpret_cast<cf*>(smem + Launch2<C>::TABLE_FLOATS) + C::BUF_UNITS);
-        if (t == 0) *word = __hip_atomic_fetch_add(p.xq + (pb & 7) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.xq_base[pb & 7];
+        if (tu == 0) *word = __hip_atomic_fetch_add(p.xq + (pb & 7) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.xq_base[pb & 7];
         lds_barrier();
         xrow = (int)__builtin_amdgcn_readfirstlane(*word);
         if (xrow < 0 || xrow > 0x0fffffff) xrow = 0x0fffffff;  // (queue positions stay far below; keeps the frame arithmetic in range)
@@ -207,7 +383,7 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   cf* const park = lds + C::BUF_UNITS;
   // persistent form: the previous patch of this workgroup is counted on its tiles once its plane stores have drained
   [[maybe_unused]] auto count_previous = [&]() RPSF_AI {
-    if (t < (C::HALF ? 2 : 4)) __hip_atomic_fetch_add(p.tile_done + reinterpret_cast<const unsigned*>(park)[1 + t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tu < (C::HALF ? 2 : 4)) __hip_atomic_fetch_add(p.tile_done + reinterpret_cast<const unsigned*>(park)[1 + t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   if (!patchy) {
     if constexpr (PERSIST) {
@@ -221,12 +397,14 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
     if constexpr (PERSIST && C::T == 512) {
       if (!again && blk < p.sum_first) {  // a head summing workgroup: the image prefetch is its side job
         ImagePrefetch<C> prefetch(p, blk, p.prefetch && p.n_frames <= 1);
-        sum_tiles_worker(p.ts, 0, 1, prefetch);
+        sum_tiles_worker<ImagePrefetch<C>&, C::WIDE ? 4 : 8>(p.ts, 0, 1, prefetch);
         prefetch.finish();
         return;
       }
     }
 #endif
+    if constexpr (C::WIDE) sum_tiles_worker<NoSideJob, 4>(p.ts, 0, 1);
+    else
     sum_tiles_worker(p.ts, 0, 1);
     return;
   }
@@ -289,6 +467,10 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
 #pragma unroll
   for (int j = 0; j < 64; ++j) v[j] = cf{(float)(t + j), (float)(t - j)};
 #else
+#if defined(RPSF_DEV_WIDE)
+  if constexpr (C::WIDE) wide_gather<C>(t, dup, v, im, pr, pc);
+  else
+#endif
   load_raw2<C, HOT>(t, v, im, pr, pc, fast, maps);
 #endif
   if (!again) {
@@ -300,6 +482,21 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
 #if defined(RPSF_DEV_CARRY) || defined(RPSF_STAMPS)  // the workgroup's block index at dispatch, kept in an unused word of the bin-pair table
   if (PERSIST && !again && t == 0) ot[Launch2<C>::OT_WORDS - 1] = blockIdx.x & 0x3fffffffu;
 #endif
+#if defined(RPSF_DEV_WIDE)
+  if constexpr (C::WIDE) {
+    ABL_VALU(wide_swap<C>(v));
+    wide_window<C>(t, dup, v, win);
+    STAMP(1);
+    wide_transform<C>(t, tu, dup, gids, v, tw, lds, g, [&]() RPSF_AI {
+      if constexpr (PERSIST) {
+        if (again) count_previous();
+      }
+    });
+    ABL_VALU(wide_swap<C>(v));
+    STAMP(9);
+  }
+#endif
+  if constexpr (!C::WIDE) {
   window_patch2<C>(t, v, win);
 #if defined(RPSF_DEV_SKEW)  // development: the second wave of every SIMD (waves w and w + WAVES/2 share one) starts the barrier-free stage-1 / X1 region late,
                             // so that its butterflies fall under its partner's LDS bursts instead of competing with its butterflies
@@ -410,6 +607,7 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   ABL_LDS(x1_read2<C, 1>(t, v, lds));
   ABL_VALU(stage1h<C, 1, true>(t, v, tw));
   STAMP(9);
+  }  // !C::WIDE
   // ---- overlap-add ----
 #if defined(RPSF2_ABL_NOSTORE)
   if (!p.tile_done) {  // keep every value live but store (almost) nothing
@@ -453,13 +651,13 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
     // positions from xq_base[xcd] on, position 0 = slot 0
     unsigned drawn = 0, my_tile = 0;
     if constexpr (PERSIST) {
-      if (t < 4) {  // (and the tiles this patch will be counted on: a load behind the stores would wait for them)
+      if (tu < 4) {  // (and the tiles this patch will be counted on: a load behind the stores would wait for them)
         const uint4 q4 = p.quads[p.seq_base + seq];
-        if constexpr (C::HALF) my_tile = quad_tile(half ? (t == 0 ? q4.z : q4.w) : (t == 0 ? q4.x : q4.y));  // the two tiles under this half
+        if constexpr (C::HALF) my_tile = quad_tile(half ? (tu == 0 ? q4.z : q4.w) : (tu == 0 ? q4.x : q4.y));  // the two tiles under this half
         else
-        my_tile = (unsigned)frame * p.n_tiles + quad_tile(t == 0 ? q4.x : t == 1 ? q4.y : t == 2 ? q4.z : q4.w);  // (this frame's counters)
+        my_tile = (unsigned)frame * p.n_tiles + quad_tile(tu == 0 ? q4.x : tu == 1 ? q4.y : tu == 2 ? q4.z : q4.w);  // (this frame's counters)
       }
-      if (t == 0 && !head_patch)
+      if (tu == 0 && !head_patch)
         drawn = __hip_atomic_fetch_add(p.xq + (pb & 7) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.xq_base[pb & 7] +
                 (p.head_patches ? (unsigned)(p.sum_first >> 3) : 0u);
     }
@@ -492,6 +690,16 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
                             [=](float* a, f32x4 val) RPSF_AI { plane_store16_wt(rsrc, (size_t)(a - pbase), val); });
     } else
 #endif
+#if defined(RPSF_DEV_WIDE)
+    if constexpr (C::WIDE)
+      wide_store<C>(t, dup, v, ov, plane, pr, pc, win,
+#if defined(RPSF2_ABL_NOSTORE)
+                    [=](float* a, f32x4 val) RPSF_AI { asm volatile("" ::"v"(val.x), "v"(val.y), "v"(val.z), "v"(val.w), "v"(a)); });
+#else
+                    [=](float* a, f32x4 val) RPSF_AI { plane_store16_wt(rsrc, (size_t)(a - pbase), val); });
+#endif
+    else
+#endif
     store_patch2<C, HOT>(
         t, v, ov, ov, plane, pr, pc, win, nullptr, add, []<int R1, int C1>(const float* a) RPSF_AI { return *reinterpret_cast<const f32x4*>(a); },
         [](const float* a) { return *a; },
@@ -505,8 +713,8 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
     if constexpr (PERSIST) {
       // No drain here: the next patch's loads queue behind these stores anyway, and the patch is counted on its tiles from
       // inside the next pass (count_previous), when the stores are known to have been acknowledged.
-      if (t == 0) *reinterpret_cast<unsigned*>(park) = drawn;  // (park: idle since the frequency step)
-      if (t < 4) reinterpret_cast<unsigned*>(park)[1 + t] = my_tile;
+      if (tu == 0) *reinterpret_cast<unsigned*>(park) = drawn;  // (park: idle since the frequency step)
+      if (tu < 4) reinterpret_cast<unsigned*>(park)[1 + tu] = my_tile;
       lds_barrier();
       STAMP(12);
       const unsigned nx = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const unsigned*>(park));
@@ -515,7 +723,7 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
       const bool more = (int)nx < (left < p.chunk ? left : p.chunk) * (p.n_frames > 1 ? p.n_frames : 1) * (C::HALF ? 2 : 1);
       // (a head summing workgroup has had its patch: it re-enters under its own block index and sums from now on)
       reenter(0x40000000u | (head_patch ? (unsigned)blk : (unsigned)p.sum_first + (more ? ((nx << 3) | (unsigned)(pb & 7)) : (unsigned)p.patch_blocks)),
-              (unsigned)t);
+              (unsigned)tu);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
@@ -552,6 +760,9 @@ extern "C" __global__ __launch_bounds__(128, 2) void patch_kernel2_128p(PatchPar
 // Development: the split-patch timing skeleton (k2_256s.hip) - half patches (128 rows x 256 columns) on 256-thread workgroups, two per CU,
 // the same phases, K bytes, LDS traffic and plane stores per pixel as patch_kernel2_256p; results are wrong by design.
 extern "C" __global__ __launch_bounds__(256, 2) void patch_kernel2_256s(PatchParams p);
+#endif
+#if defined(RPSF_DEV_WIDE)
+extern "C" __global__ __launch_bounds__(1024, 4) void patch_kernel2_256w(PatchParams p);  // the 1024-thread timing skeleton (k2_256s.hip)
 #endif
 template <class C>
 struct PersistentKernel2;
