@@ -482,6 +482,29 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
 #if defined(RPSF_DEV_CARRY) || defined(RPSF_STAMPS)  // the workgroup's block index at dispatch, kept in an unused word of the bin-pair table
   if (PERSIST && !again && t == 0) ot[Launch2<C>::OT_WORDS - 1] = blockIdx.x & 0x3fffffffu;
 #endif
+  // Persistent launches: the next slot of this XCD's chunk (xq counters are never reset: this launch owns the positions from xq_base[xcd]
+  // on, position 0 = slot 0) and the tile this lane will count the patch on are requested in front of the plane stores and used behind
+  // them: the round trips - an atomic with return and a load, both in wave 0 - hide under the stores (VMEM returns in order: the values
+  // are back before the stores are acknowledged).
+  // (RPSF_DEV_EARLY_DRAW, development: requested right after the frequency step instead, a whole inverse transform ahead - measured
+  // round 4, profiles/r04e: 0.1924 vs 0.1919 ms, nothing; the "store phase" of the stamps is as long without any store, but it is not
+  // this wait either)
+#if defined(RPSF_DEV_EARLY_DRAW)
+  constexpr bool EARLY_DRAW = PERSIST && C::SPLIT_ROWS && !C::WIDE;
+#else
+  constexpr bool EARLY_DRAW = false;
+#endif
+  unsigned drawn = 0, qword = 0;  // (one register each: lane tu < 4 holds the word of its own tile)
+  [[maybe_unused]] auto draw_next = [&]() RPSF_AI {
+    if constexpr (PERSIST) {
+      if (HOT || p.tile_done) {
+        if (tu < (C::HALF ? 2 : 4)) qword = reinterpret_cast<const uint32_t*>(p.quads + (p.seq_base + seq))[C::HALF ? 2 * half + tu : tu];
+        if (tu == 0 && !head_patch)
+          drawn = __hip_atomic_fetch_add(p.xq + (pb & 7) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.xq_base[pb & 7] +
+                  (p.head_patches ? (unsigned)(p.sum_first >> 3) : 0u);
+      }
+    }
+  };
 #if defined(RPSF_DEV_WIDE)
   if constexpr (C::WIDE) {
     ABL_VALU(wide_swap<C>(v));
@@ -581,6 +604,7 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
 #endif
   if constexpr (C::SPLIT_ROWS) ABL_VALU(stage3_rows<C, true, 0, 0>(t, gids, v));
   STAMP(6);
+  if constexpr (EARLY_DRAW) draw_next();
   // ---- inverse ----
   ABL_LDS(x2_last_write2<C, 0>(gids, v, lds));
   if constexpr (C::SPLIT_ROWS) ABL_VALU(stage3_rows<C, true, 1, 0>(t, gids, v));
@@ -646,21 +670,7 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
     // counted on its four tiles; the workgroups behind the patches in the grid sum a tile as soon as its count is complete.
     const float* pbase = ov.out;
     const __amdgpu_buffer_rsrc_t rsrc = plane_rsrc(pbase);
-    // persistent: the next slot of this XCD's chunk, drawn now so that the round trip hides under the stores (VMEM returns
-    // in order: the value is back before the stores are acknowledged).  xq counters are never reset: this launch owns the
-    // positions from xq_base[xcd] on, position 0 = slot 0
-    unsigned drawn = 0, my_tile = 0;
-    if constexpr (PERSIST) {
-      if (tu < 4) {  // (and the tiles this patch will be counted on: a load behind the stores would wait for them)
-        const uint4 q4 = p.quads[p.seq_base + seq];
-        if constexpr (C::HALF) my_tile = quad_tile(half ? (tu == 0 ? q4.z : q4.w) : (tu == 0 ? q4.x : q4.y));  // the two tiles under this half
-        else
-        my_tile = (unsigned)frame * p.n_tiles + quad_tile(tu == 0 ? q4.x : tu == 1 ? q4.y : tu == 2 ? q4.z : q4.w);  // (this frame's counters)
-      }
-      if (tu == 0 && !head_patch)
-        drawn = __hip_atomic_fetch_add(p.xq + (pb & 7) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.xq_base[pb & 7] +
-                (p.head_patches ? (unsigned)(p.sum_first >> 3) : 0u);
-    }
+    if constexpr (!EARLY_DRAW) draw_next();
 #if defined(RPSF_DEV_CARRY)
     // timing experiment (results are wrong): the right half of every patch goes to the workgroup's private carry buffer, what the
     // previous patch left there is added to the left half, and only that reaches a colour plane (two planes, by lattice-row parity)
@@ -714,7 +724,7 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
       // No drain here: the next patch's loads queue behind these stores anyway, and the patch is counted on its tiles from
       // inside the next pass (count_previous), when the stores are known to have been acknowledged.
       if (tu == 0) *reinterpret_cast<unsigned*>(park) = drawn;  // (park: idle since the frequency step)
-      if (tu < 4) reinterpret_cast<unsigned*>(park)[1 + tu] = my_tile;
+      if (tu < 4) reinterpret_cast<unsigned*>(park)[1 + tu] = (unsigned)frame * p.n_tiles + quad_tile(qword);  // (this frame's counters)
       lds_barrier();
       STAMP(12);
       const unsigned nx = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const unsigned*>(park));

@@ -50,3 +50,10 @@ if (st[:, 14] > 0).all():  # entry stamp (kernel's first instructions of the pas
     print(f"workgroups {len(np.unique(st[:, 15]))}; end stamp -> entry stamp of the same workgroup's next pass (barrier, jump, first instruction fetch): "
           f"mean {gaps2.mean():.2f}  p10 {np.percentile(gaps2,10):.2f}  p50 {np.percentile(gaps2,50):.2f}  p90 {np.percentile(gaps2,90):.2f} us")
     print(f"period of a workgroup (start stamp to start stamp): mean {e2e.mean():.2f}  p10 {np.percentile(e2e,10):.2f}  p90 {np.percentile(e2e,90):.2f} us")
+# where the launch's time goes: the start of the first patch, the last patch's end and the kernel's own duration
+print(f"first start 0.0, median start of the first 240: {np.percentile(start[:240], 50):.1f} us, last patch end {end[-1]:.1f} us, kernel {ker[0]*1e3:.1f} us "
+      f"(launch -> first start and last end -> kernel end together: {ker[0]*1e3 - end[-1]:.1f} us)")
+per = np.array([np.sum((start >= lo) & (start < lo + 10)) for lo in range(0, int(end[-1]) + 10, 10)])
+print("patch starts per 10 us:", " ".join(str(int(x)) for x in per))
+pe = np.array([np.sum((end >= lo) & (end < lo + 10)) for lo in range(0, int(end[-1]) + 10, 10)])
+print("patch ends per 10 us:  ", " ".join(str(int(x)) for x in pe))
