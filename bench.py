@@ -259,6 +259,7 @@ def run_batch(args, rank, world, device, comm):
     if comm is not None:
         elapsed = comm.allreduce_max(elapsed)
     ms_per_step = 1e3 * elapsed / args.steps
+    timed_region_ms = 1e3 * elapsed
     iters = max(10, min(args.steps, 100))
     total_ms, kernel_ms = plan.apply_batch_device_timed(d_in.ptr, d_out.ptr, frames, stride, stride, geom, iters)
     kern_avg_ms = float(np.mean(kernel_ms))
@@ -290,7 +291,7 @@ def run_batch(args, rank, world, device, comm):
     line = {
         "metric": "corrected Mpixels/sec + fraction of HBM roofline, batch of 2048^2 frames / 128-patch, shared transfer array",
         "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_ms": args.prewarm_ms,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 4), "timed_region_ms": round(timed_region_ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {
             "workload": f"{frames} frames per GPU of {h}x{w} starfields, {n}x{n} patches ({len(coords)} per frame), one "
@@ -327,7 +328,11 @@ def main() -> None:
     ap.add_argument("--comm", choices=["rccl", "gloo"], default="rccl",
                     help="seam transport for N > 1; 'gloo' is a debug stand-in (host copies) used to exercise the "
                          "multi-rank flow on a box with fewer GPUs than ranks")
-    ap.add_argument("--verify", action="store_true", help="check every rank's owned rows against the CPU oracle")
+    ap.add_argument("--verify", action="store_true", default=None,
+                    help="check every rank's owned rows against the CPU oracle on one step outside the timed loops (default: on for N > 1)")
+    ap.add_argument("--no-verify", dest="verify", action="store_false")
+    ap.add_argument("--one-seam", action="store_true",
+                    help="N > 1: time only the --seam mode (default: the other seam mode is timed as a second leg in the same process)")
     ap.add_argument("--frames", type=int, default=8, help="config 5: frames per GPU in one batch")
     ap.add_argument("--rotate", type=int, default=1,
                     help="N = 1 only: this many DIFFERENT device-resident frames (and output buffers) are corrected in rotation.  "
@@ -361,6 +366,8 @@ def main() -> None:
         args.gpus = world
     if args.config is None:
         args.config = 3 if world == 1 or args.weak else 4
+    if args.verify is None:
+        args.verify = world > 1
 
     from oracle import regpsf_oracle as orc  # synthetic inputs + cpu_baseline only
     from regularizepsf_amd import _native
@@ -427,7 +434,6 @@ def main() -> None:
                 box = [None]
                 print(f"[bench] RCCL unavailable on rank 0 ({e})", file=sys.stderr, flush=True)
             dist.broadcast_object_list(box, src=0)
-            no_exchange = args.seam == "recompute" or args.config == 5  # no data-path collective: gloo can carry the barrier
             err = None
             if box[0] is not None:
                 try:
@@ -443,10 +449,9 @@ def main() -> None:
             if bad:
                 if comm is not None:
                     comm.close()
-                if not no_exchange:
-                    raise SystemExit("--seam exchange needs RCCL on every rank (" + "; ".join(bad) + ")")
-                if rank == 0:
-                    print(f"[bench] RCCL did not come up ({'; '.join(bad)}): barrier and max-reduction over gloo", file=sys.stderr, flush=True)
+                if rank == 0:  # (a box with fewer GPUs than ranks: RCCL refuses two ranks on one device)
+                    print(f"[bench] RCCL did not come up ({'; '.join(bad)}): barrier, max-reduction and seam rows over gloo (host copies)",
+                          file=sys.stderr, flush=True)
                 comm = GlooSeam(rank, world, device)
         else:
             comm = GlooSeam(rank, world, device)
@@ -454,6 +459,14 @@ def main() -> None:
         return run_batch(args, rank, world, device, comm)
     shard = ShardedApply(coords, kernel_for, n, height, w, rank, world, device, comm, pad_mode=pad, seam=args.seam,
                          overlap=not args.no_overlap)
+    # N > 1: BOTH seam modes run in this process - the --seam one is the headline (timed first), the other a second leg with its own
+    # plans, K and buffers - so that the first run on a real multi-GPU node exercises the RCCL send / recv of the halo rows AND the
+    # collective-free recompute, whichever of them is the default
+    other_seam = {"recompute": "exchange", "exchange": "recompute"}[args.seam]
+    shard2 = None
+    if world > 1 and not args.one_seam:
+        shard2 = ShardedApply(coords, kernel_for, n, height, w, rank, world, device, comm, pad_mode=pad, seam=other_seam,
+                              overlap=not args.no_overlap)
     band = shard.band
     band_image = image_rows(band.image_row0, band.image_row0 + band.image_rows)
     shard.upload_rows(band_image)
@@ -505,6 +518,51 @@ def main() -> None:
     if comm is not None:
         elapsed = comm.allreduce_max(elapsed)  # whole-job time = slowest rank
     ms_per_step = 1e3 * elapsed / args.steps
+    timed_region_ms = 1e3 * elapsed
+
+    def verify_owned_rows(sh, label):
+        """One step of `sh`, then every rank checks the rows it owns against the float64 oracle on the same inputs: the patches that
+        touch those rows on the image rows they read (a band's worth of work per rank, not the whole frame)."""
+        sh.step()
+        barrier()
+        b = sh.band
+        lo, hi = b.out_row0, b.out_row0 + b.own_rows
+        idx = [i for i, (r, _) in enumerate(coords) if r < hi and r + n > lo]
+        r_lo = max(0, min(coords[i][0] for i in idx))
+        r_hi = min(height, max(coords[i][0] for i in idx) + n)
+        # (cropping the image is exact: a patch hangs over the crop only where the crop edge is the image edge)
+        sub = image_rows(r_lo, r_hi)
+        ref = orc.apply_transfer(sub, [(coords[i][0] - r_lo, coords[i][1]) for i in idx], kernel_for(idx), workers=-1)
+        ref_own = ref[lo - r_lo:hi - r_lo]
+        own = sh.owned_rows().astype(np.float64)
+        scale = float(np.abs(ref).max())
+        err = float(np.abs(own - ref_own).max() / scale)
+        err2 = float(np.linalg.norm(own - ref_own) / np.linalg.norm(ref_own))
+        print(f"[verify] rank {rank} seam={label}: rows {lo}..{hi}, max|d|/max|ref| = {err:.3e}, rel L2 = {err2:.3e}", file=sys.stderr, flush=True)
+        worst = comm.allreduce_max(max(err, err2)) if comm is not None else max(err, err2)
+        if worst > 1e-5:
+            raise SystemExit(f"verification failed (seam={label}): {worst:.3e}")
+        return worst
+
+    verified = {}
+    if args.verify:
+        verified[args.seam if world > 1 else "single"] = verify_owned_rows(shard, args.seam if world > 1 else "single")
+
+    # ---------------- N > 1: the other seam mode, same steps, same barriers ----------------
+    other_ms = None
+    if shard2 is not None:
+        band2 = shard2.band
+        shard2.upload_rows(image_rows(band2.image_row0, band2.image_row0 + band2.image_rows))
+        for _ in range(max(args.warmup, 2)):
+            shard2.step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            shard2.step()
+        barrier()
+        other_ms = 1e3 * comm.allreduce_max(time.perf_counter() - t0) / args.steps
+        if args.verify:
+            verified[other_seam] = verify_owned_rows(shard2, other_seam)
 
     # ---------------- the same plan on a stream of NEW frames (N = 1): --new-frames different resident starfields and outputs in
     # rotation.  The headline loop above corrects ONE frame K times (SURVEY.md 8d's timed region); that frame and part of its colour
@@ -554,18 +612,12 @@ def main() -> None:
     achieved = alg_bytes / (step_ms * 1e-3) / 1e9
     achieved_kernel = alg_bytes / (kern_avg_ms * 1e-3) / 1e9
 
-    if args.verify:  # every rank checks the rows it owns against the float64 oracle on the same inputs
-        run_step()
-        barrier()
-        own = shard.owned_rows().astype(np.float64)
-        full_image = image_rows(0, height)
-        ref = orc.apply_transfer(full_image, coords, kernel_for(list(range(len(coords)))), workers=-1)
-        ref_own = ref[band.out_row0:band.out_row0 + band.own_rows]
-        err = float(np.abs(own - ref_own).max() / np.abs(ref).max())
-        print(f"[verify] rank {rank}: rows {band.out_row0}..{band.out_row0 + band.own_rows}, max|d|/max|ref| = {err:.3e}",
-              file=sys.stderr, flush=True)
-        if err > 1e-5:
-            raise SystemExit(f"verification failed on rank {rank}")
+    rccl_ranks = None
+    if comm is not None and not isinstance(comm, GlooSeam):
+        try:
+            rccl_ranks = comm.ranks()
+        except Exception as e:  # noqa: BLE001 - a diagnostic field must not take the run down
+            print(f"[bench] ncclCommCount: {e}", file=sys.stderr, flush=True)
     if comm is not None:  # orderly shutdown: nobody tears RCCL down while a peer is still in a collective
         import torch.distributed as dist
 
@@ -581,7 +633,8 @@ def main() -> None:
     line = {
         "metric": f"corrected Mpixels/sec + fraction of HBM roofline, {h1}^2 image / {n}-patch",
         "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_ms": args.prewarm_ms,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak",
+        "ms_per_step": round(ms_per_step, 4), "timed_region_ms": round(timed_region_ms, 3), "higher_is_better": True,
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
             "workload": f"{height}x{w} starfield, {n}x{n} patches, {len(coords)} patches "
@@ -605,6 +658,18 @@ def main() -> None:
             "apply_avg_ms_events": round(apply_avg_ms, 4), "patches_this_rank": my_patches,
         },
     }
+    if world > 1:  # both seam modes of this run (the headline is config.seam), the transport, and what RCCL says about its communicator
+        line["config"]["seam"] = args.seam
+        line["sync"] = "gloo" if isinstance(comm, GlooSeam) else "rccl"
+        line["rccl_ranks"] = rccl_ranks
+        line[f"scaling_{args.seam}_ms"] = round(ms_per_step, 4)
+        if other_ms is not None:
+            line[f"scaling_{other_seam}_ms"] = round(other_ms, 4)
+            line["seam_rows_transport"] = ("gloo (host copies: debugging stand-in)" if isinstance(comm, GlooSeam) else
+                                           "RCCL ncclSend / ncclRecv in the timed region")
+    if verified:
+        line["verify"] = {"max_error": max(verified.values()), "legs": sorted(verified), "bound": 1e-5,
+                          "what": "every rank's own output rows of one step against the float64 oracle (max|d|/max|ref| and relative L2)"}
     if new_frames_ms is not None:  # same bytes, same plan, every step a frame the caches have not seen for args.new_frames - 1 applies
         line["roofline"]["ms_per_step_new_frames"] = round(new_frames_ms, 4)
         line["roofline"]["frac_new_frames"] = round(alg_bytes / (new_frames_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)

@@ -219,6 +219,9 @@ int rpsf_comm_seam_exchange_add(rpsf_comm* comm, const void* send_dev, size_t se
 int rpsf_comm_seam_exchange(rpsf_comm* comm, const void* send_dev, size_t send_count, void* recv_dev, size_t recv_count,
                             void* stream);
 void* rpsf_comm_stream(rpsf_comm* comm);
+/* The number of ranks RCCL reports for the communicator (ncclCommCount) - evidence for a harness that the seam exchange
+ * spans the GPUs it was launched on. */
+int rpsf_comm_ranks(rpsf_comm* comm, int* ranks);
 /* Make `waiter` (a hipStream_t) wait for everything enqueued on `signaller` so far. */
 int rpsf_stream_wait(int device, void* waiter, void* signaller);
 /* accum_dev[0:count] += src_dev[0:count] (float32, on `device`, asynchronous on stream): the add of the seam

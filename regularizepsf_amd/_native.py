@@ -89,6 +89,7 @@ _PROTOTYPES = {
     "rpsf_comm_seam_exchange_add": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p]),
     "rpsf_comm_seam_exchange": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]),
     "rpsf_comm_stream": (c_void_p, [c_void_p]),
+    "rpsf_comm_ranks": (c_int, [c_void_p, POINTER(ctypes.c_int)]),
     "rpsf_stream_wait": (c_int, [c_int, c_void_p, c_void_p]),
     "rpsf_add_rows": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rpsf_comm_barrier": (c_int, [c_void_p, c_void_p]),
@@ -421,6 +422,12 @@ class Comm:
 
     def barrier(self, stream=None) -> None:
         check(lib().rpsf_comm_barrier(self._handle, stream))
+
+    def ranks(self) -> int:
+        """The rank count RCCL itself reports for this communicator (ncclCommCount)."""
+        n = ctypes.c_int(0)
+        check(lib().rpsf_comm_ranks(self._handle, ctypes.byref(n)))
+        return int(n.value)
 
     def allreduce_max(self, value: float) -> float:
         v = c_double(value)

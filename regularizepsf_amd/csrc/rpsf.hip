@@ -1750,6 +1750,7 @@ typedef int (*fn_recv)(void*, size_t, int, int, void*, hipStream_t);
 typedef int (*fn_group)(void);
 typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
 typedef const char* (*fn_errstr)(int);
+typedef int (*fn_comm_count)(void*, int*);
 
 static struct {
   void* h;
@@ -1761,6 +1762,7 @@ static struct {
   fn_group group_start, group_end;
   fn_allreduce allreduce;
   fn_errstr errstr;
+  fn_comm_count comm_count;
 } g_rccl;
 
 static int load_rccl() {
@@ -1783,6 +1785,7 @@ static int load_rccl() {
   g_rccl.group_end = (fn_group)dlsym(h, "ncclGroupEnd");
   g_rccl.allreduce = (fn_allreduce)dlsym(h, "ncclAllReduce");
   g_rccl.errstr = (fn_errstr)dlsym(h, "ncclGetErrorString");
+  g_rccl.comm_count = (fn_comm_count)dlsym(h, "ncclCommCount");
   if (!g_rccl.get_uid || !g_rccl.comm_init || !g_rccl.comm_destroy || !g_rccl.send || !g_rccl.recv ||
       !g_rccl.group_start || !g_rccl.group_end || !g_rccl.allreduce)
     return fail(RPSF_E_RCCL, "librccl is missing expected symbols");
@@ -1880,6 +1883,15 @@ extern "C" int rpsf_comm_seam_exchange(rpsf_comm* c, const void* send_dev, size_
   return RPSF_OK;
 }
 extern "C" void* rpsf_comm_stream(rpsf_comm* c) { return c ? (void*)c->stream : nullptr; }
+
+// How many ranks RCCL itself counts in the communicator (ncclCommCount): what a harness prints next to its timings to show that the
+// collective path really spans the GPUs it was launched on
+extern "C" int rpsf_comm_ranks(rpsf_comm* c, int* ranks) {
+  if (!c || !ranks) return fail(RPSF_E_BADARG, "null argument");
+  if (!g_rccl.comm_count) return fail(RPSF_E_RCCL, "librccl has no ncclCommCount");
+  NCCL_TRY(g_rccl.comm_count(c->comm, ranks));
+  return RPSF_OK;
+}
 
 // Work enqueued on `waiter` after this call starts only when everything enqueued on `signaller` so far has finished
 extern "C" int rpsf_stream_wait(int device, void* waiter, void* signaller) {

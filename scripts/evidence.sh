@@ -1,8 +1,15 @@
 #!/bin/bash
-# run on the GPU box from the repo root
-R=${1:-r02}
+# run on the GPU box from the repo root:  scripts/evidence.sh r04zz
+# Order matters: the PMC passes come first and refresh profiles/traffic_latest.json, so that the bench lines written afterwards cite THIS set
+# as their traffic_source (round 3's cited the set before).
+R=${1:-r04}
 mkdir -p gpurun_out/$R
+REPO=$(pwd)
 python -m pytest tests -m gpu -x -q > gpurun_out/$R/pytest_gpu.log 2>&1; tail -2 gpurun_out/$R/pytest_gpu.log
+bash scripts/pmc_passes.sh gpurun_out/$R/pmc -- python3 $REPO/bench.py --steps 10 --warmup 2 --no-cpu --new-frames 0 > gpurun_out/$R/pmc.log 2>&1
+cp gpurun_out/$R/pmc/summary.txt gpurun_out/$R/bench_pmc_summary.txt; head -30 gpurun_out/$R/bench_pmc_summary.txt
+python3 scripts/traffic.py gpurun_out/$R/bench_pmc_summary.txt "profiles/${R}_bench_pmc_summary.txt" > gpurun_out/$R/traffic.json; cat gpurun_out/$R/traffic.json
+cp gpurun_out/$R/traffic.json profiles/traffic_latest.json
 python bench.py --steps 50 --warmup 5 > gpurun_out/$R/bench.json 2> gpurun_out/$R/bench.err; cat gpurun_out/$R/bench.json | cut -c1-300
 python bench.py --config 2 --steps 50 --warmup 5 > gpurun_out/$R/bench_config2.json 2>/dev/null
 python bench.py --config 4 --steps 20 --warmup 3 > gpurun_out/$R/bench_config4_8192.json 2>/dev/null
@@ -11,11 +18,7 @@ python bench.py --config 1 --steps 50 --warmup 5 --new-frames 0 > gpurun_out/$R/
 for f in config1 config2 config4_8192 config5_batch; do cut -c1-200 gpurun_out/$R/bench_$f.json; done
 python scripts/band_times.py --steps 40 --seam recompute > gpurun_out/$R/band_times_recompute.log 2>&1; tail -1 gpurun_out/$R/band_times_recompute.log | cut -c1-300
 python scripts/band_times.py --steps 40 --seam exchange --worlds 1,8 > gpurun_out/$R/band_times_exchange.log 2>&1; tail -1 gpurun_out/$R/band_times_exchange.log | cut -c1-300
-REPO=$(pwd)
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/$R/stats -- python3 $REPO/bench.py --steps 100 --warmup 5 --no-cpu --new-frames 0 > $REPO/gpurun_out/$R/stats.log 2>&1)
 find gpurun_out/$R/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/$R/bench_kernel_stats.csv
 head -4 gpurun_out/$R/bench_kernel_stats.csv
-bash scripts/pmc_passes.sh gpurun_out/$R/pmc -- python3 $REPO/bench.py --steps 10 --warmup 2 --no-cpu --new-frames 0 > gpurun_out/$R/pmc.log 2>&1
-cp gpurun_out/$R/pmc/summary.txt gpurun_out/$R/bench_pmc_summary.txt; head -30 gpurun_out/$R/bench_pmc_summary.txt
-python3 scripts/traffic.py gpurun_out/$R/bench_pmc_summary.txt "profiles/${R}_bench_pmc_summary.txt" > gpurun_out/$R/traffic.json; cat gpurun_out/$R/traffic.json
 rm -rf gpurun_out/$R/stats gpurun_out/$R/pmc/pass*
