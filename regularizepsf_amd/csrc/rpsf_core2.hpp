@@ -430,6 +430,21 @@ RPSF_HD void freq_b(int t, const GroupIds<C>& gids, cf* v, cf* k, const cf* __re
   });
 }
 
+// Two K chunks in flight (development, RPSF_KDEPTH2; SPLIT_ROWS plans only: one slot per thread): k0 holds chunk 0 and k1 chunk 1 on entry; each later
+// chunk is requested into the buffer its predecessor-but-one has just freed, one chunk of pair words ahead of its use.
+template <class C>
+RPSF_HD void freq_b_depth2(int t, const GroupIds<C>& gids, cf* v, cf* k0, cf* k1, const cf* __restrict__ g, const cf* __restrict__ tw, const cf* park) {
+  static_assert(C::SPLIT_ROWS && C::NCHUNK == 4, "one slot, four chunks");
+  pair_words<C, 0, 0 * C::KCH, C::KCH>(gids, v, k0, tw);
+  load_k_chunk2<C, 2>(t, k0, g);
+  pair_words<C, 0, 1 * C::KCH, C::KCH>(gids, v, k1, tw);
+  load_k_chunk2<C, 3>(t, k1, g);
+  pair_words<C, 0, 2 * C::KCH, C::KCH>(gids, v, k0, tw);
+  pair_words<C, 0, 3 * C::KCH, C::KCH>(gids, v, k1, tw);
+  if (t < 64) self_unpark<C>(t, v, park);
+  stage3_cols<C, true, 0>(v);
+}
+
 // K staged through the exchange buffer (RPSF_KSTAGE2): the buffer is idle between the last forward and the first inverse exchange,
 // so the pair words of chunks 1 and 2 (2 x KCH words per thread: 128 KiB at N = 256) are requested by LDS-DMA as soon as the last
 // forward read is done - no registers needed for data in flight - and chunk 3 takes the registers chunk 0 frees.  One deep request

@@ -598,6 +598,10 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
 #if defined(RPSF_KSTAGE2)
   freq_b_staged<C>(t, gids, v, k, g, tw, park, lds);
   ABL_BAR();  // every staged word has been used: the inverse exchange may overwrite the buffer
+#elif defined(RPSF_KDEPTH2)  // development: two chunks of pair words in flight from here on (requested any earlier, the allocator spills 56 registers)
+  cf k1[2 * C::KCH];
+  load_k_chunk2<C, 1>(t, k1, g);
+  freq_b_depth2<C>(t, gids, v, k, k1, g, tw, park);
 #else
   freq_b<C>(t, gids, v, k, g, tw, park);
 #endif
