@@ -590,8 +590,13 @@ extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int
     set_corner_extremes(p);
     HIP_TRY(hipMalloc(&p->d_sink, 128 * sizeof(float)));
 #if defined(RPSF_STAMPS)
-    HIP_TRY(hipMalloc(&p->d_stamps, sizeof(unsigned long long) * 16 * (size_t)n_patches));
-    HIP_TRY(hipMemset(p->d_stamps, 0, sizeof(unsigned long long) * 16 * (size_t)n_patches));
+#if defined(RPSF_WAVE_STAMPS)
+    constexpr size_t STAMP_WAVES = 8;
+#else
+    constexpr size_t STAMP_WAVES = 1;
+#endif
+    HIP_TRY(hipMalloc(&p->d_stamps, sizeof(unsigned long long) * 16 * STAMP_WAVES * (size_t)n_patches));
+    HIP_TRY(hipMemset(p->d_stamps, 0, sizeof(unsigned long long) * 16 * STAMP_WAVES * (size_t)n_patches));
 #endif
     p->v2 = has_v2(N);
     p->no_fuse = std::getenv("RPSF_NO_FUSE") != nullptr;
@@ -1252,7 +1257,11 @@ extern "C" int rpsf_plan_debug_stamps(rpsf_plan* p, unsigned long long* host, si
   if (!p->d_stamps) return fail(RPSF_E_STATE, "phase timestamps exist only in builds with -DRPSF_STAMPS");
   HIP_TRY(hipSetDevice(p->device));
   HIP_TRY(hipDeviceSynchronize());
+#if defined(RPSF_WAVE_STAMPS)
+  count = std::min(count, (size_t)16 * 8 * p->n_patches);
+#else
   count = std::min(count, (size_t)16 * p->n_patches);
+#endif
   HIP_TRY(hipMemcpy(host, p->d_stamps, count * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return RPSF_OK;
 }

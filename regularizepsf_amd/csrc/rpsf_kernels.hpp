@@ -313,7 +313,12 @@ struct Launch {
 __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-#if defined(RPSF_STAMPS)
+#if defined(RPSF_WAVE_STAMPS)  // diagnostic: lane 0 of EVERY wave (up to 8 per patch) stamps - scripts/dev_wave_stamps.py
+#define STAMP(i)                                                                                                                              \
+  do {                                                                                                                                        \
+    if ((threadIdx.x & 63) == 0) p.stamps[((size_t)patch * 8 + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_amdgcn_s_memrealtime();             \
+  } while (0)
+#elif defined(RPSF_STAMPS)
 #define STAMP(i)                                                                                         \
   do {                                                                                                   \
     if (threadIdx.x == 0) p.stamps[(size_t)patch * 16 + (i)] = __builtin_amdgcn_s_memrealtime();          \

@@ -528,6 +528,9 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   if (C::WAVES >= 2 && t >= C::T / 2) __builtin_amdgcn_s_sleep(RPSF_DEV_SKEW);
 #endif
   STAMP(1);
+#if defined(RPSF_DEV_PRIO_HEAD)  // development: the same for the barrier-free head of a pass (stage 1 and the first X1)
+  if (C::WAVES >= 2 && t >= C::T / 2) __builtin_amdgcn_s_setprio(1);
+#endif
   // ---- forward: the halves leapfrog through stage 1, X1 (wave-local) and stage 2 ----
   ABL_VALU(stage1h<C, 0, false>(t, v, tw));
   ABL_LDS(x1_write2<C, 0>(t, v, lds));
@@ -536,6 +539,9 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   ABL_LDS(x1_read2<C, 0>(t, v, lds));
   ABL_LDS(x1_write2<C, 1>(t, v, lds));  // (a wave's DS operations complete in order: these writes cannot overtake the reads)
   STAMP(2);
+#if defined(RPSF_DEV_PRIO_HEAD)
+  if (C::WAVES >= 2) __builtin_amdgcn_s_setprio(0);
+#endif
   ABL_VALU(stage2h<C, 0, false>(t, v, tw));
   wave_lds_sync();
   ABL_LDS(x1_read2<C, 1>(t, v, lds));
@@ -626,17 +632,27 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   if (C::WAVES >= 2 && t >= C::T / 2) __builtin_amdgcn_s_sleep(RPSF_DEV_SKEW);
 #endif
   STAMP(7);
+#if defined(RPSF_DEV_PRIO_TAIL)  // development: the second wave of every SIMD (waves WAVES/2 ...) gets the issue priority behind the last barrier of a pass,
+                                // until stamp 8 (1), 9 (2) or the end of the stores (3): age-based arbitration lets it fall 2 us behind there (profiles/r04i)
+  if (C::WAVES >= 2 && t >= C::T / 2) __builtin_amdgcn_s_setprio(1);
+#endif
   ABL_LDS(x1_write2<C, 0>(t, v, lds));
   ABL_VALU(stage2h<C, 1, true>(t, v, tw));
   wave_lds_sync();
   ABL_LDS(x1_read2<C, 0>(t, v, lds));
   ABL_LDS(x1_write2<C, 1>(t, v, lds));
   STAMP(8);
+#if defined(RPSF_DEV_PRIO_TAIL)
+  if (RPSF_DEV_PRIO_TAIL == 1 && C::WAVES >= 2) __builtin_amdgcn_s_setprio(0);
+#endif
   ABL_VALU(stage1h<C, 0, true>(t, v, tw));
   wave_lds_sync();
   ABL_LDS(x1_read2<C, 1>(t, v, lds));
   ABL_VALU(stage1h<C, 1, true>(t, v, tw));
   STAMP(9);
+#if defined(RPSF_DEV_PRIO_TAIL)
+  if (RPSF_DEV_PRIO_TAIL == 2 && C::WAVES >= 2) __builtin_amdgcn_s_setprio(0);
+#endif
   }  // !C::WIDE
   // ---- overlap-add ----
 #if defined(RPSF2_ABL_NOSTORE)
@@ -726,6 +742,9 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
 #endif
         [](float* a, float val) RPSF_AI { __hip_atomic_store(reinterpret_cast<unsigned*>(a), __float_as_uint(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); });
     STAMP(10);
+#if defined(RPSF_DEV_PRIO_TAIL)
+    if (RPSF_DEV_PRIO_TAIL == 3 && C::WAVES >= 2) __builtin_amdgcn_s_setprio(0);
+#endif
     if constexpr (PERSIST) {
       // No drain here: the next patch's loads queue behind these stores anyway, and the patch is counted on its tiles from
       // inside the next pass (count_previous), when the stores are known to have been acknowledged.

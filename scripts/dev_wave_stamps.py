@@ -1,5 +1,6 @@
-"""Development aid: per-wave phase timing of the N=256 patch kernel.  Needs a diagnostic library in which STAMP()
-records lane 0 of every wave at ((patch * 8 + wave) * 16 + i) and the stamp buffer is 8x larger."""
+"""Development aid: per-wave phase timing of the N=256 patch kernel.  Needs a library built with -DRPSF_STAMPS -DRPSF_WAVE_STAMPS: STAMP()
+records lane 0 of every wave at ((patch * 8 + wave) * 16 + i) and the stamp buffer is 8x larger.
+    RPSF_LIB=devlibs/wave_stamps.so python scripts/dev_wave_stamps.py"""
 import ctypes, pathlib, sys
 import numpy as np
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
@@ -18,7 +19,7 @@ tot, ker = plan.apply_device_timed(d_img.ptr, d_out.ptr, geom, 1)
 out = np.zeros(len(coords) * 8 * 16, np.uint64)
 _native.check(_native.lib().rpsf_plan_debug_stamps(plan._handle, out.ctypes.data_as(ctypes.c_void_p), out.size))
 st = out.reshape(len(coords), 8, 16).astype(np.int64)
-names = ["load", "stage1", "X1", "stage2", "X2", "-", "-", "freq", "X2'", "stage2'", "X1'", "stage1'", "store"]
+names = ["gather", "S1+X1", "S2h0", "X2fwd", "freq_a", "freq_b", "X2inv", "X1inv", "S1inv", "stores", "-", "drain", "-"]  # second-generation kernel's stamps 0 .. 12
 print(f"kernel {ker[0]*1e3:.1f} us")
 t0 = st[:, :, 0].min(axis=1, keepdims=True)
 rel = (st[:, :, :14] - t0[:, :, None]) * 0.01
