@@ -143,9 +143,9 @@ def build(force: bool = False, verbose: bool = True, defines: tuple[str, ...] = 
         objs = list(pool.map(compile_one, SOURCES))
     check_reentry_contract(next(o for o in objs if o.stem == "k2_256p"), "patch_kernel2_256p")
     check_reentry_contract(next(o for o in objs if o.stem == "k2_128p"), "patch_kernel2_128p")
-    if "-DRPSF_DEV_SPLIT" in defines:
+    if any(d.startswith("-DRPSF_DEV_SPLIT") for d in defines):
         check_reentry_contract(next(o for o in objs if o.stem == "k2_256s"), "patch_kernel2_256s")
-    if "-DRPSF_DEV_WIDE" in defines:
+    if any(d.startswith("-DRPSF_DEV_WIDE") for d in defines):
         check_reentry_contract(next(o for o in objs if o.stem == "k2_256s"), "patch_kernel2_256w")
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(out), *[str(o) for o in objs], "-ldl"]
     if verbose:

@@ -312,6 +312,80 @@ __device__ __forceinline__ void wide_transform(int t, int tu, int dup, const Gro
   }
   ABL_VALU(stage1h<C, 0, true>(t, v, tw));
 }
+
+// ... and the same work as a PING-PONG between the two halves of the workgroup (RPSF_DEV_WIDE=2): in every segment between two workgroup barriers one
+// half (8 waves, two per SIMD: the SIMD's full issue rate) runs a stage's arithmetic while the other half moves its values through LDS, then they
+// swap - arithmetic beside LDS traffic by construction, which the lock-step kernels only get where the column-parity halves leapfrog.
+template <class C, int PART>
+__device__ __forceinline__ void wide_freq(int t, int tu, const GroupIds<C>& gids, cf* v, cf* k, const cf* tw, const cf* g) {
+  if constexpr (PART == 0) {
+    ABL_VALU(stage3_rows<C, false, 0, 0>(t, gids, v));
+    ABL_VALU(fft_axis<1, 2, 16, 4, false, 0>(v));
+  }
+#if !defined(RPSF2_ABL_NOVALU)
+  int qa, ma;
+  gid_to_qm2<C>(gids[0], qa, ma);
+  const cf w0 = tw[ma], w1 = tw[ma + C::M];
+  StaticFor<2 * PART, 2 * PART + 2>::run([&]<int CI>() RPSF_AI {
+    StaticFor<0, 4>::run([&]<int I>() RPSF_AI {
+      constexpr int EE = CI * 4 + I;
+      const PairOut o = pair_op(v[2 * EE], v[62 - 2 * EE], k[2 * I], k[2 * I + 1], (EE & 1) ? w1 : w0);
+      v[2 * EE] = o.a, v[62 - 2 * EE] = o.b;
+    });
+    if constexpr (CI + 1 < 4) wide_load_k<C, CI + 1>(tu, k, g);
+  });
+#else
+  StaticFor<2 * PART, 2 * PART + 2>::run([&]<int CI>() RPSF_AI {
+    cf acc = k[0];
+    StaticFor<1, 8>::run([&]<int I>() RPSF_AI { acc = acc + k[I]; });
+    v[2 * CI] = v[2 * CI] + acc;
+    if constexpr (CI + 1 < 4) wide_load_k<C, CI + 1>(tu, k, g);
+  });
+#endif
+  if constexpr (PART == 1) {
+    ABL_VALU(fft_axis<1, 2, 16, 4, true, 0>(v));
+    ABL_VALU(stage3_rows<C, true, 0, 0>(t, gids, v));
+  }
+}
+template <class C, class COUNT>
+__device__ __forceinline__ void wide_transform_pp(int t, int tu, int dup, const GroupIds<C>& gids, cf* v, const cf* tw, cf* lds, const cf* g, COUNT&& count_previous) {
+  // ONE code path for both halves, the second half one segment behind the first: a segment is a stage's arithmetic (V) or an exchange (L), they alternate
+  // strictly - S1 | X1 | S2 | X2 | F | X2' | S2' | X1' | S1' - and every segment carries two workgroup barriers (middle and end: the X2 exchanges need the one
+  // in the middle, the others keep step), so that while one half is in an L segment the other is in the V segment next to it, and LDS holds one half at a time.
+  cf k[8];
+  if (dup == 1) { ABL_BAR(); ABL_BAR(); }
+  ABL_VALU(stage1h<C, 0, false>(t, v, tw));
+  ABL_BAR(); ABL_BAR();
+  ABL_LDS(x1_write2<C, 0>(t, v, lds));
+  ABL_BAR();
+  ABL_LDS(x1_read2<C, 0>(t, v, lds));
+  ABL_BAR();
+  ABL_VALU(stage2h<C, 0, false>(t, v, tw));
+  wide_load_k<C, 0>(tu, k, g);
+  ABL_BAR();
+  count_previous();
+  ABL_BAR();
+  ABL_LDS(x2_mid_write2<C, 0>(t, v, lds));
+  ABL_BAR();
+  ABL_LDS(x2_last_read2<C, 0>(gids, v, lds));
+  ABL_BAR();
+  wide_freq<C, 0>(t, tu, gids, v, k, tw, g);
+  ABL_BAR();
+  wide_freq<C, 1>(t, tu, gids, v, k, tw, g);
+  ABL_BAR();
+  ABL_LDS(x2_last_write2<C, 0>(gids, v, lds));
+  ABL_BAR();
+  ABL_LDS(x2_mid_read2<C, 0>(t, v, lds));
+  ABL_BAR();
+  ABL_VALU(stage2h<C, 0, true>(t, v, tw));
+  ABL_BAR(); ABL_BAR();
+  ABL_LDS(x1_write2<C, 0>(t, v, lds));
+  ABL_BAR();
+  ABL_LDS(x1_read2<C, 0>(t, v, lds));
+  ABL_BAR();
+  ABL_VALU(stage1h<C, 0, true>(t, v, tw));
+  // (the first half owes two barriers: it pays them behind its stores, which so run beside the second half's last stage - patch_body2)
+}
 #endif  // RPSF_DEV_WIDE
 
 template <class C, class REENTER, bool HOT = false>
@@ -322,7 +396,7 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   // (tu: the thread's id in the workgroup - protocol duties; t: the thread of the plan it computes as - the same except in the 1024-thread skeleton)
   const int tu = threadIdx.x;
   const int t = C::WIDE ? (tu & (T - 1)) : tu;
-  [[maybe_unused]] const int dup = C::WIDE ? tu / T : 0;
+  [[maybe_unused]] const int dup = C::WIDE ? (int)__builtin_amdgcn_readfirstlane((unsigned)(tu / T)) : 0;  // (wave-uniform: a scalar branch condition)
   // Fused plane sum: a few workgroups at the head of the grid sum finished tiles beside the patches for the whole
   // launch (the patches leave half of the HBM bandwidth unused), the ones at its tail take the CUs the partial last
   // round of patches leaves idle.  All of them draw tiles from one queue.
@@ -512,7 +586,11 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
     ABL_VALU(wide_swap<C>(v));
     wide_window<C>(t, dup, v, win);
     STAMP(1);
+#if RPSF_DEV_WIDE >= 2
+    wide_transform_pp<C>(t, tu, dup, gids, v, tw, lds, g, [&]() RPSF_AI {
+#else
     wide_transform<C>(t, tu, dup, gids, v, tw, lds, g, [&]() RPSF_AI {
+#endif
       if constexpr (PERSIST) {
         if (again) count_previous();
       }
@@ -741,6 +819,11 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
         [=](float* a, f32x4 val) RPSF_AI { plane_store16_wt(rsrc, (size_t)(a - pbase), val); },
 #endif
         [](float* a, float val) RPSF_AI { __hip_atomic_store(reinterpret_cast<unsigned*>(a), __float_as_uint(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); });
+#if defined(RPSF_DEV_WIDE) && RPSF_DEV_WIDE >= 2
+    if constexpr (C::WIDE) {
+      if (dup == 0) { ABL_BAR(); ABL_BAR(); }
+    }
+#endif
     STAMP(10);
 #if defined(RPSF_DEV_PRIO_TAIL)
     if (RPSF_DEV_PRIO_TAIL == 3 && C::WAVES >= 2) __builtin_amdgcn_s_setprio(0);
