@@ -435,10 +435,20 @@ RPSF_HD void freq_b(int t, const GroupIds<C>& gids, cf* v, cf* k, const cf* __re
 template <class C>
 RPSF_HD void freq_b_depth2(int t, const GroupIds<C>& gids, cf* v, cf* k0, cf* k1, const cf* __restrict__ g, const cf* __restrict__ tw, const cf* park) {
   static_assert(C::SPLIT_ROWS && C::NCHUNK == 4, "one slot, four chunks");
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RPSF_PIN() __builtin_amdgcn_sched_barrier(0)  // (the scheduler otherwise sinks a chunk's loads below the pair words in front of them)
+#else
+#define RPSF_PIN() ((void)0)
+#endif
+  RPSF_PIN();
   pair_words<C, 0, 0 * C::KCH, C::KCH>(gids, v, k0, tw);
+  RPSF_PIN();
   load_k_chunk2<C, 2>(t, k0, g);
+  RPSF_PIN();
   pair_words<C, 0, 1 * C::KCH, C::KCH>(gids, v, k1, tw);
+  RPSF_PIN();
   load_k_chunk2<C, 3>(t, k1, g);
+  RPSF_PIN();
   pair_words<C, 0, 2 * C::KCH, C::KCH>(gids, v, k0, tw);
   pair_words<C, 0, 3 * C::KCH, C::KCH>(gids, v, k1, tw);
   if (t < 64) self_unpark<C>(t, v, park);

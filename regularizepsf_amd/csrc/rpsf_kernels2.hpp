@@ -694,6 +694,15 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
 #endif
   if constexpr (C::SPLIT_ROWS) ABL_VALU(stage3_rows<C, true, 0, 0>(t, gids, v));
   STAMP(6);
+#if defined(RPSF_DEV_SLEEP_ALL)  // development, sensitivity of the apply to the length of a patch's chain: every wave / only wave 0 / all but wave 0 naps here (units of 64 cycles)
+  __builtin_amdgcn_s_sleep(RPSF_DEV_SLEEP_ALL);
+#endif
+#if defined(RPSF_DEV_SLEEP_W0)
+  if (t < 64) __builtin_amdgcn_s_sleep(RPSF_DEV_SLEEP_W0);
+#endif
+#if defined(RPSF_DEV_SLEEP_REST)
+  if (t >= 64) __builtin_amdgcn_s_sleep(RPSF_DEV_SLEEP_REST);
+#endif
   if constexpr (EARLY_DRAW) draw_next();
   // ---- inverse ----
   ABL_LDS(x2_last_write2<C, 0>(gids, v, lds));
