@@ -559,16 +559,18 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   if (PERSIST && !again && t == 0) ot[Launch2<C>::OT_WORDS - 1] = blockIdx.x & 0x3fffffffu;
 #endif
   // Persistent launches: the next slot of this XCD's chunk (xq counters are never reset: this launch owns the positions from xq_base[xcd]
-  // on, position 0 = slot 0) and the tile this lane will count the patch on are requested in front of the plane stores and used behind
-  // them: the round trips - an atomic with return and a load, both in wave 0 - hide under the stores (VMEM returns in order: the values
-  // are back before the stores are acknowledged).
-  // (RPSF_DEV_EARLY_DRAW, development: requested right after the frequency step instead, a whole inverse transform ahead - measured
-  // round 4, profiles/r04e: 0.1924 vs 0.1919 ms, nothing; the "store phase" of the stamps is as long without any store, but it is not
-  // this wait either)
-#if defined(RPSF_DEV_EARLY_DRAW)
-  constexpr bool EARLY_DRAW = PERSIST && C::SPLIT_ROWS && !C::WIDE;
-#else
+  // on, position 0 = slot 0) and the tile this lane will count the patch on.
+  // 256-pixel plan (EARLY_DRAW): REQUESTED right after the frequency step and PUT INTO LDS IN FRONT OF THE PLANE STORES, a whole inverse
+  // transform later, when the two round trips - an atomic with return and a load, both in wave 0 - are long over.  Used behind the stores,
+  // as until round 4, the values cost a drain: the stores sit in divergent branches (interior / rim paths), the compiler cannot count them,
+  // so the wait in front of the use was `s_waitcnt vmcnt(0)` - wave 0 waited for the acknowledgement of its 32 write-through stores, and
+  // the seven other waves for wave 0 at the barrier behind it (the "No drain here" below was not true of the code object).
+  // 128-pixel plan: requested in front of the stores, used behind them (no register to spare across its slot-by-slot frequency step - 44
+  // spilled VGPRs - and four workgroups per CU that cover for one another).
+#if defined(RPSF_DEV_LATE_DRAW)  // development: A/B
   constexpr bool EARLY_DRAW = false;
+#else
+  constexpr bool EARLY_DRAW = PERSIST && C::SPLIT_ROWS && !C::WIDE;
 #endif
   unsigned drawn = 0, qword = 0;  // (one register each: lane tu < 4 holds the word of its own tile)
   [[maybe_unused]] auto draw_next = [&]() RPSF_AI {
@@ -606,9 +608,6 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   if (C::WAVES >= 2 && t >= C::T / 2) __builtin_amdgcn_s_sleep(RPSF_DEV_SKEW);
 #endif
   STAMP(1);
-#if defined(RPSF_DEV_PRIO_HEAD)  // development: the same for the barrier-free head of a pass (stage 1 and the first X1)
-  if (C::WAVES >= 2 && t >= C::T / 2) __builtin_amdgcn_s_setprio(1);
-#endif
   // ---- forward: the halves leapfrog through stage 1, X1 (wave-local) and stage 2 ----
   ABL_VALU(stage1h<C, 0, false>(t, v, tw));
   ABL_LDS(x1_write2<C, 0>(t, v, lds));
@@ -617,9 +616,6 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   ABL_LDS(x1_read2<C, 0>(t, v, lds));
   ABL_LDS(x1_write2<C, 1>(t, v, lds));  // (a wave's DS operations complete in order: these writes cannot overtake the reads)
   STAMP(2);
-#if defined(RPSF_DEV_PRIO_HEAD)
-  if (C::WAVES >= 2) __builtin_amdgcn_s_setprio(0);
-#endif
   ABL_VALU(stage2h<C, 0, false>(t, v, tw));
   wave_lds_sync();
   ABL_LDS(x1_read2<C, 1>(t, v, lds));
@@ -719,27 +715,17 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   if (C::WAVES >= 2 && t >= C::T / 2) __builtin_amdgcn_s_sleep(RPSF_DEV_SKEW);
 #endif
   STAMP(7);
-#if defined(RPSF_DEV_PRIO_TAIL)  // development: the second wave of every SIMD (waves WAVES/2 ...) gets the issue priority behind the last barrier of a pass,
-                                // until stamp 8 (1), 9 (2) or the end of the stores (3): age-based arbitration lets it fall 2 us behind there (profiles/r04i)
-  if (C::WAVES >= 2 && t >= C::T / 2) __builtin_amdgcn_s_setprio(1);
-#endif
   ABL_LDS(x1_write2<C, 0>(t, v, lds));
   ABL_VALU(stage2h<C, 1, true>(t, v, tw));
   wave_lds_sync();
   ABL_LDS(x1_read2<C, 0>(t, v, lds));
   ABL_LDS(x1_write2<C, 1>(t, v, lds));
   STAMP(8);
-#if defined(RPSF_DEV_PRIO_TAIL)
-  if (RPSF_DEV_PRIO_TAIL == 1 && C::WAVES >= 2) __builtin_amdgcn_s_setprio(0);
-#endif
   ABL_VALU(stage1h<C, 0, true>(t, v, tw));
   wave_lds_sync();
   ABL_LDS(x1_read2<C, 1>(t, v, lds));
   ABL_VALU(stage1h<C, 1, true>(t, v, tw));
   STAMP(9);
-#if defined(RPSF_DEV_PRIO_TAIL)
-  if (RPSF_DEV_PRIO_TAIL == 2 && C::WAVES >= 2) __builtin_amdgcn_s_setprio(0);
-#endif
   }  // !C::WIDE
   // ---- overlap-add ----
 #if defined(RPSF2_ABL_NOSTORE)
@@ -780,6 +766,10 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
     const float* pbase = ov.out;
     const __amdgpu_buffer_rsrc_t rsrc = plane_rsrc(pbase);
     if constexpr (!EARLY_DRAW) draw_next();
+    if constexpr (EARLY_DRAW) {  // (park: idle since the frequency step; the previous pass's words were read by count_previous long ago)
+      if (tu == 0) *reinterpret_cast<unsigned*>(park) = drawn;
+      if (tu < 4) reinterpret_cast<unsigned*>(park)[1 + tu] = (unsigned)frame * p.n_tiles + quad_tile(qword);  // (this frame's counters)
+    }
 #if defined(RPSF_DEV_CARRY)
     // timing experiment (results are wrong): the right half of every patch goes to the workgroup's private carry buffer, what the
     // previous patch left there is added to the left half, and only that reaches a colour plane (two planes, by lattice-row parity)
@@ -834,14 +824,13 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
     }
 #endif
     STAMP(10);
-#if defined(RPSF_DEV_PRIO_TAIL)
-    if (RPSF_DEV_PRIO_TAIL == 3 && C::WAVES >= 2) __builtin_amdgcn_s_setprio(0);
-#endif
     if constexpr (PERSIST) {
       // No drain here: the next patch's loads queue behind these stores anyway, and the patch is counted on its tiles from
       // inside the next pass (count_previous), when the stores are known to have been acknowledged.
-      if (tu == 0) *reinterpret_cast<unsigned*>(park) = drawn;  // (park: idle since the frequency step)
-      if (tu < 4) reinterpret_cast<unsigned*>(park)[1 + tu] = (unsigned)frame * p.n_tiles + quad_tile(qword);  // (this frame's counters)
+      if constexpr (!EARLY_DRAW) {
+        if (tu == 0) *reinterpret_cast<unsigned*>(park) = drawn;  // (park: idle since the frequency step)
+        if (tu < 4) reinterpret_cast<unsigned*>(park)[1 + tu] = (unsigned)frame * p.n_tiles + quad_tile(qword);  // (this frame's counters)
+      }
       lds_barrier();
       STAMP(12);
       const unsigned nx = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const unsigned*>(park));
