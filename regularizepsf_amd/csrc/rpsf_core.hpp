@@ -56,14 +56,30 @@ RPSF_HD cf operator*(cf a, cf b) { return cf{a.x * b.x, a.y * b.y}; }
 RPSF_HD cf operator*(cf a, float b) { return cf{a.x * b, a.y * b}; }
 RPSF_HD cf operator-(cf a) { return cf{-a.x, -a.y}; }
 #else
+// Packed complex (development, RPSF_PACKED_CF): a value is an aligned register pair and the arithmetic is written on whole pairs -
+// element-wise fma / add / mul with swizzled and negated operands - so that the compiler emits v_pk_* with op_sel / neg modifiers and no
+// component moves (what sank the earlier packed builds: 490 ... 1,274 v_mov).  A twiddled butterfly is three v_pk_fma instead of six FMAs,
+// a complex product two instructions instead of four; by the issue table of profiles/r04d (4.6 ... 4.8 cycles per packed instruction against
+// 2.55 ... 3.5 per scalar one) that is ~14 % fewer cycles for the networks.
 typedef float cf __attribute__((ext_vector_type(2)));
+RPSF_HD cf pk_swap(cf a) { return __builtin_shufflevector(a, a, 1, 0); }
+RPSF_HD cf pk_fma(cf a, cf b, cf c) { return __builtin_elementwise_fma(a, b, c); }
 #endif
 
+#if !defined(RPSF_PACKED_CF)
 RPSF_HD cf cmul(cf a, cf b) { return cf{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
 RPSF_HD cf cmulc(cf a, cf b) { return cf{a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y}; }  // a * conj(b)
 RPSF_HD cf cconj(cf a) { return cf{a.x, -a.y}; }
 RPSF_HD cf mul_pi(cf a) { return cf{-a.y, a.x}; }   // a * (+i)
 RPSF_HD cf mul_mi(cf a) { return cf{a.y, -a.x}; }   // a * (-i)
+#else
+// a b = a (b.x, b.x) + swap(a) (-b.y, b.y);   a conj(b) = a (b.x, b.x) + swap(a) (b.y, -b.y)
+RPSF_HD cf cmul(cf a, cf b) { return pk_fma(pk_swap(a), cf{-b.y, b.y}, a * cf{b.x, b.x}); }
+RPSF_HD cf cmulc(cf a, cf b) { return pk_fma(pk_swap(a), cf{b.y, -b.y}, a * cf{b.x, b.x}); }
+RPSF_HD cf cconj(cf a) { return __builtin_shufflevector(a, -a, 0, 3); }
+RPSF_HD cf mul_pi(cf a) { return __builtin_shufflevector(a, -a, 3, 0); }   // (-a.y, a.x)
+RPSF_HD cf mul_mi(cf a) { return __builtin_shufflevector(a, -a, 1, 2); }   // (a.y, -a.x)
+#endif
 // select on VALUES: `c ? arr[i] : arr[j]` would become a load through a selected pointer and
 // push the whole register tile into scratch
 RPSF_HD cf sel(bool c, cf a, cf b) { return cf{c ? a.x : b.x, c ? a.y : b.y}; }
@@ -130,10 +146,15 @@ RPSF_HD void butterfly_dit(cf e, cf o, cf& x, cf& y) {
   } else {
     constexpr float c = cos64(k);
     constexpr float s = INV ? sin64(k) : -sin64(k);  // W = c + i s
+#if defined(RPSF_PACKED_CF)
+    x = pk_fma(pk_swap(o), cf{-s, s}, pk_fma(o, cf{c, c}, e));
+    y = pk_fma(e, cf{2.0f, 2.0f}, -x);
+#else
     x.x = __builtin_fmaf(-s, o.y, __builtin_fmaf(c, o.x, e.x));
     x.y = __builtin_fmaf(c, o.y, __builtin_fmaf(s, o.x, e.y));
     y.x = __builtin_fmaf(2.0f, e.x, -x.x);
     y.y = __builtin_fmaf(2.0f, e.y, -x.y);
+#endif
   }
 }
 template <int LOG, bool INV>

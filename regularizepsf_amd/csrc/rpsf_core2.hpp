@@ -618,8 +618,13 @@ RPSF_HD void window_patch2(int t, cf* v, const float* __restrict__ win) {
       const f32x4 w4 = *reinterpret_cast<const f32x4*>(win + 4 * cp);
       cf& a = v[2 * (R1 * NCOL + C1)];
       cf& b = v[2 * (R1 * NCOL + C1) + 1];
+#if defined(RPSF_PACKED_CF)
+      a = a * (cf{w4.x, w4.y} * wr);
+      b = b * (cf{w4.z, w4.w} * wr);
+#else
       a = cf{a.x * (w4.x * wr), a.y * (w4.y * wr)};
       b = cf{b.x * (w4.z * wr), b.y * (w4.w * wr)};
+#endif
     });
   });
 }
