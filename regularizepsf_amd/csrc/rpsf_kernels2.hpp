@@ -573,6 +573,10 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   constexpr bool EARLY_DRAW = PERSIST && C::SPLIT_ROWS && !C::WIDE;
 #endif
   unsigned drawn = 0, qword = 0;  // (one register each: lane tu < 4 holds the word of its own tile)
+  // (Tried on top of it, round 4, profiles/r04o: every wave reads the drawn position behind the last barrier of the inverse exchange, fetches the next
+  // slot's descriptor and touches one dword of each of the next patch's 2048 lines, a transform stage ahead of its gather - new frames 0.2095 -> 0.204 ms,
+  // but the repeated frame of the headline loop 0.1916 -> 0.200: the descriptor's scalar load sits on the chain right behind a barrier.  The opt-in
+  // prefetch by the head summing workgroups does better on new frames, 0.201, at no cost to the repeated one.  Not kept.)
   [[maybe_unused]] auto draw_next = [&]() RPSF_AI {
     if constexpr (PERSIST) {
       if (HOT || p.tile_done) {
@@ -710,6 +714,12 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   ABL_VALU(stage2h<C, 0, true>(t, v, tw));
   ABL_BAR();
   ABL_LDS(x2_mid_read2<C, 1>(t, v, lds));
+  if constexpr (EARLY_DRAW) {  // (park: idle since the frequency step; the previous pass's words were read by count_previous long ago)
+    if (HOT || p.tile_done) {
+      if (tu == 0) *reinterpret_cast<unsigned*>(park) = drawn;
+      if (tu < 4) reinterpret_cast<unsigned*>(park)[1 + tu] = (unsigned)frame * p.n_tiles + quad_tile(qword);  // (this frame's counters)
+    }
+  }
   ABL_BAR();  // X1 regions alias the X2 image
 #if defined(RPSF_DEV_SKEW)
   if (C::WAVES >= 2 && t >= C::T / 2) __builtin_amdgcn_s_sleep(RPSF_DEV_SKEW);
@@ -766,10 +776,6 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
     const float* pbase = ov.out;
     const __amdgpu_buffer_rsrc_t rsrc = plane_rsrc(pbase);
     if constexpr (!EARLY_DRAW) draw_next();
-    if constexpr (EARLY_DRAW) {  // (park: idle since the frequency step; the previous pass's words were read by count_previous long ago)
-      if (tu == 0) *reinterpret_cast<unsigned*>(park) = drawn;
-      if (tu < 4) reinterpret_cast<unsigned*>(park)[1 + tu] = (unsigned)frame * p.n_tiles + quad_tile(qword);  // (this frame's counters)
-    }
 #if defined(RPSF_DEV_CARRY)
     // timing experiment (results are wrong): the right half of every patch goes to the workgroup's private carry buffer, what the
     // previous patch left there is added to the left half, and only that reaches a colour plane (two planes, by lattice-row parity)
