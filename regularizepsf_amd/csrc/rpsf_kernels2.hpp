@@ -489,9 +489,29 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   // The slot descriptor through the scalar cache (a constant-address-space load of a uniform address): as a vector load it
   // would queue behind the plane stores of the workgroup's previous patch - VMEM returns in order - and the gather, which
   // needs the corner, would not even be issued before those stores are acknowledged.
+  // (256-pixel plan, re-entries: the previous pass of this workgroup has fetched the descriptor already and left it in LDS - words 12 ... 16 of the park
+  // area: corner, patch, plane, and the slot it belongs to + 1 -, which saves the scalar load's round trip at the head of the pass: DESC_AHEAD)
   typedef const int __attribute__((address_space(4))) cint_as4;
-  const cint_as4* dptr = (const cint_as4*)(const void*)(p.desc + (p.seq_base + seq));
-  const int4 dsc = make_int4(dptr[0], dptr[1], dptr[2], dptr[3]);
+#if defined(RPSF_DEV_NO_DESC_AHEAD)
+  constexpr bool DESC_AHEAD = false;
+#else
+  constexpr bool DESC_AHEAD = PERSIST && HOT && C::SPLIT_ROWS && !C::WIDE;
+#endif
+  int4 dsc;
+  {
+    const cint_as4* dptr = (const cint_as4*)(const void*)(p.desc + (p.seq_base + seq));
+    bool have = false;
+    if constexpr (DESC_AHEAD) {
+      if (again) {
+        const int4 q = *reinterpret_cast<const int4*>(reinterpret_cast<const int*>(park) + 12);
+        const int tag = reinterpret_cast<const int*>(park)[16];
+        dsc = make_int4(__builtin_amdgcn_readfirstlane(q.x), __builtin_amdgcn_readfirstlane(q.y), __builtin_amdgcn_readfirstlane(q.z),
+                        __builtin_amdgcn_readfirstlane(q.w));
+        have = (int)__builtin_amdgcn_readfirstlane(tag) == seq + 1;  // (workgroup-uniform)
+      }
+    }
+    if (!have) dsc = make_int4(dptr[0], dptr[1], dptr[2], dptr[3]);
+  }
   const int patch = dsc.z;
   // Start-up stagger.  The workgroups of one round move in lock step otherwise - all CUs stream K at one moment, store at
   // another, and the memory system alternates between idle and saturated.  The first resident workgroup of each CU is
@@ -573,6 +593,8 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   constexpr bool EARLY_DRAW = PERSIST && C::SPLIT_ROWS && !C::WIDE;
 #endif
   unsigned drawn = 0, qword = 0;  // (one register each: lane tu < 4 holds the word of its own tile)
+  [[maybe_unused]] int4 ndsc = make_int4(0, 0, 0, 0);  // DESC_AHEAD: the next slot's descriptor (wave 0, scalar) and the slot it belongs to + 1
+  [[maybe_unused]] int ntag = 0;
   // (Tried on top of it, round 4, profiles/r04o: every wave reads the drawn position behind the last barrier of the inverse exchange, fetches the next
   // slot's descriptor and touches one dword of each of the next patch's 2048 lines, a transform stage ahead of its gather - new frames 0.2095 -> 0.204 ms,
   // but the repeated frame of the headline loop 0.1916 -> 0.200: the descriptor's scalar load sits on the chain right behind a barrier.  The opt-in
@@ -721,6 +743,20 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
     }
   }
   ABL_BAR();  // X1 regions alias the X2 image
+  // DESC_AHEAD: wave 0 knows the drawn position (its lane 0 holds it) and fetches the next slot's descriptor through the scalar cache now; the
+  // value is first touched in front of the stores, a stage and a half later (a use right here would put the load's round trip on the chain).
+  if constexpr (DESC_AHEAD && EARLY_DRAW) {
+    if (tu < 64 && p.n_frames <= 1 && !head_patch) {
+      const int nx0 = (int)__builtin_amdgcn_readfirstlane(drawn);
+      const int left0 = p.n_patches - (pb & 7) * p.chunk;
+      if (nx0 >= 0 && nx0 < (left0 < p.chunk ? left0 : p.chunk)) {
+        const int nseq = (pb & 7) * p.chunk + nx0;
+        const cint_as4* nd = (const cint_as4*)(const void*)(p.desc + (p.seq_base + nseq));
+        ndsc = make_int4(nd[0], nd[1], nd[2], nd[3]);
+        ntag = nseq + 1;
+      }
+    }
+  }
 #if defined(RPSF_DEV_SKEW)
   if (C::WAVES >= 2 && t >= C::T / 2) __builtin_amdgcn_s_sleep(RPSF_DEV_SKEW);
 #endif
@@ -776,6 +812,12 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
     const float* pbase = ov.out;
     const __amdgpu_buffer_rsrc_t rsrc = plane_rsrc(pbase);
     if constexpr (!EARLY_DRAW) draw_next();
+    if constexpr (DESC_AHEAD && EARLY_DRAW) {
+      if (tu == 0) {
+        *reinterpret_cast<int4*>(reinterpret_cast<int*>(park) + 12) = ndsc;
+        reinterpret_cast<int*>(park)[16] = ntag;
+      }
+    }
 #if defined(RPSF_DEV_CARRY)
     // timing experiment (results are wrong): the right half of every patch goes to the workgroup's private carry buffer, what the
     // previous patch left there is added to the left half, and only that reaches a colour plane (two planes, by lattice-row parity)
