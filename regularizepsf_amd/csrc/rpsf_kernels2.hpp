@@ -492,10 +492,10 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   // (256-pixel plan, re-entries: the previous pass of this workgroup has fetched the descriptor already and left it in LDS - words 12 ... 16 of the park
   // area: corner, patch, plane, and the slot it belongs to + 1 -, which saves the scalar load's round trip at the head of the pass: DESC_AHEAD)
   typedef const int __attribute__((address_space(4))) cint_as4;
-#if defined(RPSF_DEV_NO_DESC_AHEAD)
-  constexpr bool DESC_AHEAD = false;
-#else
+#if defined(RPSF_DEV_DESC_AHEAD)  // (development: measured round 4, profiles/r04p - 0.1916 vs 0.1916 ms, nothing - so it stays out of the product)
   constexpr bool DESC_AHEAD = PERSIST && HOT && C::SPLIT_ROWS && !C::WIDE;
+#else
+  constexpr bool DESC_AHEAD = false;
 #endif
   int4 dsc;
   {
