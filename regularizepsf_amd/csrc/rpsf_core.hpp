@@ -73,9 +73,30 @@ RPSF_HD cf cconj(cf a) { return cf{a.x, -a.y}; }
 RPSF_HD cf mul_pi(cf a) { return cf{-a.y, a.x}; }   // a * (+i)
 RPSF_HD cf mul_mi(cf a) { return cf{a.y, -a.x}; }   // a * (-i)
 #else
-// a b = a (b.x, b.x) + swap(a) (-b.y, b.y);   a conj(b) = a (b.x, b.x) + swap(a) (b.y, -b.y)
-RPSF_HD cf cmul(cf a, cf b) { return pk_fma(pk_swap(a), cf{-b.y, b.y}, a * cf{b.x, b.x}); }
-RPSF_HD cf cmulc(cf a, cf b) { return pk_fma(pk_swap(a), cf{b.y, -b.y}, a * cf{b.x, b.x}); }
+// a b = a (b.x, b.x) + swap(a) (-b.y, b.y);   a conj(b) = a (b.x, b.x) + swap(a) (b.y, -b.y).  With a run-time b the two instructions are written
+// out with their operand swizzles (the compiler builds the pair (-b.y, b.y) with moves otherwise); with a compile-time b it folds the constants itself.
+RPSF_HD cf cmul(cf a, cf b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (!(__builtin_constant_p(b.x) && __builtin_constant_p(b.y))) {
+    cf t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(b));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    return r;
+  }
+#endif
+  return pk_fma(pk_swap(a), cf{-b.y, b.y}, a * cf{b.x, b.x});
+}
+RPSF_HD cf cmulc(cf a, cf b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (!(__builtin_constant_p(b.x) && __builtin_constant_p(b.y))) {
+    cf t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(b));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    return r;
+  }
+#endif
+  return pk_fma(pk_swap(a), cf{b.y, -b.y}, a * cf{b.x, b.x});
+}
 RPSF_HD cf cconj(cf a) { return __builtin_shufflevector(a, -a, 0, 3); }
 RPSF_HD cf mul_pi(cf a) { return __builtin_shufflevector(a, -a, 3, 0); }   // (-a.y, a.x)
 RPSF_HD cf mul_mi(cf a) { return __builtin_shufflevector(a, -a, 1, 2); }   // (a.y, -a.x)
@@ -141,8 +162,13 @@ RPSF_HD void butterfly_dit(cf e, cf o, cf& x, cf& y) {
   if constexpr (k == 0) {
     x = e + o, y = e - o;
   } else if constexpr (k == 16) {
+#if defined(RPSF_PACKED_CF)
+    const cf sgn = INV ? cf{-1.0f, 1.0f} : cf{1.0f, -1.0f};  // +-i o = swap(o) * sgn, folded into the two accumulations
+    x = pk_fma(pk_swap(o), sgn, e), y = pk_fma(pk_swap(o), -sgn, e);
+#else
     cf t = INV ? mul_pi(o) : mul_mi(o);
     x = e + t, y = e - t;
+#endif
   } else {
     constexpr float c = cos64(k);
     constexpr float s = INV ? sin64(k) : -sin64(k);  // W = c + i s
@@ -611,6 +637,21 @@ RPSF_HD void x2_last_write(const GroupIds<C>& gids, const cf* v, float* lds) {
 struct PairOut { cf a, b; };
 // two-sided: bins p (value za) and -p (value zb); ka = K'_h(p), kb = K'_h(p + (0,N/2)); w = W_N^kc(p)
 RPSF_HD PairOut pair_op(cf za, cf zb, cf ka, cf kb, cf w) {
+#if defined(RPSF_PACKED_CF)
+  // the same algebra on register pairs, sixteen packed instructions: conj / +-i are sign patterns of the accumulations
+  const cf e2 = pk_fma(zb, cf{1.0f, -1.0f}, za);           // za + conj(zb)
+  const cf d = pk_fma(zb, cf{-1.0f, 1.0f}, za);            // za - conj(zb);  o2 = -i d
+  const cf t = cmul(d, w);                                  // w o2 = -i t
+  const cf s1 = pk_fma(pk_swap(t), cf{1.0f, -1.0f}, e2);   // e2 + w o2
+  const cf s2 = pk_fma(pk_swap(t), cf{-1.0f, 1.0f}, e2);   // e2 - w o2
+  const cf y1 = cmul(s1, ka), y2 = cmul(s2, kb);
+  const cf ep2 = y1 + y2;
+  const cf op2 = cmulc(y1 - y2, w);
+  PairOut rr;
+  rr.a = pk_fma(pk_swap(op2), cf{-1.0f, 1.0f}, ep2);       // ep + i op
+  rr.b = pk_fma(ep2, cf{1.0f, -1.0f}, pk_swap(op2));       // conj(ep) + i conj(op)
+  return rr;
+#else
   cf zbc = cconj(zb);
   cf e2 = za + zbc;
   cf o2 = mul_mi(za - zbc);
@@ -623,6 +664,7 @@ RPSF_HD PairOut pair_op(cf za, cf zb, cf ka, cf kb, cf w) {
   r.a = ep + mul_pi(op);
   r.b = cconj(ep) + mul_pi(cconj(op));
   return r;
+#endif
 }
 
 // ------------------------------------------------------------------------------------------

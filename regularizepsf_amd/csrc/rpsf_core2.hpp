@@ -674,7 +674,12 @@ RPSF_HD void store_patch2(int t, const cf* v, const OutView& pv, const OutView& 
         const float wr = win[r];
         const f32x4 w4 = *reinterpret_cast<const f32x4*>(win + 4 * cp);
         const cf a = v[2 * (R1 * NCOL + C1)], b = v[2 * (R1 * NCOL + C1) + 1];
+#if defined(RPSF_PACKED_CF)
+        const cf pa = a * (cf{w4.x, w4.y} * wr), pb = b * (cf{w4.z, w4.w} * wr);
+        f32x4 val = {pa.x, pa.y, pb.x, pb.y};
+#else
         f32x4 val = {a.x * (w4.x * wr), a.y * (w4.y * wr), b.x * (w4.z * wr), b.y * (w4.w * wr)};
+#endif
         if (!qw || quad_mode(qw[QD]) == QUAD_SIDE) {
 #if defined(RPSF_DEV_QUAD)  // timing experiment (results are wrong): the plane traffic of 2 x 2 patches whose overlaps were summed on chip -
           // of the 16 quadrants of such a group 9 reach a plane
