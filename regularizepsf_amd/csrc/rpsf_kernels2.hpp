@@ -24,6 +24,11 @@ __device__ __forceinline__ f32x4 load16_sc1(const float* base, size_t span_bytes
 //   RPSF2_ABL_NOGATHER / _NOK / _NOSTORE: no pixel loads / no K loads / no output stores;
 //   RPSF2_ABL_NOLDS: no LDS exchanges (barriers stay); RPSF2_ABL_NOBAR: no workgroup barriers either;
 //   RPSF2_ABL_NOVALU: no butterflies and no pair operations.
+// (In a fused / persistent launch RPSF2_ABL_NOSTORE turns the plane stores into no-ops that keep the values live, so that the protocol runs on.)
+// Other development switches of this file, all measured in round 4 (profiles/r04*):
+//   RPSF_DEV_SPLIT / RPSF_DEV_WIDE[=2]: timing skeletons of other structures (split patch; 1024 threads per patch, lock-step or ping-pong) - k2_256s.hip;
+//   RPSF_DEV_LATE_DRAW, RPSF_DEV_DESC_AHEAD, RPSF_KDEPTH2: protocol / K-stream variants;  RPSF_DEV_SLEEP_ALL / _W0 / _REST: chain-sensitivity naps;
+//   RPSF_WAVE_STAMPS (with RPSF_STAMPS): lane 0 of every wave stamps;  RPSF_PACKED_CF (rpsf_core.hpp): hand-packed complex arithmetic.
 #if defined(RPSF2_ABL_NOLDS)
 #define ABL_LDS(...) ((void)0)
 #else
