@@ -971,3 +971,46 @@ def test_device_resident_psf_to_transform_chain():
     edited = rp.ArrayPSFTransform.construct(s, t, 3.0, 0.1)
     assert np.array_equal(edited._transfer_kernel.values, _native.build_transfer(got_s, got_t, 3.0, 0.1), equal_nan=True)
     assert not np.array_equal(edited._transfer_kernel.values, sweep[0][2]._transfer_kernel.values)
+
+
+def test_specialised_persistent_kernels_and_the_geometries_they_hand_back():
+    """The persistent kernels are compiled for "fused colour planes, every 16-byte unit of a patch maps to four consecutive image columns or to the
+    fill" (patch_body2's HOT instantiation: no pixel-by-pixel rim paths in the code); the launcher proves that per apply (hot_geometry, rpsf.hip) and
+    hands everything else to the one-patch-per-workgroup kernel.  One plan per patch size, the same frame under every pad mode - 'constant',
+    'symmetric', 'wrap' run the persistent kernel, 'reflect' and 'edge' tear units apart and must not - and through image / output views whose rows
+    are unaligned (a one-float offset, an odd stride): all against the oracle, and the aligned result bit-identical to the one-patch-per-workgroup
+    launch of the same plan."""
+    import os
+
+    from regularizepsf_amd import _native
+
+    for n, shape in ((256, (768, 1024)), (128, (512, 640))):
+        rng = np.random.default_rng(400 + n)
+        coords = [tuple(int(v) for v in c) for c in rp.calculate_covering(shape, n)]
+        k = (rng.standard_normal((len(coords), n, n)) + 1j * rng.standard_normal((len(coords), n, n))).astype(np.complex64)
+        image = (rng.standard_normal(shape) * 10 + 30).astype(np.float32)
+        plan = _native.Plan(n, coords)
+        plan.set_transfer(k)
+        outs = {}
+        for mode in ("symmetric", "constant", "wrap", "reflect", "edge"):
+            outs[mode] = plan.apply(image, _native.PAD_MODES[mode])
+            check(outs[mode].astype(np.float64), orc.apply_transfer(image, coords, k, pad_mode=mode))
+        os.environ["RPSF_NO_PERSIST"] = "1"
+        try:
+            plain = _native.Plan(n, coords)
+            plain.set_transfer(k)
+            for mode in ("symmetric", "wrap", "reflect"):
+                assert np.array_equal(plain.apply(image, _native.PAD_MODES[mode]), outs[mode]), mode
+        finally:
+            del os.environ["RPSF_NO_PERSIST"]
+        # device-resident views: the image one float into its buffer (rows no longer 16-byte aligned) with an odd stride
+        h, w = shape
+        ld = w + 3
+        host = np.zeros(h * ld + 1, np.float32)
+        host[1:].reshape(h, ld)[:, :w] = image
+        d_img = _native.DeviceBuffer(host.nbytes).upload(host)
+        d_out = _native.DeviceBuffer(h * w * 4)
+        geom = _native.Geometry(h, w, _native.PAD_MODES["symmetric"], 0.0, 0, 0, 0, h, ld, 0, h, w)
+        plan.apply_device(d_img.at(4), d_out.ptr, geom)
+        plan.synchronize()
+        assert np.array_equal(d_out.download((h, w)), outs["symmetric"])
