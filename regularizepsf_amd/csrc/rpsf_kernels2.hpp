@@ -590,12 +590,17 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   // as until round 4, the values cost a drain: the stores sit in divergent branches (interior / rim paths), the compiler cannot count them,
   // so the wait in front of the use was `s_waitcnt vmcnt(0)` - wave 0 waited for the acknowledgement of its 32 write-through stores, and
   // the seven other waves for wave 0 at the barrier behind it (the "No drain here" below was not true of the code object).
-  // 128-pixel plan: requested in front of the stores, used behind them (no register to spare across its slot-by-slot frequency step - 44
-  // spilled VGPRs - and four workgroups per CU that cover for one another).
 #if defined(RPSF_DEV_LATE_DRAW)  // development: A/B
   constexpr bool EARLY_DRAW = false;
 #else
   constexpr bool EARLY_DRAW = PERSIST && C::SPLIT_ROWS && !C::WIDE;
+#endif
+  // (the 128-pixel plan, MID_DRAW: requested behind the last barrier of the inverse exchange - across its slot-by-slot frequency step the two values cost 44
+  // spilled registers - and put into LDS in front of the stores all the same: configs 2 / 5 -0.7 % / -0.5 %, profiles/r04r)
+#if defined(RPSF_DEV_LATE_DRAW)
+  constexpr bool MID_DRAW = false;
+#else
+  constexpr bool MID_DRAW = PERSIST && !EARLY_DRAW && !C::WIDE && !C::HALF;
 #endif
   unsigned drawn = 0, qword = 0;  // (one register each: lane tu < 4 holds the word of its own tile)
   [[maybe_unused]] int4 ndsc = make_int4(0, 0, 0, 0);  // DESC_AHEAD: the next slot's descriptor (wave 0, scalar) and the slot it belongs to + 1
@@ -748,6 +753,7 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
     }
   }
   ABL_BAR();  // X1 regions alias the X2 image
+  if constexpr (MID_DRAW) draw_next();
   // DESC_AHEAD: wave 0 knows the drawn position (its lane 0 holds it) and fetches the next slot's descriptor through the scalar cache now; the
   // value is first touched in front of the stores, a stage and a half later (a use right here would put the load's round trip on the chain).
   if constexpr (DESC_AHEAD && EARLY_DRAW) {
@@ -816,7 +822,11 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
     // counted on its four tiles; the workgroups behind the patches in the grid sum a tile as soon as its count is complete.
     const float* pbase = ov.out;
     const __amdgpu_buffer_rsrc_t rsrc = plane_rsrc(pbase);
-    if constexpr (!EARLY_DRAW) draw_next();
+    if constexpr (!EARLY_DRAW && !MID_DRAW) draw_next();
+    if constexpr (MID_DRAW) {
+      if (tu == 0) *reinterpret_cast<unsigned*>(park) = drawn;
+      if (tu < 4) reinterpret_cast<unsigned*>(park)[1 + tu] = (unsigned)frame * p.n_tiles + quad_tile(qword);
+    }
     if constexpr (DESC_AHEAD && EARLY_DRAW) {
       if (tu == 0) {
         *reinterpret_cast<int4*>(reinterpret_cast<int*>(park) + 12) = ndsc;
@@ -880,7 +890,7 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
     if constexpr (PERSIST) {
       // No drain here: the next patch's loads queue behind these stores anyway, and the patch is counted on its tiles from
       // inside the next pass (count_previous), when the stores are known to have been acknowledged.
-      if constexpr (!EARLY_DRAW) {
+      if constexpr (!EARLY_DRAW && !MID_DRAW) {
         if (tu == 0) *reinterpret_cast<unsigned*>(park) = drawn;  // (park: idle since the frequency step)
         if (tu < 4) reinterpret_cast<unsigned*>(park)[1 + tu] = (unsigned)frame * p.n_tiles + quad_tile(qword);  // (this frame's counters)
       }
