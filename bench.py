@@ -331,6 +331,8 @@ def main() -> None:
     ap.add_argument("--verify", action="store_true", default=None,
                     help="check every rank's owned rows against the CPU oracle on one step outside the timed loops (default: on for N > 1)")
     ap.add_argument("--no-verify", dest="verify", action="store_false")
+    ap.add_argument("--second-leg-timeout", type=float, default=300.0,
+                    help="N > 1: seconds the second seam leg may take before the headline line is emitted without it")
     ap.add_argument("--one-seam", action="store_true",
                     help="N > 1: time only the --seam mode (default: the other seam mode is timed as a second leg in the same process)")
     ap.add_argument("--frames", type=int, default=8, help="config 5: frames per GPU in one batch")
@@ -548,22 +550,6 @@ def main() -> None:
     if args.verify:
         verified[args.seam if world > 1 else "single"] = verify_owned_rows(shard, args.seam if world > 1 else "single")
 
-    # ---------------- N > 1: the other seam mode, same steps, same barriers ----------------
-    other_ms = None
-    if shard2 is not None:
-        band2 = shard2.band
-        shard2.upload_rows(image_rows(band2.image_row0, band2.image_row0 + band2.image_rows))
-        for _ in range(max(args.warmup, 2)):
-            shard2.step()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            shard2.step()
-        barrier()
-        other_ms = 1e3 * comm.allreduce_max(time.perf_counter() - t0) / args.steps
-        if args.verify:
-            verified[other_seam] = verify_owned_rows(shard2, other_seam)
-
     # ---------------- the same plan on a stream of NEW frames (N = 1): --new-frames different resident starfields and outputs in
     # rotation.  The headline loop above corrects ONE frame K times (SURVEY.md 8d's timed region); that frame and part of its colour
     # planes then sit in the 256 MB Infinity Cache from step to step, which a production stream of frames does not have.
@@ -618,15 +604,6 @@ def main() -> None:
             rccl_ranks = comm.ranks()
         except Exception as e:  # noqa: BLE001 - a diagnostic field must not take the run down
             print(f"[bench] ncclCommCount: {e}", file=sys.stderr, flush=True)
-    if comm is not None:  # orderly shutdown: nobody tears RCCL down while a peer is still in a collective
-        import torch.distributed as dist
-
-        barrier()
-        comm.close()
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank != 0:
-        return
     total_pixels = height * w
     value = total_pixels / (ms_per_step * 1e-3) / 1e6
     cus, name = _native.device_info(device)
@@ -658,11 +635,62 @@ def main() -> None:
             "apply_avg_ms_events": round(apply_avg_ms, 4), "patches_this_rank": my_patches,
         },
     }
+    # ---------------- N > 1: the other seam mode, same steps, same barriers - AFTER the headline line exists, under a watchdog: a hang or an
+    # error in this leg (RCCL send / recv between GPUs has never run before the first multi-GPU node this is launched on) must not cost the
+    # headline its JSON line ----------------
+    other_ms, second_leg_note = None, None
+    if shard2 is not None:
+        import threading
+
+        def give_up():
+            if rank == 0:
+                line["config"]["seam"] = args.seam
+                line["sync"] = "gloo" if isinstance(comm, GlooSeam) else "rccl"
+                line["rccl_ranks"] = rccl_ranks
+                line[f"scaling_{args.seam}_ms"] = round(ms_per_step, 4)
+                line[f"scaling_{other_seam}_ms"] = None
+                line["second_leg"] = f"seam={other_seam}: no result after {args.second_leg_timeout:.0f} s (watchdog); the headline leg is complete"
+                if verified:
+                    line["verify"] = {"max_error": max(verified.values()), "legs": sorted(verified), "bound": 1e-5}
+                emit_json(line)
+            os._exit(0)  # (kernels or collectives of the second leg may never return: no orderly shutdown)
+
+        dog = threading.Timer(args.second_leg_timeout, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            band2 = shard2.band
+            shard2.upload_rows(image_rows(band2.image_row0, band2.image_row0 + band2.image_rows))
+            for _ in range(max(args.warmup, 2)):
+                shard2.step()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                shard2.step()
+            barrier()
+            other_ms = 1e3 * comm.allreduce_max(time.perf_counter() - t0) / args.steps
+            if args.verify:
+                verified[other_seam] = verify_owned_rows(shard2, other_seam)
+        except (Exception, SystemExit) as e:  # noqa: BLE001 - reported in the line (a failed verification too); peers that wait for this rank are ended by their watchdogs
+            second_leg_note = f"seam={other_seam}: {type(e).__name__}: {e}"
+            print(f"[bench] second leg failed on rank {rank}: {second_leg_note}", file=sys.stderr, flush=True)
+        dog.cancel()
+    if comm is not None and second_leg_note is None:  # orderly shutdown: nobody tears RCCL down while a peer is still in a collective
+        import torch.distributed as dist
+
+        barrier()
+        comm.close()
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank != 0:
+        return
     if world > 1:  # both seam modes of this run (the headline is config.seam), the transport, and what RCCL says about its communicator
         line["config"]["seam"] = args.seam
         line["sync"] = "gloo" if isinstance(comm, GlooSeam) else "rccl"
         line["rccl_ranks"] = rccl_ranks
         line[f"scaling_{args.seam}_ms"] = round(ms_per_step, 4)
+        if second_leg_note is not None:
+            line["second_leg"] = second_leg_note
         if other_ms is not None:
             line[f"scaling_{other_seam}_ms"] = round(other_ms, 4)
             line["seam_rows_transport"] = ("gloo (host copies: debugging stand-in)" if isinstance(comm, GlooSeam) else
