@@ -84,7 +84,9 @@ __device__ __forceinline__ void plane_store16_wt(__amdgpu_buffer_rsrc_t r, size_
   __builtin_amdgcn_raw_buffer_store_b128(q, r, (int)(RPSF_PLANE_OFF(float_offset) * sizeof(float)), 0, RPSF_DEV_PLANE_AUX);
 }
 
-template <int UN = 8>  // groups in flight per thread: 4 x UN sixteen-byte loads
+// UN: groups in flight per thread (4 x UN sixteen-byte loads);  KNOWN_FUSED: the caller is a fused launch (the persistent kernels), so the
+// plane loads are the write-through-aware ones without a run-time choice in front of each
+template <int UN = 8, bool KNOWN_FUSED = false>
 __device__ __forceinline__ void sum_tile(const TileSum& p0, uint32_t entry, int tid, int nthreads, bool known_complete = false) {
   typedef float f4 __attribute__((ext_vector_type(4)));
   const uint32_t tile = entry & 0xffffffu, frame = entry >> 24;
@@ -102,7 +104,7 @@ __device__ __forceinline__ void sum_tile(const TileSum& p0, uint32_t entry, int 
 #else
   const int cov = cov_all;
 #endif
-  const bool fused = p.done != nullptr;
+  const bool fused = KNOWN_FUSED || p.done != nullptr;
   if (fused && !known_complete) {  // wait until every contributor of the tile has published its stores
     if (tid == 0) {
       const uint32_t want = p.epoch * (uint32_t)__builtin_popcount(cov_all & 15);
@@ -170,10 +172,10 @@ __device__ __forceinline__ void sum_tile(const TileSum& p0, uint32_t entry, int 
 struct NoSideJob {
   __device__ __forceinline__ bool operator()() const { return false; }
 };
-template <class BETWEEN = NoSideJob, int UN = 8>
+template <class BETWEEN = NoSideJob, int UN = 8, bool KNOWN_FUSED = false>
 __device__ __forceinline__ void sum_tiles_worker(const TileSum& p, int block, int nblocks, BETWEEN&& between = BETWEEN()) {
   if (!p.queue) {
-    for (int i = block; i < p.count; i += nblocks) sum_tile<UN>(p, p.tiles[i], threadIdx.x, blockDim.x);
+    for (int i = block; i < p.count; i += nblocks) sum_tile<UN, KNOWN_FUSED>(p, p.tiles[i], threadIdx.x, blockDim.x);
     return;
   }
 #if !defined(RPSF_DEV_SUM_BLOCKING)
@@ -224,7 +226,7 @@ __device__ __forceinline__ void sum_tiles_worker(const TileSum& p, int block, in
     __syncthreads();
     if (tile == 0xffffffffu) return;
     if (tile == 0xfffffffeu) continue;
-    sum_tile<UN>(p, tile, threadIdx.x, blockDim.x, true);
+    sum_tile<UN, KNOWN_FUSED>(p, tile, threadIdx.x, blockDim.x, true);
   }
 #else
   __shared__ uint32_t next;
@@ -234,7 +236,7 @@ __device__ __forceinline__ void sum_tiles_worker(const TileSum& p, int block, in
     const uint32_t i = next;
     __syncthreads();
     if (i >= (uint32_t)p.count) return;
-    sum_tile<UN>(p, sum_entry(p, i), threadIdx.x, blockDim.x);
+    sum_tile<UN, KNOWN_FUSED>(p, sum_entry(p, i), threadIdx.x, blockDim.x);
   }
 #endif
 }

@@ -410,6 +410,13 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
 #if defined(RPSF_STAMPS)  // diagnostic builds: when did this pass reach the kernel's first instructions (stamp 14, through an LDS word)
   if (threadIdx.x == 0) *reinterpret_cast<unsigned long long*>(reinterpret_cast<cf*>(smem + Launch2<C>::TABLE_FLOATS) + C::BUF_UNITS + 4) = __builtin_amdgcn_s_memrealtime();
 #endif
+#if defined(RPSF_DEV_SUM_RUNTIME)  // development: A/B of the tile sums with the run-time choice of plane loads left in
+  constexpr bool SUM_KNOWN_FUSED = false;
+#else
+  // (the tile sums of the 128-pixel persistent kernel are compiled for "fused" - no run-time choice of loads in front of each of the 32: config 2 -2 %;
+  // in the 256-pixel kernel the same is worth -0.3 % at 4096^2 and +0.9 % at 8192^2, so it keeps the choice: profiles/r04t)
+  constexpr bool SUM_KNOWN_FUSED = HOT && !C::SPLIT_ROWS;
+#endif
   const bool again = PERSIST && ((blockIdx.x >> 30) & 1u);
 #if defined(RPSF_STAMPS)  // ... and which workgroup this is (its block index at dispatch, kept in LDS across re-entries: stamp 15)
   // (an unused word of the bin-pair table: bit 31 clear, so the walk of the self-paired bins ignores it; written again behind the table staging below)
@@ -476,7 +483,7 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
     if constexpr (PERSIST && C::T == 512) {
       if (!again && blk < p.sum_first) {  // a head summing workgroup: the image prefetch is its side job
         ImagePrefetch<C> prefetch(p, blk, p.prefetch && p.n_frames <= 1);
-        sum_tiles_worker<ImagePrefetch<C>&, C::WIDE ? 4 : 8>(p.ts, 0, 1, prefetch);
+        sum_tiles_worker<ImagePrefetch<C>&, C::WIDE ? 4 : 8, SUM_KNOWN_FUSED>(p.ts, 0, 1, prefetch);
         prefetch.finish();
         return;
       }
@@ -484,7 +491,7 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
 #endif
     if constexpr (C::WIDE) sum_tiles_worker<NoSideJob, 4>(p.ts, 0, 1);
     else
-    sum_tiles_worker(p.ts, 0, 1);
+    sum_tiles_worker<NoSideJob, 8, SUM_KNOWN_FUSED>(p.ts, 0, 1);
     return;
   }
   ImageView im = p.im;
