@@ -742,6 +742,12 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
 #if defined(RPSF_DEV_SLEEP_REST)
   if (t >= 64) __builtin_amdgcn_s_sleep(RPSF_DEV_SLEEP_REST);
 #endif
+#if defined(RPSF_DEV_SLEEP_W13)  // waves 1-3 only (the first wave of SIMDs 1-3)
+  if (t >= 64 && t < 256) __builtin_amdgcn_s_sleep(RPSF_DEV_SLEEP_W13);
+#endif
+#if defined(RPSF_DEV_SLEEP_W47)  // waves 4-7 only (the second wave of every SIMD)
+  if (t >= 256) __builtin_amdgcn_s_sleep(RPSF_DEV_SLEEP_W47);
+#endif
   if constexpr (EARLY_DRAW) draw_next();
   // ---- inverse ----
   ABL_LDS(x2_last_write2<C, 0>(gids, v, lds));
