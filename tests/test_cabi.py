@@ -44,6 +44,9 @@ def test_bad_arguments_are_reported_not_crashed():
     for size in (1, 5000):  # 16..256 have compiled plans, 2..4096 the hipFFT fallback, nothing else exists
         rc = handle.rpsf_plan_create(ctypes.byref(out), 0, size, 1, coords.ctypes.data_as(ctypes.c_void_p))
         assert rc == _native.E_UNSUPPORTED and str(size).encode() in handle.rpsf_last_error()
+    # the communicator's rank count (ncclCommCount behind it): null arguments are an error code, not a crash
+    n = ctypes.c_int(-1)
+    assert handle.rpsf_comm_ranks(None, ctypes.byref(n)) == _native.E_BADARG and n.value == -1
 
 
 def _gpu_present():
