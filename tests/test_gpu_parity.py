@@ -234,6 +234,7 @@ def test_rccl_wrapper_single_rank():
     assert len(uid) == 128
     comm = _native.Comm(0, 0, 1, uid)
     assert comm.allreduce_max(3.25) == 3.25
+    assert comm.ranks() == 1  # ncclCommCount through rpsf_comm_ranks: what bench.py --gpus N prints as rccl_ranks
     comm.barrier()
     buf = _native.DeviceBuffer(4096)
     comm.seam_exchange_add(buf.ptr, 1024, buf.ptr, 0, buf.ptr)  # no neighbour: nothing to send or receive
