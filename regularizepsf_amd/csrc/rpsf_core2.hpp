@@ -179,6 +179,12 @@ template <class C, int H, bool INV>
 RPSF_HD void stage1h(int t, cf* v, const cf* __restrict__ tw) {
   constexpr int NR = 1 << C::A1, NCOL = 1 << C::B1;
   ThreadPos2<C> tp(t);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RPSF_DEV_KEEP_TW_ADDR)
+  // The inverse stage recomputes its twiddle addresses (two integer instructions each): left to itself the compiler keeps the forward stage's fifteen
+  // alive across the whole pass and spills three of them - scratch reloads in the last stage of the chain, behind the in-order vector-memory pipe.
+  // (256-pixel plan: 3 spilled VGPRs / 16 B of scratch -> none, timing unchanged, profiles/r04x; the 128-pixel plan never spilled them)
+  if constexpr (INV && C::SPLIT_ROWS) asm volatile("" : "+v"(tp.r_low), "+v"(tp.c2));
+#endif
   const int c_low = 2 * tp.c2 + H;
   auto row_tw = [&]() RPSF_AI {
     StaticFor<1, NR>::run([&]<int K1>() RPSF_AI {
