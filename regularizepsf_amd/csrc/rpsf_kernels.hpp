@@ -87,8 +87,16 @@ __device__ __forceinline__ void plane_store16_wt(__amdgpu_buffer_rsrc_t r, size_
 // UN: groups in flight per thread (4 x UN sixteen-byte loads);  KNOWN_FUSED: the caller is a fused launch (the persistent kernels), so the
 // plane loads are the write-through-aware ones without a run-time choice in front of each
 template <int UN = 8, bool KNOWN_FUSED = false>
-__device__ __forceinline__ void sum_tile(const TileSum& p0, uint32_t entry, int tid, int nthreads, bool known_complete = false) {
+__device__ __forceinline__ void sum_tile(const TileSum& p0, uint32_t entry_any_lane, int tid, int nthreads, bool known_complete = false) {
   typedef float f4 __attribute__((ext_vector_type(4)));
+  // The entry is the same in every lane (the whole workgroup sums one tile), but it comes out of LDS or a strided loop, so the compiler has to assume
+  // otherwise - and then the tile's coverage mask is a vector value and every "is this plane present" choice of the 32 loads a v_cndmask on VCC, which
+  // gfx950 issues at 23 cycles apiece (scripts/micro/valu_mix.hip, profiles/r04y).  Saying that it is uniform makes them scalar selects.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RPSF_DEV_SUM_VECTOR_COV)
+  const uint32_t entry = __builtin_amdgcn_readfirstlane(entry_any_lane);
+#else
+  const uint32_t entry = entry_any_lane;
+#endif
   const uint32_t tile = entry & 0xffffffu, frame = entry >> 24;
   TileSum p = p0;  // this frame's planes, output and counters
   p.planes += (size_t)frame * p0.planes_frame_floats;
@@ -117,35 +125,51 @@ __device__ __forceinline__ void sum_tile(const TileSum& p0, uint32_t entry, int 
   if (y0 >= y1 || x0 >= x1) return;
   const bool vec = ((x0 | x1 | p.ld_planes | p.ld_out) & 3) == 0 && (p.plane_stride & 3) == 0 &&
                    ((reinterpret_cast<uintptr_t>(p.planes) | reinterpret_cast<uintptr_t>(p.out)) & 15) == 0;
-  if (vec) {
-    const __amdgpu_buffer_rsrc_t rsrc = plane_rsrc(p.planes);
-    const int gw = (x1 - x0) >> 2, total = gw * (y1 - y0);
-    // (UN = 8: 32 sixteen-byte loads per thread - a whole tile per pass for the patch kernels' workgroup sizes)
-    for (int i0 = tid; i0 < total; i0 += UN * nthreads) {
-      f4 v[UN][4];
-#pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        const int i = min(i0 + u * nthreads, total - 1);
-        const size_t off = (size_t)(y0 + i / gw - p.row0) * p.ld_planes + x0 + ((i % gw) << 2);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {  // unconditional loads (redirected to plane 0's line when unused) so that they overlap
-          const size_t o = ((cov >> k) & 1) ? off + k * p.plane_stride : off;
-          v[u][k] = fused ? plane_load16_wt(rsrc, o) : __builtin_nontemporal_load(reinterpret_cast<const f4*>(p.planes + o));
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        const int i = i0 + u * nthreads;
-        if (i >= total) break;
-        f4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if ((cov >> k) & 1) acc += v[u][k];
-#if defined(RPSF_DEV_OUT_PLAIN)  // development: output stores of the tile sum without the streaming hint
-        *reinterpret_cast<f4*>(p.out + (size_t)(y0 + i / gw - p.row0) * p.ld_out + x0 + ((i % gw) << 2)) = acc;
+  const int gw = (x1 - x0) >> 2;
+#if defined(RPSF_DEV_SUM_DIVIDE)  // development: A/B against an integer division per element
+  constexpr bool POW2 = false;
+  const bool wide_path = vec;
 #else
-        __builtin_nontemporal_store(acc, reinterpret_cast<f4*>(p.out + (size_t)(y0 + i / gw - p.row0) * p.ld_out + x0 + ((i % gw) << 2)));
+  // (a tile is 2^k groups of four pixels wide except where the image clips its last column to something else - those few tiles go pixel by pixel)
+  constexpr bool POW2 = true;
+  const bool wide_path = vec && (gw & (gw - 1)) == 0;
 #endif
+  if (wide_path) {
+    const __amdgpu_buffer_rsrc_t rsrc = plane_rsrc(p.planes);
+    const int total = gw * (y1 - y0);
+    // (UN = 8: 32 sixteen-byte loads per thread - a whole tile per pass for the patch kernels' workgroup sizes)
+    // Row and column group of element i: a tile is 2^k groups wide except where the image clips it, and an integer division by a run-time
+    // value is a dozen instructions, three of them v_cndmask on VCC (23 cycles apiece on gfx950): the power-of-two case shifts and masks.
+    {
+      const int sh = 31 - __builtin_clz((unsigned)gw);
+      auto row_of = [&](int i) RPSF_AI { return POW2 ? i >> sh : i / gw; };
+      auto col_of = [&](int i) RPSF_AI { return POW2 ? i & (gw - 1) : i % gw; };
+      for (int i0 = tid; i0 < total; i0 += UN * nthreads) {
+        f4 v[UN][4];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          const int i = min(i0 + u * nthreads, total - 1);
+          const size_t off = (size_t)(y0 + row_of(i) - p.row0) * p.ld_planes + x0 + (col_of(i) << 2);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {  // unconditional loads (redirected to plane 0's line when unused) so that they overlap
+            const size_t o = ((cov >> k) & 1) ? off + k * p.plane_stride : off;
+            v[u][k] = fused ? plane_load16_wt(rsrc, o) : __builtin_nontemporal_load(reinterpret_cast<const f4*>(p.planes + o));
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          const int i = i0 + u * nthreads;
+          if (i >= total) break;
+          f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if ((cov >> k) & 1) acc += v[u][k];
+#if defined(RPSF_DEV_OUT_PLAIN)  // development: output stores of the tile sum without the streaming hint
+          *reinterpret_cast<f4*>(p.out + (size_t)(y0 + row_of(i) - p.row0) * p.ld_out + x0 + (col_of(i) << 2)) = acc;
+#else
+          __builtin_nontemporal_store(acc, reinterpret_cast<f4*>(p.out + (size_t)(y0 + row_of(i) - p.row0) * p.ld_out + x0 + (col_of(i) << 2)));
+#endif
+        }
       }
     }
   } else {

@@ -13,6 +13,9 @@ __global__ __launch_bounds__(1024) void k(float* out, int iters, float seed) {
   float r[32];
 #pragma unroll
   for (int i = 0; i < 32; ++i) r[i] = seed + i * 0.001f + threadIdx.x * 1e-6f;
+  const unsigned long long mask64 = __builtin_amdgcn_read_exec() ^ (0x5555555555555555ull * (unsigned)(seed != 7.f));
+  const float mf = (threadIdx.x & 1) ? 1.f : 0.f;
+  const unsigned mi = (threadIdx.x & 1) ? 0xffffffffu : 0u;
   f2 p[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) p[i] = f2{seed + i, seed - i * 0.5f};
@@ -30,7 +33,19 @@ __global__ __launch_bounds__(1024) void k(float* out, int iters, float seed) {
       if (KIND == 6) asm volatile("v_fma_f32 %0, %1, 2.0, %2" : "=v"(d) : "v"(a), "v"(b));               // inline constant
       if (KIND == 7) asm volatile("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
       if (KIND == 8) asm volatile("v_fma_f32 %0, %1, %2, -%3" : "=v"(d) : "v"(a), "v"(b), "v"(c));        // with a source modifier
-      if (KIND >= 10) {
+      if (KIND == 30) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(d), "+v"(r[(i + 5) % 32]));   // gfx950: swaps d[32:63] with the other register's [0:31]
+      if (KIND == 31) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(d), "+v"(r[(i + 5) % 32]));
+      if (KIND == 32) asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(a));
+      if (KIND == 33) asm volatile("v_mov_b32_dpp %0, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(a));
+      if (KIND == 34) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(d) : "v"(a), "v"(b));
+      if (KIND == 35) asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(mask64));  // mask in an SGPR pair, as the compiler emits it
+      if (KIND == 36) {  // the same selection by arithmetic: d = a + m (b - a), m = 0 / 1 per lane
+        float tdiff;
+        asm volatile("v_sub_f32 %0, %1, %2" : "=v"(tdiff) : "v"(b), "v"(a));
+        asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(mf), "v"(tdiff), "v"(a));
+      }
+      if (KIND == 37) asm volatile("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(mi), "v"(a), "v"(b));  // bitwise select with a per-lane all-ones / all-zeros mask
+      if (KIND >= 10 && KIND < 30) {
         f2& pd = p[i % 16];
         const f2 pa = p[(i + 3) % 16], pb = p[(i + 7) % 16], pc = p[(i + 11) % 16];
         if (KIND == 10) asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(pd) : "v"(pa), "v"(pb), "v"(pc));
@@ -108,5 +123,7 @@ int main() {
   RUN(k<10>, "v_pk_fma 3 distinct src", 4); RUN(k<15>, "v_pk_fma 2 distinct src", 4); RUN(k<13>, "v_pk_fma op_sel swizzle", 4);
   RUN(k<11>, "v_pk_add", 2); RUN(k<14>, "v_pk_add neg", 2); RUN(k<12>, "v_pk_mul", 2);
   RUN(kmix<0>, "mix fma/add/fmac/sub", 1.5); RUN(kmix<1>, "fma chain (dependent)", 2);
+  RUN(k<30>, "v_permlane32_swap", 0); RUN(k<31>, "v_permlane16_swap", 0); RUN(k<32>, "v_mov_dpp quad_perm", 0); RUN(k<33>, "v_mov_dpp row_ror:8", 0);
+  RUN(k<34>, "v_cndmask (vcc)", 0); RUN(k<35>, "v_cndmask_e64 (sgpr mask)", 0); RUN(k<36>, "select by sub + fma (2 inst)", 0); RUN(k<37>, "v_bfi select", 0);
   return 0;
 }

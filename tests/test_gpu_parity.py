@@ -1015,3 +1015,20 @@ def test_specialised_persistent_kernels_and_the_geometries_they_hand_back():
         plan.apply_device(d_img.at(4), d_out.ptr, geom)
         plan.synchronize()
         assert np.array_equal(d_out.download((h, w)), outs["symmetric"])
+
+
+def test_fused_sum_of_tiles_the_image_clips_to_an_odd_width():
+    """The tile sums inside the persistent launch index a tile's 16-byte groups by shift and mask; a last tile column that the image clips to a width
+    that is no power of two (96 pixels = 24 groups at N = 256) goes pixel by pixel instead.  Width 608 = 4 x 128 + 96, fused (a multiple of 32)."""
+    from regularizepsf_amd import _native
+
+    n, shape = 256, (512, 608)
+    rng = np.random.default_rng(608)
+    coords = [tuple(int(v) for v in c) for c in rp.calculate_covering(shape, n)]
+    k = (rng.standard_normal((len(coords), n, n)) + 1j * rng.standard_normal((len(coords), n, n))).astype(np.complex64)
+    image = (rng.standard_normal(shape) * 10 + 30).astype(np.float32)
+    plan = _native.Plan(n, coords)
+    plan.set_transfer(k)
+    out = plan.apply(image, _native.PAD_MODES["symmetric"])
+    check(out.astype(np.float64), orc.apply_transfer(image, coords, k))
+    assert np.array_equal(plan.apply(image, _native.PAD_MODES["symmetric"]), out)
