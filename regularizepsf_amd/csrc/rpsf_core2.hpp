@@ -547,15 +547,17 @@ RPSF_HD void load_raw2(int t, cf* v, const ImageView& im, int pr, int pc, bool f
   ThreadPos2<C> tp(t);
   constexpr int NR = 1 << C::A1, NCOL = 1 << C::B1;
   if (__builtin_expect(fast, 1)) {
-    const float* base = im.img + (size_t)(pr - im.row0) * im.ld + pc;
+    // (one row multiplication per thread: the rows of a thread's units are a fixed, workgroup-uniform step apart - v_mul_lo_u32 is a quarter-rate
+    // instruction, and the compiler otherwise spends one per unit row)
+    const float* base = im.img + (size_t)(pr - im.row0) * im.ld + pc + (size_t)tp.r_low * im.ld;
+    const size_t rstep = (size_t)im.ld << (C::A2 + C::AL);
     StaticFor<0, NR>::run([&]<int R1>() RPSF_AI {
-      const int r = (R1 << (C::A2 + C::AL)) + tp.r_low;
       StaticFor<0, NCOL>::run([&]<int C1>() RPSF_AI {
         const int cp = (C1 << C::B2) + tp.c2;
 #if defined(RPSF_DEV_GATHER_NT)  // development: pixel gather with the streaming hint
-        const f32x4 q = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base + (size_t)r * im.ld + 4 * cp));
+        const f32x4 q = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base + R1 * rstep + 4 * cp));
 #else
-        const f32x4 q = *reinterpret_cast<const f32x4*>(base + (size_t)r * im.ld + 4 * cp);
+        const f32x4 q = *reinterpret_cast<const f32x4*>(base + R1 * rstep + 4 * cp);
 #endif
         v[2 * (R1 * NCOL + C1)] = cf{q.x, q.y};
         v[2 * (R1 * NCOL + C1) + 1] = cf{q.z, q.w};
@@ -663,6 +665,8 @@ RPSF_HD void store_patch2(int t, const cf* v, const OutView& pv, const OutView& 
   if (__builtin_expect(fast, 1)) {
     float* prow0 = pbase + (size_t)(pr - pv.row0) * pv.ld + pc;
     float* drow0 = qw ? dv.out + (size_t)(pr - dv.row0) * dv.ld + pc : nullptr;
+    float* const prow_t = prow0 + (size_t)tp.r_low * pv.ld;             // (one row multiplication per thread, as in load_raw2)
+    const size_t pstep = (size_t)pv.ld << (C::A2 + C::AL);
     constexpr int BATCH = 4;  // rows of units whose running sums are in flight together
     StaticFor<0, NR / BATCH>::run([&]<int RB>() RPSF_AI {
       f32x4 old[BATCH * NCOL];
@@ -691,7 +695,7 @@ RPSF_HD void store_patch2(int t, const cf* v, const OutView& pv, const OutView& 
           // of the 16 quadrants of such a group 9 reach a plane
           if (!(((plane == 0 ? 1 : plane == 1 ? 3 : plane == 2 ? 5 : 15) >> QD) & 1)) return;
 #endif
-          pstore4(prow0 + (size_t)r * pv.ld + 4 * cp, val);
+          pstore4(prow_t + R1 * pstep + 4 * cp, val);
         } else if (quad_mode(qw[QD]) == QUAD_DIRECT) {
           val += old[U];
           *reinterpret_cast<f32x4*>(drow0 + (size_t)r * dv.ld + 4 * cp) = val;
