@@ -413,9 +413,12 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
 #if defined(RPSF_DEV_SUM_RUNTIME)  // development: A/B of the tile sums with the run-time choice of plane loads left in
   constexpr bool SUM_KNOWN_FUSED = false;
 #else
-  // (the tile sums of the 128-pixel persistent kernel are compiled for "fused" - no run-time choice of loads in front of each of the 32: config 2 -2 %;
-  // in the 256-pixel kernel the same is worth -0.3 % at 4096^2 and +0.9 % at 8192^2, so it keeps the choice: profiles/r04t)
-  constexpr bool SUM_KNOWN_FUSED = HOT && !C::SPLIT_ROWS;
+  // (the tile sums of the persistent kernels are compiled for "fused" - no run-time choice between two kinds of load in front of each of the 32 of a pass:
+  // config 2 -2 %; in the 256-pixel kernel -1.2 % at 4096^2 and nothing at 8192^2 once the sums index by shift and mask, profiles/r04t, r04aa)
+#if defined(RPSF_DEV_SUM_RUNTIME)  // development: A/B of the tile sums with the run-time choice of plane loads left in
+  constexpr bool SUM_KNOWN_FUSED = false;
+#else
+  constexpr bool SUM_KNOWN_FUSED = HOT;
 #endif
   const bool again = PERSIST && ((blockIdx.x >> 30) & 1u);
 #if defined(RPSF_STAMPS)  // ... and which workgroup this is (its block index at dispatch, kept in LDS across re-entries: stamp 15)
