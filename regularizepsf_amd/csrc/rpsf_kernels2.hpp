@@ -410,9 +410,6 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
 #if defined(RPSF_STAMPS)  // diagnostic builds: when did this pass reach the kernel's first instructions (stamp 14, through an LDS word)
   if (threadIdx.x == 0) *reinterpret_cast<unsigned long long*>(reinterpret_cast<cf*>(smem + Launch2<C>::TABLE_FLOATS) + C::BUF_UNITS + 4) = __builtin_amdgcn_s_memrealtime();
 #endif
-#if defined(RPSF_DEV_SUM_RUNTIME)  // development: A/B of the tile sums with the run-time choice of plane loads left in
-  constexpr bool SUM_KNOWN_FUSED = false;
-#else
   // (the tile sums of the persistent kernels are compiled for "fused" - no run-time choice between two kinds of load in front of each of the 32 of a pass:
   // config 2 -2 %; in the 256-pixel kernel -1.2 % at 4096^2 and nothing at 8192^2 once the sums index by shift and mask, profiles/r04t, r04aa)
 #if defined(RPSF_DEV_SUM_RUNTIME)  // development: A/B of the tile sums with the run-time choice of plane loads left in
