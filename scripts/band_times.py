@@ -26,6 +26,7 @@ ap.add_argument("--steps", type=int, default=60)
 ap.add_argument("--no-overlap", action="store_true")
 ap.add_argument("--worlds", default="1,2,4,8")
 ap.add_argument("--seam", choices=["exchange", "recompute"], default="exchange")
+ap.add_argument("--ranks", default="", help="development sweeps: only these ranks of every world (comma-separated; default all)")
 args = ap.parse_args()
 
 hip = ctypes.CDLL("libamdhip64.so")
@@ -63,7 +64,7 @@ link = LocalLink(128 * w)
 base = None
 for world in [int(v) for v in args.worlds.split(",")]:
     times = []
-    for rank in range(world):
+    for rank in ([r for r in (int(v) for v in args.ranks.split(",")) if r < world] if args.ranks else range(world)):
         sh = ShardedApply(coords, lambda idx: np.resize(kk, (len(idx), n, n)), n, h, w, rank, world, 0, link if world > 1 else None,
                           seam=args.seam, overlap=not args.no_overlap)
         b = sh.band
