@@ -20,6 +20,8 @@
 // swap in l3); only the four self-paired groups need their own path (two threads park them in LDS and wave 0 walks
 // their bin pairs, one pair per lane).
 #pragma once
+#include <algorithm>
+#include <utility>
 #include <vector>
 
 #include "rpsf_core.hpp"
@@ -59,7 +61,13 @@ struct Cfg2 {
   static constexpr int X1_ROWU = 34;  // 32 + 2: rows stay 16-byte aligned and a 16-lane group of b128 reads covers all banks
   static constexpr int X1_WAVE_UNITS = 2 * 32 * X1_ROWU;
   static constexpr int X1_UNITS = WAVES * X1_WAVE_UNITS;
-  static constexpr int X2_UNITS = EA * G;
+  // X2 image: EA planes of 32 rows (register digit j'') x 32 units (lane digit l5'), rows X2_ROWU units apart.  With 33 (34 for the 128-pixel plan)
+  // instead of 32 the bank of a group's unit depends on both digits, which is what lets build_slot_table2 deal the slots so that the
+  // gid-indexed side of the exchange (x2_last_read2 / x2_last_write2) is free of bank conflicts; the lane-indexed side touches runs of
+  // consecutive units either way.  Both fit under the X1 regions' size.
+  static constexpr int X2_ROWU = LOGN_ == 8 ? 33 : 34;
+  static constexpr int X2_G = 32 * X2_ROWU;
+  static constexpr int X2_UNITS = EA * X2_G;
   static constexpr int BUF_UNITS = X1_UNITS > X2_UNITS ? X1_UNITS : X2_UNITS;
   static constexpr int PARK_UNITS = 2 * 2 * E;  // two threads x two groups
   static constexpr int LDS_UNITS = BUF_UNITS + PARK_UNITS;
@@ -89,6 +97,9 @@ RPSF_HD int partner_gid2(int gid) {
   gid_to_qm2<C>(gid, q, m);
   return qm_to_gid2<C>((C::Q - q) & (C::Q - 1), (C::M - m) & (C::M - 1));
 }
+// unit of group gid = (j'' << 5) + l5' inside a plane of the X2 image
+template <class C>
+RPSF_HD int x2_unit(int gid) { return gid + (gid >> 5) * (C::X2_ROWU - 32); }
 enum SlotKind : int { SLOT_GENERAL = 0, SLOT_Q0 = 1, SLOT_M0 = 2, SLOT_SELF = 3 };
 template <class C>
 RPSF_HD int slot_kind2(int gid_a) {
@@ -100,33 +111,249 @@ RPSF_HD int slot_kind2(int gid_a) {
   return SLOT_GENERAL;
 }
 
-// Slot table: tab[(t*NSLOT + s)*2 + member] = gid.  Slot sigma = s*T + t.  The two self-paired slots come first
-// (threads 0 and 1 of slot 0: (0,0)+(Q/2,0) and (0,M/2)+(Q/2,M/2)), then the q = 0 / m = 0 pairs (all inside wave 0's
-// slot 0), then the rest in ascending gid.  Host only.
+// Slot table: tab[(t*NSLOT + s)*2 + member] = gid.  Slot sigma = s*T + t.  The two self-paired slots are threads 0 and 1 of slot 0
+// ((0,0)+(Q/2,0) and (0,M/2)+(Q/2,M/2)), the q = 0 / m = 0 pairs sit in slot 0 of wave 0 (only that wave runs their code).  Host only.
+//
+// Which thread takes which pair, and which group of a pair is member A, is free otherwise - K is folded by the same table (pack_kernel2) -
+// and decides the LDS bank conflicts of the gid-indexed side of the X2 exchange: a ds_read_b64 serves 32 lanes at once from 64 banks, a
+// ds_write_b64 16 lanes from 32, one LDS-array cycle per distinct address on a bank, so the 32 lanes of a half wave want member-A units that
+// differ modulo 32, member-B units likewise, and each run of 16 lanes units that differ modulo 16.  In ascending order of gid (the table until
+// round 4) the reads took 2.8 x and the writes 1.95 x the conflict-free cycles at both sizes - the q = 0 pairs, 31 slots of wave 0, sat on two
+// bank pairs.  deal_slots2 deals the pairs so that every half wave is conflict-free (tests/test_emulator.py counts the cycles):
+//  1. the special pairs go to the two half waves of wave 0 / slot 0, half and orientation chosen depth-first, a branch left as soon as the bank
+//     values still missing in a half cannot be supplied by general pairs (a bipartite matching of bank values);
+//  2. the two halves are completed by such a matching;
+//  3. the remaining pairs form a regular multigraph on the 32 bank values; an Euler orientation makes every value a member-A bank as often as a
+//     member-B bank, and the regular bipartite multigraph (A bank -> B bank) falls apart into perfect matchings - one half wave each;
+//  4. inside a half the 32 slots split into two runs of 16 whose units differ modulo 16 (two-colouring of the union of two perfect matchings).
+namespace slots2 {
+// perfect matching, left vertex i -> adj[i] = (right vertex, tag); result[i] = (right, tag), empty if there is none (Kuhn's augmenting paths)
+inline std::vector<std::pair<int, int>> match(const std::vector<std::vector<std::pair<int, int>>>& adj, int n_right) {
+  const int nl = (int)adj.size();
+  std::vector<int> owner(n_right, -1), tag(n_right, -1);
+  std::vector<char> seen;
+  auto grow = [&](auto&& self, int a) -> bool {
+    for (const auto& [b, e] : adj[a]) {
+      if (seen[b]) continue;
+      seen[b] = 1;
+      if (owner[b] < 0 || self(self, owner[b])) {
+        owner[b] = a, tag[b] = e;
+        return true;
+      }
+    }
+    return false;
+  };
+  for (int a = 0; a < nl; ++a) {
+    seen.assign(n_right, 0);
+    if (!grow(grow, a)) return {};
+  }
+  std::vector<std::pair<int, int>> out(nl);
+  for (int b = 0; b < n_right; ++b)
+    if (owner[b] >= 0) out[owner[b]] = {b, tag[b]};
+  return out;
+}
+}  // namespace slots2
+
+template <class C>
+inline bool deal_slots2(std::vector<std::pair<int, int>>& slots) {
+  using Pair = std::pair<int, int>;
+  constexpr int NB = 32;
+  const int T = C::T, NS = C::NSLOT, nhalves = T * NS / 32;
+  auto bank = [](int g) { return x2_unit<C>(g) & (NB - 1); };
+  std::vector<char> seen(C::G, 0);
+  const Pair selfs[2] = {{qm_to_gid2<C>(0, 0), qm_to_gid2<C>(C::Q / 2, 0)}, {qm_to_gid2<C>(0, C::M / 2), qm_to_gid2<C>(C::Q / 2, C::M / 2)}};
+  for (const Pair& s : selfs) seen[s.first] = seen[s.second] = 1;
+  std::vector<Pair> special, general;
+  for (int g = 0; g < C::G; ++g) {
+    if (seen[g]) continue;
+    const int p = partner_gid2<C>(g);
+    if (p == g) return false;
+    seen[g] = seen[p] = 1;
+    int q, m;
+    gid_to_qm2<C>(g, q, m);
+    (q == 0 || m == 0 ? special : general).push_back({g, p});
+  }
+  if ((int)special.size() + 2 > 64) return false;
+  // general pairs by bank type, either way round: (pair index, swapped)
+  std::vector<Pair> pool[NB][NB];
+  for (int e = 0; e < (int)general.size(); ++e) {
+    const int x = bank(general[e].first), y = bank(general[e].second);
+    pool[x][y].push_back({e, 0});
+    if (x != y) pool[y][x].push_back({e, 1});
+  }
+  std::vector<std::vector<Pair>> halves(2);
+  bool used_a[2][NB] = {}, used_b[2][NB] = {};
+  for (const Pair& s : selfs) {
+    if (used_a[0][bank(s.first)] || used_b[0][bank(s.second)]) return false;
+    halves[0].push_back(s), used_a[0][bank(s.first)] = used_b[0][bank(s.second)] = true;
+  }
+  // (tag of a matched edge: missing A bank * 32 + missing B bank)
+  auto completion = [&](int h) {
+    std::vector<int> mb, ib(NB, -1);
+    for (int y = 0; y < NB; ++y)
+      if (!used_b[h][y]) ib[y] = (int)mb.size(), mb.push_back(y);
+    std::vector<std::vector<Pair>> adj;
+    for (int x = 0; x < NB; ++x) {
+      if (used_a[h][x]) continue;
+      adj.emplace_back();
+      for (int y : mb)
+        if (!pool[x][y].empty()) adj.back().push_back({ib[y], x * NB + y});
+    }
+    return slots2::match(adj, (int)mb.size());
+  };
+  long budget = 200000;  // (both plans finish in a few dozen steps; a bound, so that a configuration without a solution falls back quickly)
+  auto place = [&](auto&& self, int i) -> bool {
+    if (i == (int)special.size()) return true;
+    if (--budget < 0) return false;
+    for (int h = 0; h < 2; ++h) {
+      if (halves[h].size() >= 32) continue;
+      for (int o = 0; o < 2; ++o) {
+        const Pair pr = o ? Pair{special[i].second, special[i].first} : special[i];
+        const int x = bank(pr.first), y = bank(pr.second);
+        if (used_a[h][x] || used_b[h][y]) continue;
+        halves[h].push_back(pr), used_a[h][x] = used_b[h][y] = true;
+        if ((halves[h].size() == 32 || !completion(h).empty()) && self(self, i + 1)) return true;
+        halves[h].pop_back(), used_a[h][x] = used_b[h][y] = false;
+      }
+    }
+    return false;
+  };
+  if (!place(place, 0)) return false;
+  std::vector<char> taken(general.size(), 0);
+  for (int h = 0; h < 2; ++h) {
+    if (halves[h].size() == 32) continue;
+    const auto ml = completion(h);
+    if (ml.empty()) return false;
+    for (const auto& [b, tag] : ml) {
+      const int x = tag / NB, y = tag % NB;
+      bool found = false;
+      for (const auto& [e, sw] : pool[x][y]) {
+        if (taken[e]) continue;
+        taken[e] = 1, found = true;
+        halves[h].push_back(sw ? Pair{general[e].second, general[e].first} : general[e]);
+        break;
+      }
+      if (!found) return false;
+    }
+  }
+  // the rest: Euler orientation on the bank values ...
+  std::vector<Pair> rest;
+  for (int e = 0; e < (int)general.size(); ++e)
+    if (!taken[e]) rest.push_back(general[e]);
+  std::vector<std::vector<int>> inc(NB);
+  for (int e = 0; e < (int)rest.size(); ++e) {
+    inc[bank(rest[e].first)].push_back(e);
+    if (bank(rest[e].second) != bank(rest[e].first)) inc[bank(rest[e].second)].push_back(e);
+  }
+  std::vector<char> done(rest.size(), 0);
+  std::vector<size_t> ptr(NB, 0);
+  for (int start = 0; start < NB; ++start)
+    for (;;) {
+      int v = start;
+      bool moved = false;
+      for (;;) {
+        while (ptr[v] < inc[v].size() && done[inc[v][ptr[v]]]) ++ptr[v];
+        if (ptr[v] == inc[v].size()) break;
+        const int e = inc[v][ptr[v]];
+        if (bank(rest[e].first) != v) std::swap(rest[e].first, rest[e].second);
+        done[e] = 1, v = bank(rest[e].second), moved = true;
+      }
+      if (!moved) break;
+    }
+  int deg_a[NB] = {}, deg_b[NB] = {};
+  for (const Pair& pr : rest) ++deg_a[bank(pr.first)], ++deg_b[bank(pr.second)];
+  for (int x = 0; x < NB; ++x)
+    if (deg_a[x] != nhalves - 2 || deg_b[x] != nhalves - 2) return false;
+  // ... and one perfect matching per remaining half wave
+  std::vector<char> gone(rest.size(), 0);
+  for (int k = 2; k < nhalves; ++k) {
+    std::vector<std::vector<Pair>> adj(NB);
+    for (int e = 0; e < (int)rest.size(); ++e)
+      if (!gone[e]) adj[bank(rest[e].first)].push_back({bank(rest[e].second), e});
+    const auto ml = slots2::match(adj, NB);
+    if (ml.empty()) return false;
+    halves.emplace_back();
+    for (const auto& [b, e] : ml) halves.back().push_back(rest[e]), gone[e] = 1;
+  }
+  // runs of 16 lanes
+  slots.assign((size_t)T * NS, Pair{-1, -1});
+  for (int hi = 0; hi < nhalves; ++hi) {
+    const std::vector<Pair>& hv = halves[hi];
+    if (hv.size() != 32) return false;
+    std::vector<int> nb[32];
+    for (int member = 0; member < 2; ++member) {
+      int first[16];
+      for (int& f : first) f = -1;
+      for (int i = 0; i < 32; ++i) {
+        const int r = bank(member ? hv[i].second : hv[i].first) & 15;
+        if (first[r] < 0) first[r] = i;
+        else nb[first[r]].push_back(i), nb[i].push_back(first[r]);
+      }
+    }
+    int col[32];
+    for (int& c : col) c = -1;
+    for (int s0 = 0; s0 < 32; ++s0) {
+      if (col[s0] >= 0) continue;
+      col[s0] = 0;
+      std::vector<int> st{s0};
+      while (!st.empty()) {
+        const int x = st.back();
+        st.pop_back();
+        for (int y : nb[x])
+          if (col[y] < 0) col[y] = 1 - col[x], st.push_back(y);
+      }
+    }
+    std::vector<int> run[2];
+    for (int i = 0; i < 32; ++i) run[col[i]].push_back(i);
+    if (hi == 0) {  // lanes 0 and 1 are the self-paired slots (entries 0 and 1), whatever that costs the first run
+      if (col[0] == 1) std::swap(run[0], run[1]);
+      auto it = std::find(run[1].begin(), run[1].end(), 1);
+      if (it != run[1].end()) {
+        run[1].erase(it);
+        int sw = -1;
+        for (int i : run[0])
+          if (i > 1) sw = i;
+        run[0].erase(std::find(run[0].begin(), run[0].end(), sw));
+        run[0].push_back(1), run[1].push_back(sw);
+      }
+      std::vector<int> r0{0, 1};
+      for (int i : run[0])
+        if (i > 1) r0.push_back(i);
+      run[0] = r0;
+    }
+    if (run[0].size() != 16 || run[1].size() != 16) return false;
+    const int s = hi / (2 * (T / 64)), w = hi % (2 * (T / 64)) / 2, hb = hi & 1;
+    for (int l = 0; l < 32; ++l) slots[(size_t)s * T + w * 64 + hb * 32 + l] = hv[l < 16 ? run[0][l] : run[1][l - 16]];
+  }
+  return true;
+}
+
 template <class C>
 inline void build_slot_table2(uint16_t* tab) {
-  const int G = C::G;
-  std::vector<char> seen(G, 0);
-  std::vector<int> slots;
-  auto push = [&](int a, int b) {
-    slots.push_back(a), slots.push_back(b);
-    seen[a] = seen[b] = 1;
-  };
-  push(qm_to_gid2<C>(0, 0), qm_to_gid2<C>(C::Q / 2, 0));
-  push(qm_to_gid2<C>(0, C::M / 2), qm_to_gid2<C>(C::Q / 2, C::M / 2));
-  for (int pass = 0; pass < 2; ++pass)
-    for (int g = 0; g < G; ++g) {
-      if (seen[g]) continue;
-      int q, m;
-      gid_to_qm2<C>(g, q, m);
-      if (pass == 0 && q != 0 && m != 0) continue;
-      push(g, partner_gid2<C>(g));
-    }
-  const int ns = (int)slots.size() / 2;
-  for (int sigma = 0; sigma < ns; ++sigma) {
+  std::vector<std::pair<int, int>> slots;
+  if (!deal_slots2<C>(slots)) {  // (not reached by the plans in use: any order with the special slots in wave 0 is correct, only slower)
+    const int G = C::G;
+    std::vector<char> seen(G, 0);
+    slots.clear();
+    auto push = [&](int a, int b) {
+      slots.push_back({a, b});
+      seen[a] = seen[b] = 1;
+    };
+    push(qm_to_gid2<C>(0, 0), qm_to_gid2<C>(C::Q / 2, 0));
+    push(qm_to_gid2<C>(0, C::M / 2), qm_to_gid2<C>(C::Q / 2, C::M / 2));
+    for (int pass = 0; pass < 2; ++pass)
+      for (int g = 0; g < G; ++g) {
+        if (seen[g]) continue;
+        int q, m;
+        gid_to_qm2<C>(g, q, m);
+        if (pass == 0 && q != 0 && m != 0) continue;
+        push(g, partner_gid2<C>(g));
+      }
+  }
+  for (int sigma = 0; sigma < (int)slots.size(); ++sigma) {
     const int s = sigma / C::T, t = sigma % C::T;
-    tab[(t * C::NSLOT + s) * 2 + 0] = (uint16_t)slots[2 * sigma];
-    tab[(t * C::NSLOT + s) * 2 + 1] = (uint16_t)slots[2 * sigma + 1];
+    tab[(t * C::NSLOT + s) * 2 + 0] = (uint16_t)slots[sigma].first;
+    tab[(t * C::NSLOT + s) * 2 + 1] = (uint16_t)slots[sigma].second;
   }
 }
 template <class C>
@@ -277,27 +504,27 @@ RPSF_HD void x1_read2(int t, cf* v, const cf* lds) {
 template <class C, int H>
 RPSF_HD void x2_mid_write2(int t, const cf* v, cf* lds) {
   ThreadPos2<C> tp(t);
-  cf* base = lds + tp.r3 * C::G + tp.l5;
-  StaticFor<0, 32>::run([&]<int J>() RPSF_AI { base[J * 32] = v[2 * J + H]; });
+  cf* base = lds + tp.r3 * C::X2_G + tp.l5;
+  StaticFor<0, 32>::run([&]<int J>() RPSF_AI { base[J * C::X2_ROWU] = v[2 * J + H]; });
 }
 template <class C, int H>
 RPSF_HD void x2_mid_read2(int t, cf* v, const cf* lds) {
   ThreadPos2<C> tp(t);
-  const cf* base = lds + tp.r3 * C::G + tp.l5;
-  StaticFor<0, 32>::run([&]<int J>() RPSF_AI { v[2 * J + H] = base[J * 32]; });
+  const cf* base = lds + tp.r3 * C::X2_G + tp.l5;
+  StaticFor<0, 32>::run([&]<int J>() RPSF_AI { v[2 * J + H] = base[J * C::X2_ROWU]; });
 }
 template <class C, int H>
 RPSF_HD void x2_last_read2(const GroupIds<C>& gids, cf* v, const cf* lds) {
   StaticFor<0, C::P>::run([&]<int GI>() RPSF_AI {
-    const cf* base = lds + gids[GI];
-    StaticFor<0, C::EA>::run([&]<int R3>() RPSF_AI { v[GI * C::E + 2 * R3 + H] = base[R3 * C::G]; });
+    const cf* base = lds + x2_unit<C>(gids[GI]);
+    StaticFor<0, C::EA>::run([&]<int R3>() RPSF_AI { v[GI * C::E + 2 * R3 + H] = base[R3 * C::X2_G]; });
   });
 }
 template <class C, int H>
 RPSF_HD void x2_last_write2(const GroupIds<C>& gids, const cf* v, cf* lds) {
   StaticFor<0, C::P>::run([&]<int GI>() RPSF_AI {
-    cf* base = lds + gids[GI];
-    StaticFor<0, C::EA>::run([&]<int R3>() RPSF_AI { base[R3 * C::G] = v[GI * C::E + 2 * R3 + H]; });
+    cf* base = lds + x2_unit<C>(gids[GI]);
+    StaticFor<0, C::EA>::run([&]<int R3>() RPSF_AI { base[R3 * C::X2_G] = v[GI * C::E + 2 * R3 + H]; });
   });
 }
 

@@ -138,3 +138,21 @@ extern "C" int emu2_apply(int N, int n_patches, const int32_t* coords, int H, in
     default: return -1;
   }
 }
+
+// The slot table the plan uploads and the X2 image's geometry, for the bank-conflict count of tests/test_emulator.py:
+// tab[(t*nslot + s)*2 + member] = gid (2 * threads * nslot entries), units[gid] = 8-byte unit of the group inside a plane of the image.
+template <class C>
+static int emu2_slot_table_t(uint16_t* tab, int32_t* units, int* threads, int* nslot, int* dealt) {
+  build_slot_table2<C>(tab);
+  for (int g = 0; g < C::G; ++g) units[g] = x2_unit<C>(g);
+  std::vector<std::pair<int, int>> slots;
+  *threads = C::T, *nslot = C::NSLOT, *dealt = deal_slots2<C>(slots) ? 1 : 0;
+  return 0;
+}
+extern "C" int emu2_slot_table(int N, uint16_t* tab, int32_t* units, int* threads, int* nslot, int* dealt) {
+  switch (N) {
+    case 256: return emu2_slot_table_t<Cfg256v2>(tab, units, threads, nslot, dealt);
+    case 128: return emu2_slot_table_t<Cfg128v2>(tab, units, threads, nslot, dealt);
+    default: return -1;
+  }
+}
