@@ -57,3 +57,10 @@ per = np.array([np.sum((start >= lo) & (start < lo + 10)) for lo in range(0, int
 print("patch starts per 10 us:", " ".join(str(int(x)) for x in per))
 pe = np.array([np.sum((end >= lo) & (end < lo + 10)) for lo in range(0, int(end[-1]) + 10, 10)])
 print("patch ends per 10 us:  ", " ".join(str(int(x)) for x in pe))
+# rim patches (hang over an image edge: gathered through the np.pad index maps, stored through the clipped path) against interior ones
+cc = np.array(coords)
+rim = (cc[:, 0] < 0) | (cc[:, 1] < 0) | (cc[:, 0] + n > size) | (cc[:, 1] + n > size)
+tot_p = (st[:, last] - st[:, 0]) * 0.01
+print(f"rim patches {int(rim.sum())} of {len(rim)}: stamp 0 -> {last} mean {tot_p[rim].mean():.2f} us against {tot_p[~rim].mean():.2f} us for interior ones")
+for i, nm in enumerate(names):
+    print(f"  {nm:18s} rim {d[rim, i].mean():6.2f}  interior {d[~rim, i].mean():6.2f} us")
