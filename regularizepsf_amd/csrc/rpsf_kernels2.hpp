@@ -586,7 +586,13 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
     if (t + T < N) tw[t + T] = tw1, win[t + T] = wn1;
     if (t < Launch2<C>::OT_WORDS) ot[t] = ot0;
   }
-  lds_barrier();  // tables staged; the maps (which share LDS with the exchange buffer) are no longer needed
+  // tables staged; the maps (which share LDS with the exchange buffer) are no longer needed.  (A re-entered pass over an interior patch has
+  // neither to wait for: its first LDS operations are wave-local, and the previous pass ended with a barrier.)
+#if defined(RPSF_DEV_X1_BARRIERS)  // development: A/B against the ten-barrier pass of rounds 2-4
+  lds_barrier();
+#else
+  if (!(PERSIST && again && fast)) lds_barrier();  // (workgroup-uniform)
+#endif
 #if defined(RPSF_DEV_CARRY) || defined(RPSF_STAMPS)  // the workgroup's block index at dispatch, kept in an unused word of the bin-pair table
   if (PERSIST && !again && t == 0) ot[Launch2<C>::OT_WORDS - 1] = blockIdx.x & 0x3fffffffu;
 #endif
@@ -675,15 +681,19 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
     const cf* gs = p.gs + (size_t)kpatch * C::GS_PER_PATCH;
     StaticFor<0, C::ORBIT_ROUNDS>::run([&]<int R>() RPSF_AI { load_stream16(gs + (size_t)(R * 64 + t) * 2, ko[2 * R], ko[2 * R + 1]); });
   }
-  ABL_BAR();  // every wave has left its X1 region (X2 uses the whole buffer)
+  // No barrier between X1 and X2: a wave's X1 region IS its own two planes of the X2 image (Cfg2::X1_OWN_ROWS), which only its own
+  // x2_mid_write2 touches - its DS operations complete in order.
+#if defined(RPSF_DEV_X1_BARRIERS)
+  ABL_BAR();
+#endif
+  ABL_LDS(x2_mid_write2<C, 0>(t, v, lds));
+  ABL_VALU(stage2h<C, 1, false>(t, v, tw));
+  ABL_BAR();
   if constexpr (PERSIST) {
     // every wave has its pixels, so - VMEM returns in order - the plane stores of the workgroup's previous patch, issued
     // ahead of them, are acknowledged: that patch can be counted on its tiles
     if (again) count_previous();
   }
-  ABL_LDS(x2_mid_write2<C, 0>(t, v, lds));
-  ABL_VALU(stage2h<C, 1, false>(t, v, tw));
-  ABL_BAR();
   ABL_LDS(x2_last_read2<C, 0>(gids, v, lds));
   ABL_BAR();
   ABL_LDS(x2_mid_write2<C, 1>(t, v, lds));
@@ -765,7 +775,10 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
       if (tu < 4) reinterpret_cast<unsigned*>(park)[1 + tu] = (unsigned)frame * p.n_tiles + quad_tile(qword);  // (this frame's counters)
     }
   }
-  ABL_BAR();  // X1 regions alias the X2 image
+  // (no barrier: the wave's X1 region is the planes it has just read, see above)
+#if defined(RPSF_DEV_X1_BARRIERS)
+  ABL_BAR();
+#endif
   if constexpr (MID_DRAW) draw_next();
   // DESC_AHEAD: wave 0 knows the drawn position (its lane 0 holds it) and fetches the next slot's descriptor through the scalar cache now; the
   // value is first touched in front of the stores, a stage and a half later (a use right here would put the load's round trip on the chain).
