@@ -64,16 +64,14 @@ struct Cfg2 {
   // gid-indexed side of the exchange (x2_last_read2 / x2_last_write2) is free of bank conflicts; the lane-indexed side touches runs of
   // consecutive units either way.  Both fit under the X1 regions' size.
   static constexpr int X2_ROWU = LOGN_ == 8 ? 33 : 34;
-  static constexpr int X2_G = 32 * X2_ROWU;
-  static constexpr int X2_UNITS = EA * X2_G;
-  // X1 region of wave w (64 rows of X1_ROWU units): the wave's OWN two planes of the X2 image, r3 = 2w and 2w + 1 - the planes only its own
+  // A plane is X2_G = 32 x 34 units long whatever the row step, so that two planes are exactly one wave's X1 region:
+  // X1 region of wave w (64 rows of X1_ROWU units) = the wave's OWN two planes of the X2 image, r3 = 2w and 2w + 1 - the planes only its own
   // x2_mid_write2 / x2_mid_read2 touch - so that a wave goes from X1 to X2 and back without a workgroup barrier (two of the ten barriers of a
-  // pass until round 4).  Two planes of 33-unit rows hold 62 of the 64 rows; the other two live behind the image, at an offset that keeps the
-  // b128 reads of a 16-lane group on distinct banks (unit = 28 modulo 32: the bank slots rows 62 and 63 would have had).
-  static constexpr int X1_OWN_ROWS = 2 * X2_G / X1_ROWU < 64 ? 2 * X2_G / X1_ROWU : 64;
-  static constexpr int X1_TAIL_ROWS = 64 - X1_OWN_ROWS, X1_TAIL_PAD = 28, X1_TAIL_STRIDE = 96;
-  static_assert(X1_TAIL_ROWS * X1_ROWU <= X1_TAIL_STRIDE && X2_UNITS % 32 == 0, "tail rows of a wave");
-  static constexpr int BUF_UNITS = X2_UNITS + (X1_TAIL_ROWS ? X1_TAIL_PAD + (WAVES - 1) * X1_TAIL_STRIDE + X1_TAIL_ROWS * X1_ROWU : 0);
+  // pass until round 4).
+  static constexpr int X2_G = 32 * X1_ROWU;
+  static_assert(X2_G >= 32 * X2_ROWU && X2_G % 32 == 0, "rows of a plane; a unit's bank must not depend on the plane");
+  static constexpr int X2_UNITS = EA * X2_G;
+  static constexpr int BUF_UNITS = X2_UNITS;
   static constexpr int PARK_UNITS = 2 * 2 * E;  // two threads x two groups
   static constexpr int LDS_UNITS = BUF_UNITS + PARK_UNITS;
   static constexpr float SCALE = 1.0f / (2.0f * (float)N * (float)N);  // 1/4 (pair algebra) * 1/(N*N/2) (inverse DFT)
@@ -490,28 +488,16 @@ RPSF_HD void stage2h(int t, cf* v, const cf* __restrict__ tw) {
 // ------------------------------------------------------------------------------------------
 // LDS exchanges of half H (lds in 8-byte units)
 // ------------------------------------------------------------------------------------------
-// first unit of row rho (0 ... 63: hb * 32 + row of the half wave) of wave's X1 region, see Cfg2::X1_OWN_ROWS
-template <class C>
-RPSF_HD int x1_row_unit(int wave, int rho) {
-  const int own = wave * 2 * C::X2_G + rho * C::X1_ROWU;
-  if constexpr (C::X1_TAIL_ROWS == 0) return own;
-  else return rho < C::X1_OWN_ROWS ? own : C::X2_UNITS + C::X1_TAIL_PAD + wave * C::X1_TAIL_STRIDE + (rho - C::X1_OWN_ROWS) * C::X1_ROWU;
-}
 template <class C, int H>
 RPSF_HD void x1_write2(int t, const cf* v, cf* lds) {
   ThreadPos2<C> tp(t);
-  cf* base = lds + tp.wave * 2 * C::X2_G + tp.hb * (32 * C::X1_ROWU) + tp.l5;  // row hb * 32 + J at + J * X1_ROWU ...
-  // ... but for the last rows of the second half wave (one select per call)
-  [[maybe_unused]] cf* tail = tp.hb ? lds + C::X2_UNITS + C::X1_TAIL_PAD + tp.wave * C::X1_TAIL_STRIDE + (32 - C::X1_OWN_ROWS) * C::X1_ROWU + tp.l5 : base;
-  StaticFor<0, 32>::run([&]<int J>() RPSF_AI {
-    if constexpr (32 + J < C::X1_OWN_ROWS) base[J * C::X1_ROWU] = v[2 * J + H];
-    else tail[J * C::X1_ROWU] = v[2 * J + H];
-  });
+  cf* base = lds + tp.wave * (2 * C::X2_G) + tp.hb * (32 * C::X1_ROWU) + tp.l5;  // (the wave's own two planes of the X2 image, see Cfg2::X2_G)
+  StaticFor<0, 32>::run([&]<int J>() RPSF_AI { base[J * C::X1_ROWU] = v[2 * J + H]; });
 }
 template <class C, int H>
 RPSF_HD void x1_read2(int t, cf* v, const cf* lds) {
   ThreadPos2<C> tp(t);
-  const cf2* row = reinterpret_cast<const cf2*>(lds + x1_row_unit<C>(tp.wave, tp.hb * 32 + tp.l5));
+  const cf2* row = reinterpret_cast<const cf2*>(lds + tp.wave * (2 * C::X2_G) + tp.hb * (32 * C::X1_ROWU) + tp.l5 * C::X1_ROWU);
   StaticFor<0, 16>::run([&]<int K>() RPSF_AI {
     const cf2 u = row[K];
     v[2 * (2 * K) + H] = u.a;
