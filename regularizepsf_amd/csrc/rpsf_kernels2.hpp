@@ -568,6 +568,9 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   const bool fast = patch_inside2<C>(pr, pc, im.H, im.W, im.row0, im.rows) && quads_aligned(im.img, im.ld, pc);
   int* maps = reinterpret_cast<int*>(lds);
   if (!fast) {
+#if defined(RPSF_DEV_NO_END_BARRIER)  // (the maps overlay wave 0's X1 region, which a pass that ended without a barrier may still be reading)
+    if (PERSIST && again) lds_barrier();
+#endif
     build_pad_maps<C>(t, maps, im, pr, pc);
     lds_barrier();
   }
@@ -614,6 +617,13 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   constexpr bool MID_DRAW = false;
 #else
   constexpr bool MID_DRAW = PERSIST && !EARLY_DRAW && !C::WIDE && !C::HALF;
+#endif
+  // (development, -DRPSF_DEV_NO_END_BARRIER: the pass ends without a barrier - the park words are in LDS before the last barrier of the inverse exchange -
+  // so that from there to the first exchange barrier of the next pass every wave runs on its own)
+#if defined(RPSF_DEV_NO_END_BARRIER)
+  constexpr bool END_BARRIER = !EARLY_DRAW;
+#else
+  constexpr bool END_BARRIER = true;
 #endif
   unsigned drawn = 0, qword = 0;  // (one register each: lane tu < 4 holds the word of its own tile)
   [[maybe_unused]] int4 ndsc = make_int4(0, 0, 0, 0);  // DESC_AHEAD: the next slot's descriptor (wave 0, scalar) and the slot it belongs to + 1
@@ -767,14 +777,17 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   ABL_BAR();
   ABL_LDS(x2_last_write2<C, 1>(gids, v, lds));
   ABL_VALU(stage2h<C, 0, true>(t, v, tw));
-  ABL_BAR();
-  ABL_LDS(x2_mid_read2<C, 1>(t, v, lds));
-  if constexpr (EARLY_DRAW) {  // (park: idle since the frequency step; the previous pass's words were read by count_previous long ago)
+  // (park: idle since the frequency step; the previous pass's words were read by count_previous long ago)
+  auto park_draw = [&]() RPSF_AI {
     if (HOT || p.tile_done) {
       if (tu == 0) *reinterpret_cast<unsigned*>(park) = drawn;
       if (tu < 4) reinterpret_cast<unsigned*>(park)[1 + tu] = (unsigned)frame * p.n_tiles + quad_tile(qword);  // (this frame's counters)
     }
-  }
+  };
+  if constexpr (EARLY_DRAW && !END_BARRIER) park_draw();  // in front of the LAST barrier of the pass: every wave may read the words behind it
+  ABL_BAR();
+  ABL_LDS(x2_mid_read2<C, 1>(t, v, lds));
+  if constexpr (EARLY_DRAW && END_BARRIER) park_draw();
   // (no barrier: the wave's X1 region is the planes it has just read, see above)
 #if defined(RPSF_DEV_X1_BARRIERS)
   ABL_BAR();
@@ -920,7 +933,7 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
         if (tu == 0) *reinterpret_cast<unsigned*>(park) = drawn;  // (park: idle since the frequency step)
         if (tu < 4) reinterpret_cast<unsigned*>(park)[1 + tu] = (unsigned)frame * p.n_tiles + quad_tile(qword);  // (this frame's counters)
       }
-      lds_barrier();
+      if constexpr (END_BARRIER) lds_barrier();
       STAMP(12);
       const unsigned nx = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const unsigned*>(park));
       const int left = p.n_patches - (pb & 7) * p.chunk;  // slots of this XCD's chunk that hold a patch (x frames: queue positions)
