@@ -73,7 +73,8 @@ struct Cfg2 {
   static constexpr int X2_UNITS = EA * X2_G;
   static constexpr int BUF_UNITS = X2_UNITS;
   static constexpr int PARK_UNITS = 2 * 2 * E;  // two threads x two groups
-  static constexpr int LDS_UNITS = BUF_UNITS + PARK_UNITS;
+  static constexpr int SYNC_UNITS = 4;  // eight words behind the park area: arrival counters of the split barriers (rpsf_kernels2.hpp, RPSF_SPLIT_BARRIERS)
+  static constexpr int LDS_UNITS = BUF_UNITS + PARK_UNITS + SYNC_UNITS;
   static constexpr float SCALE = 1.0f / (2.0f * (float)N * (float)N);  // 1/4 (pair algebra) * 1/(N*N/2) (inverse DFT)
 };
 

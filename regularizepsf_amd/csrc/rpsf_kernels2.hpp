@@ -39,6 +39,12 @@ __device__ __forceinline__ f32x4 load16_sc1(const float* base, size_t span_bytes
 #else
 #define ABL_VALU(...) __VA_ARGS__
 #endif
+// (RPSF2_ABL_NOBAR_MASK: timing builds without some of the six exchange barriers of a pass - bit i = barrier i of ABL_BARI(i), 2 ... 7; results wrong)
+#if defined(RPSF2_ABL_NOBAR_MASK)
+#define ABL_BARI(i) do { if constexpr (!((RPSF2_ABL_NOBAR_MASK >> (i)) & 1)) lds_barrier(); } while (0)
+#else
+#define ABL_BARI(i) ABL_BAR()
+#endif
 #if defined(RPSF2_ABL_NOBAR)
 #define ABL_BAR() ((void)0)
 #else
@@ -467,6 +473,29 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   }
   cf* const lds = reinterpret_cast<cf*>(smem + Launch2<C>::TABLE_FLOATS);
   cf* const park = lds + C::BUF_UNITS;
+  // Split barriers (development, -DRPSF_SPLIT_BARRIERS; 256-pixel persistent kernel): where arithmetic that does not depend on the exchange sits between a
+  // wave's LDS writes and its next LDS reads, the wave ARRIVES (one LDS atomic, in order behind its writes) before that arithmetic and WAITS (polls the
+  // counter) behind it, instead of an s_barrier behind it - a wave that is slow in the arithmetic no longer holds up the others, who only need its writes.
+  // Counter k counts arrivals for ever; a generation is WAVES arrivals, and no wave can arrive for the next one before it has seen this one complete.
+#if defined(RPSF_SPLIT_BARRIERS)
+  constexpr bool SPLITB = PERSIST && C::SPLIT_ROWS && !C::WIDE && !C::HALF;
+#else
+  constexpr bool SPLITB = false;
+#endif
+  [[maybe_unused]] unsigned* const sync = reinterpret_cast<unsigned*>(park + C::PARK_UNITS);
+  [[maybe_unused]] auto arrive = [&](int k) RPSF_AI -> unsigned {
+    unsigned old = 0;
+    asm volatile("" ::: "memory");
+    if ((tu & 63) == 0) old = __hip_atomic_fetch_add(sync + k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+    return old;
+  };
+  [[maybe_unused]] auto await = [&](int k, unsigned old) RPSF_AI {
+    const unsigned target = (__builtin_amdgcn_readfirstlane(old) & ~(unsigned)(C::WAVES - 1)) + (unsigned)C::WAVES;
+    while ((int)(__builtin_amdgcn_readfirstlane(__hip_atomic_load(sync + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) - target) < 0)
+      __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+  };
   // persistent form: the previous patch of this workgroup is counted on its tiles once its plane stores have drained
   [[maybe_unused]] auto count_previous = [&]() RPSF_AI {
     if (tu < (C::HALF ? 2 : 4)) __hip_atomic_fetch_add(p.tile_done + reinterpret_cast<const unsigned*>(park)[1 + t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -585,6 +614,9 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   load_raw2<C, HOT>(t, v, im, pr, pc, fast, maps);
 #endif
   if (!again) {
+    if constexpr (SPLITB) {
+      if (tu < 8) sync[tu] = 0;
+    }
     if (t < N) tw[t] = tw0, win[t] = wn0;
     if (t + T < N) tw[t + T] = tw1, win[t + T] = wn1;
     if (t < Launch2<C>::OT_WORDS) ot[t] = ot0;
@@ -697,18 +729,25 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   ABL_BAR();
 #endif
   ABL_LDS(x2_mid_write2<C, 0>(t, v, lds));
+  [[maybe_unused]] unsigned arrived = 0;
+  if constexpr (SPLITB) arrived = arrive(2);
   ABL_VALU(stage2h<C, 1, false>(t, v, tw));
-  ABL_BAR();
+  if constexpr (SPLITB) await(2, arrived);
+  else
+  ABL_BARI(2);
   if constexpr (PERSIST) {
     // every wave has its pixels, so - VMEM returns in order - the plane stores of the workgroup's previous patch, issued
     // ahead of them, are acknowledged: that patch can be counted on its tiles
     if (again) count_previous();
   }
   ABL_LDS(x2_last_read2<C, 0>(gids, v, lds));
-  ABL_BAR();
+  ABL_BARI(3);
   ABL_LDS(x2_mid_write2<C, 1>(t, v, lds));
+  if constexpr (SPLITB) arrived = arrive(4);
   if constexpr (C::SPLIT_ROWS) ABL_VALU(stage3_rows<C, false, 0, 0>(t, gids, v));  // the row DFTs of the half that has arrived, under the exchange of the other
-  ABL_BAR();
+  if constexpr (SPLITB) await(4, arrived);
+  else
+  ABL_BARI(4);
   ABL_LDS(x2_last_read2<C, 1>(gids, v, lds));
   // no barrier: every X2 unit is read by exactly one thread, the same one that rewrites it below
 #if defined(RPSF_KSTAGE2)
@@ -771,11 +810,15 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   if constexpr (EARLY_DRAW) draw_next();
   // ---- inverse ----
   ABL_LDS(x2_last_write2<C, 0>(gids, v, lds));
+  if constexpr (SPLITB) arrived = arrive(5);
   if constexpr (C::SPLIT_ROWS) ABL_VALU(stage3_rows<C, true, 1, 0>(t, gids, v));
-  ABL_BAR();
+  if constexpr (SPLITB) await(5, arrived);
+  else
+  ABL_BARI(5);
   ABL_LDS(x2_mid_read2<C, 0>(t, v, lds));
-  ABL_BAR();
+  ABL_BARI(6);
   ABL_LDS(x2_last_write2<C, 1>(gids, v, lds));
+  if constexpr (SPLITB) arrived = arrive(7);
   ABL_VALU(stage2h<C, 0, true>(t, v, tw));
   // (park: idle since the frequency step; the previous pass's words were read by count_previous long ago)
   auto park_draw = [&]() RPSF_AI {
@@ -785,7 +828,9 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
     }
   };
   if constexpr (EARLY_DRAW && !END_BARRIER) park_draw();  // in front of the LAST barrier of the pass: every wave may read the words behind it
-  ABL_BAR();
+  if constexpr (SPLITB) await(7, arrived);
+  else
+  ABL_BARI(7);
   ABL_LDS(x2_mid_read2<C, 1>(t, v, lds));
   if constexpr (EARLY_DRAW && END_BARRIER) park_draw();
   // (no barrier: the wave's X1 region is the planes it has just read, see above)
