@@ -118,6 +118,7 @@ struct rpsf_plan {
   bool fuse_pays = false;            // the second-generation plans (N = 128, 256)
   // Persistent patch workgroups (patch_kernel2_256p; fused launches of the 256-pixel plan): per-XCD slot queues, never reset
   bool persist = false;
+  bool k_cached = false;             // 128-pixel persistent launches take patch_kernel2_128pc (plain loads of the pair words): see rpsf_plan_create
 #if defined(RPSF_DEV_SPLIT)  // development: the split-patch timing skeleton (k2_256s.hip) and its tables
   bool dev_split = false;
   uint16_t* d_tab_s = nullptr;
@@ -616,9 +617,16 @@ extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int
       if (N == 256)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_kernel2_256p), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)Launch2<Cfg256v2>::LDS_BYTES));
-      else
+      else {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_kernel2_128p), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)Launch2<Cfg128v2>::LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_kernel2_128pc), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)Launch2<Cfg128v2>::LDS_BYTES));
+        // Plain instead of streaming loads of the pair words where the plan's K (66,560 B per patch) fits the 256 MiB Infinity Cache beside the
+        // planes: measured (profiles/r04av) -6 % per apply at 72 MB of K, +6.6 % at 160 MB; RPSF_K_CACHED=0/1 overrides (tests run both forms).
+        p->k_cached = (size_t)n_patches * Cfg128v2::G_PER_PATCH * sizeof(cf) <= ((size_t)96 << 20);
+        if (const char* e = std::getenv("RPSF_K_CACHED")) p->k_cached = std::atoi(e) != 0;
+      }
     }
 #if defined(RPSF_VGPR_CAP)  // (development builds only: the product's patch kernel takes all 512 registers of a SIMD lane)
     p->cosum = p->persist && std::getenv("RPSF_COSUM") != nullptr;
@@ -1028,7 +1036,10 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
               patch_kernel2_256w<<<dim3((unsigned)wgs), dim3(1024), Launch2<Cfg256v2>::LDS_BYTES, st>>>(pp);
             } else
 #endif
-            PersistentKernel2<C>::fn<<<dim3((unsigned)wgs), dim3(Launch2<C>::WG), Launch2<C>::LDS_BYTES, st>>>(pp);
+            if (p->k_cached)
+              PersistentKernel2<C>::fn_k_cached<<<dim3((unsigned)wgs), dim3(Launch2<C>::WG), Launch2<C>::LDS_BYTES, st>>>(pp);
+            else
+              PersistentKernel2<C>::fn<<<dim3((unsigned)wgs), dim3(Launch2<C>::WG), Launch2<C>::LDS_BYTES, st>>>(pp);
             HIP_TRY(hipGetLastError());
             if (ncos) {  // ... and the apply is complete on `st` when they are
 #if defined(RPSF_VGPR_CAP)

@@ -118,6 +118,17 @@ RPSF_HD void load_stream16(const void* p, cf& a, cf& b) {
   a = cf{q.x, q.y};
   b = cf{q.z, q.w};
 }
+// the pair words of K: streamed (nontemporal) where a launch's K would push everything else out of the caches, plain where it fits beside the rest
+// and the next apply - or the next frame of a batch - finds it there (rpsf.hip, k_cached)
+template <bool NT>
+RPSF_HD void load_k16(const void* p, cf& a, cf& b) {
+  if constexpr (NT) load_stream16(p, a, b);
+  else {
+    const f32x4 q = *reinterpret_cast<const f32x4*>(p);
+    a = cf{q.x, q.y};
+    b = cf{q.z, q.w};
+  }
+}
 RPSF_HD void store_stream8(void* p, cf v) {
   f32x2 q = {v.x, v.y};
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(RPSF_NO_NT)

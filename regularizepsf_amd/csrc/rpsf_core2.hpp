@@ -576,7 +576,7 @@ RPSF_HD void stage3_cols(cf* v) {
 
 // K words: word w of thread t at cf index (w*T + t)*2 - (K'_h(p), K'_h(p + (0,N/2))) for p = bin e of member A of slot
 // w / E, e = w % E (every slot, the modulated ones included).
-template <class C, int CI>
+template <class C, int CI, bool NT = true>
 RPSF_HD void load_k_chunk2(int t, cf* k, const cf* __restrict__ g) {
   StaticFor<0, C::KCH>::run([&]<int I>() RPSF_AI {
 #if defined(RPSF2_ABL_NOK)
@@ -584,7 +584,7 @@ RPSF_HD void load_k_chunk2(int t, cf* k, const cf* __restrict__ g) {
     k[2 * I + 1] = cf{0.25f, (float)t};
     return;
 #endif
-    load_stream16(g + ((size_t)(CI * C::KCH + I) * C::T + t) * 2, k[2 * I], k[2 * I + 1]);
+    load_k16<NT>(g + ((size_t)(CI * C::KCH + I) * C::T + t) * 2, k[2 * I], k[2 * I + 1]);
   });
 }
 
@@ -642,7 +642,7 @@ RPSF_HD void freq_a(int t, const GroupIds<C>& gids, cf* v, cf* park) {
   stage3_cols<C, false, 0>(v);
   if (t < 64) self_park<C>(t, v, park);
 }
-template <class C>
+template <class C, bool NT = true>
 RPSF_HD void freq_b(int t, const GroupIds<C>& gids, cf* v, cf* k, const cf* __restrict__ g, const cf* __restrict__ tw,
                     const cf* park) {
   StaticFor<0, C::NCHUNK>::run([&]<int CI>() RPSF_AI {
@@ -653,7 +653,7 @@ RPSF_HD void freq_b(int t, const GroupIds<C>& gids, cf* v, cf* k, const cf* __re
       stage3_cols<C, false, S>(v);
     }
     pair_words<C, S, E0, C::KCH>(gids, v, k, tw);
-    if constexpr (CI + 1 < C::NCHUNK) load_k_chunk2<C, CI + 1>(t, k, g);
+    if constexpr (CI + 1 < C::NCHUNK) load_k_chunk2<C, CI + 1, NT>(t, k, g);
     if constexpr (E0 + C::KCH == C::E) {
       if constexpr (S == 0) {
         if (t < 64) self_unpark<C>(t, v, park);

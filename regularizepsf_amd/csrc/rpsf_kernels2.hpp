@@ -399,7 +399,7 @@ __device__ __forceinline__ void wide_transform_pp(int t, int tu, int dup, const 
 }
 #endif  // RPSF_DEV_WIDE
 
-template <class C, class REENTER, bool HOT = false>
+template <class C, class REENTER, bool HOT = false, bool KNT = true>
 __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reenter) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int T = C::T, N = C::N;
@@ -716,7 +716,7 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
 #pragma unroll
   for (int j = 0; j < 2 * C::KCH; ++j) k[j] = cf{1.0f + j, 0.5f * t};
 #else
-  load_k_chunk2<C, 0>(t, k, g);  // in flight across the exchange below (raw barriers do not drain VMEM)
+  load_k_chunk2<C, 0, KNT>(t, k, g);  // in flight across the exchange below (raw barriers do not drain VMEM)
 #endif
   cf ko[2 * C::ORBIT_ROUNDS];
   if (t < 64) {
@@ -787,7 +787,7 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   load_k_chunk2<C, 1>(t, k1, g);
   freq_b_depth2<C>(t, gids, v, k, k1, g, tw, park);
 #else
-  freq_b<C>(t, gids, v, k, g, tw, park);
+  freq_b<C, KNT>(t, gids, v, k, g, tw, park);
 #endif
 #endif
   if constexpr (C::SPLIT_ROWS) ABL_VALU(stage3_rows<C, true, 0, 0>(t, gids, v));
@@ -1019,6 +1019,10 @@ extern "C" __global__ __launch_bounds__(512, 2) RPSF_VGPR_ATTR void patch_kernel
 // ... and of the 128-pixel plan (k2_128p.hip): four 128-thread workgroups per CU hide the dispatch of one another, but only
 // persistent ones keep the phase offsets of the start-up stagger
 extern "C" __global__ __launch_bounds__(128, 2) void patch_kernel2_128p(PatchParams p);
+// ... the same kernel with plain instead of streaming loads of the pair words (k2_128pc.hip), for launches whose K fits the Infinity Cache beside
+// everything else (rpsf.hip, k_cached): the next apply, or the next frame of a batch, finds K there.  2048^2: -6 % per kernel, 8 x 2048^2: -2.3 %;
+// from 3072^2 (160 MB of K) on the streaming form wins (+6 %), and the 256-pixel plan at 4096^2 loses 16 % with plain loads (profiles/r04av).
+extern "C" __global__ __launch_bounds__(128, 2) void patch_kernel2_128pc(PatchParams p);
 #if defined(RPSF_DEV_SPLIT)
 // Development: the split-patch timing skeleton (k2_256s.hip) - half patches (128 rows x 256 columns) on 256-thread workgroups, two per CU,
 // the same phases, K bytes, LDS traffic and plane stores per pixel as patch_kernel2_256p; results are wrong by design.
@@ -1032,10 +1036,12 @@ struct PersistentKernel2;
 template <>
 struct PersistentKernel2<Cfg256v2> {
   static constexpr auto fn = &patch_kernel2_256p;
+  static constexpr auto fn_k_cached = &patch_kernel2_256p;  // (no such form)
 };
 template <>
 struct PersistentKernel2<Cfg128v2> {
   static constexpr auto fn = &patch_kernel2_128p;
+  static constexpr auto fn_k_cached = &patch_kernel2_128pc;
 };
 
 // K pack: the caller's full complex64 K (n, N, N) -> folded pair words in the stream layout [word][thread], plus the

@@ -1032,3 +1032,33 @@ def test_fused_sum_of_tiles_the_image_clips_to_an_odd_width():
     out = plan.apply(image, _native.PAD_MODES["symmetric"])
     check(out.astype(np.float64), orc.apply_transfer(image, coords, k))
     assert np.array_equal(plan.apply(image, _native.PAD_MODES["symmetric"]), out)
+
+
+def test_both_forms_of_the_128_pixel_persistent_kernel():
+    """The 128-pixel persistent kernel exists twice: with streaming loads of the pair words of K (patch_kernel2_128p) and with plain ones
+    (patch_kernel2_128pc, chosen at plan creation when K fits the Infinity Cache beside the planes; RPSF_K_CACHED overrides).  Same frame,
+    same K, both forms, single frame and a batch of three that share K: against the oracle, and bit-identical to each other."""
+    import os
+
+    from regularizepsf_amd import _native
+
+    n, shape = 128, (640, 768)
+    rng = np.random.default_rng(77)
+    coords = [tuple(int(v) for v in c) for c in rp.calculate_covering(shape, n)]
+    k = (rng.standard_normal((len(coords), n, n)) + 1j * rng.standard_normal((len(coords), n, n))).astype(np.complex64)
+    frames = (rng.standard_normal((3, *shape)) * 10 + 30).astype(np.float32)
+    outs = {}
+    for form in ("0", "1"):
+        os.environ["RPSF_K_CACHED"] = form
+        try:
+            plan = _native.Plan(n, coords)
+        finally:
+            del os.environ["RPSF_K_CACHED"]
+        plan.set_transfer(k)
+        single = plan.apply(frames[0], _native.PAD_MODES["symmetric"])
+        check(single.astype(np.float64), orc.apply_transfer(frames[0], coords, k, pad_mode="symmetric"))
+        batch = plan.apply_batch(frames, _native.PAD_MODES["symmetric"])
+        assert np.array_equal(batch[0], single)
+        check(batch[2].astype(np.float64), orc.apply_transfer(frames[2], coords, k, pad_mode="symmetric"))
+        outs[form] = (single, batch)
+    assert np.array_equal(outs["0"][0], outs["1"][0]) and np.array_equal(outs["0"][1], outs["1"][1])
