@@ -16,8 +16,8 @@ python bench.py --config 4 --steps 20 --warmup 3 > gpurun_out/$R/bench_config4_8
 python bench.py --config 5 --steps 20 --warmup 3 > gpurun_out/$R/bench_config5_batch.json 2>/dev/null
 python bench.py --config 1 --steps 50 --warmup 5 --new-frames 0 > gpurun_out/$R/bench_config1.json 2>/dev/null
 for f in config1 config2 config4_8192 config5_batch; do cut -c1-200 gpurun_out/$R/bench_$f.json; done
-python scripts/band_times.py --steps 40 --seam recompute > gpurun_out/$R/band_times_recompute.log 2>&1; tail -1 gpurun_out/$R/band_times_recompute.log | cut -c1-300
-python scripts/band_times.py --steps 40 --seam exchange --worlds 1,8 > gpurun_out/$R/band_times_exchange.log 2>&1; tail -1 gpurun_out/$R/band_times_exchange.log | cut -c1-300
+python scripts/band_times.py --steps 200 --seam recompute > gpurun_out/$R/band_times_recompute.log 2>&1; tail -1 gpurun_out/$R/band_times_recompute.log | cut -c1-300
+python scripts/band_times.py --steps 200 --seam exchange --worlds 1,8 > gpurun_out/$R/band_times_exchange.log 2>&1; tail -1 gpurun_out/$R/band_times_exchange.log | cut -c1-300
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/$R/stats -- python3 $REPO/bench.py --steps 100 --warmup 5 --no-cpu --new-frames 0 > $REPO/gpurun_out/$R/stats.log 2>&1)
 find gpurun_out/$R/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/$R/bench_kernel_stats.csv
 head -4 gpurun_out/$R/bench_kernel_stats.csv
