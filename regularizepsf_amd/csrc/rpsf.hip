@@ -1003,7 +1003,12 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
             // plane stores kept in the Infinity Cache, r02av: 0.210 / 0.208 / 0.193 / 0.190 / 0.189 / 0.191 / 0.195 ms at 0 / 5 / 8 / 10 / 12 / 15 / 20 us)
             // (and smaller launches too: 2048^2 0.0811 -> 0.0787 ms, 3072^2 0.138 -> 0.131 ms, a band of 520 patches 128 -> 121 us)
             // (long launches take more: 8192^2 0.736 / 0.726 / 0.714 / 0.703 / 0.698 / 0.719 ms at 6 / 12 / 18 / 24 / 30 / 36 us)
-            if (p->stagger_us < 0 && (long)p->n_patches * tune_frames >= 256) pp.stagger_ticks = (long)p->n_patches * tune_frames >= 2048 ? 2400 : 1200;
+            // (round 4, seven-barrier pass, profiles/r04az: 4096^2 at 12 / 16 / 20 us - the repeated frame 0.1835 / 0.1843 / 0.1880 ms, a NEW frame every step
+            // 0.2019 / 0.1962 / 0.1933: 16 us from 1024 patches of the 256-pixel plan on; 8192^2 0.714 / 0.688 / 0.691 / 0.690 at 12 / 16 / 20 / 24)
+            if (p->stagger_us < 0 && (long)p->n_patches * tune_frames >= 256) {
+              const long work = (long)p->n_patches * tune_frames;
+              pp.stagger_ticks = work >= 2048 ? 2400 : (work >= 1024 && std::is_same_v<C, Cfg256v2>) ? 1600 : 1200;
+            }
             for (int x = 0; x < 8; ++x) {
               pp.xq_base[x] = p->xq_base[x];
               // draws of this launch: one per slot and frame, plus the one past the end that tells each of the chunk's workgroups to stop
