@@ -1008,6 +1008,10 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
             if (p->stagger_us < 0 && (long)p->n_patches * tune_frames >= 256) {
               const long work = (long)p->n_patches * tune_frames;
               pp.stagger_ticks = work >= 2048 ? 2400 : (work >= 1024 && std::is_same_v<C, Cfg256v2>) ? 1600 : 1200;
+              // The 128-pixel plan - four workgroups per CU, out of step with one another anyway - is better off WITHOUT it since round 4 (profiles/r04ba):
+              // 2048^2 0.0655 -> 0.0603 ms (-8 %), 3072^2 -6 %, 8 x 2048^2 0.3252 -> 0.3198; only single frames of 4096^2 and more still take a short one
+              // (6 us: -1 ... -3 %).
+              if constexpr (std::is_same_v<C, Cfg128v2>) pp.stagger_ticks = tune_frames == 1 && p->n_patches >= 4096 ? 600 : 0;
             }
             for (int x = 0; x < 8; ++x) {
               pp.xq_base[x] = p->xq_base[x];
