@@ -15,7 +15,7 @@ import sys
 
 PKG = pathlib.Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
-SOURCES = [CSRC / n for n in ("rpsf.hip", "k1_256.hip", "k1_128.hip", "k1_small.hip", "k2_256.hip", "k2_256p.hip", "k2_128.hip", "k2_128p.hip", "k2_128pc.hip", "k2_256s.hip")]
+SOURCES = [CSRC / n for n in ("rpsf.hip", "k1_256.hip", "k1_128.hip", "k1_small.hip", "k2_256.hip", "k2_256p.hip", "k2_128.hip", "k2_128p.hip", "k2_128pc.hip", "k2_128pcs.hip", "k2_256s.hip")]
 HEADERS = [CSRC / n for n in ("rpsf_core.hpp", "rpsf_core2.hpp", "rpsf_kernels.hpp", "rpsf_kernels2.hpp", "rpsf_device.hpp")] + [
     PKG.parent / "include" / "rpsf.h"]
 TARGET = PKG / "librpsf_hip.so"
@@ -144,6 +144,7 @@ def build(force: bool = False, verbose: bool = True, defines: tuple[str, ...] = 
     check_reentry_contract(next(o for o in objs if o.stem == "k2_256p"), "patch_kernel2_256p")
     check_reentry_contract(next(o for o in objs if o.stem == "k2_128p"), "patch_kernel2_128p")
     check_reentry_contract(next(o for o in objs if o.stem == "k2_128pc"), "patch_kernel2_128pc")
+    check_reentry_contract(next(o for o in objs if o.stem == "k2_128pcs"), "patch_kernel2_128pcs")
     if any(d.startswith("-DRPSF_DEV_SPLIT") for d in defines):
         check_reentry_contract(next(o for o in objs if o.stem == "k2_256s"), "patch_kernel2_256s")
     if any(d.startswith("-DRPSF_DEV_WIDE") for d in defines):

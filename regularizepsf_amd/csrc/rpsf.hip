@@ -622,6 +622,8 @@ extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int
                                     (int)Launch2<Cfg128v2>::LDS_BYTES));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_kernel2_128pc), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)Launch2<Cfg128v2>::LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_kernel2_128pcs), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)Launch2<Cfg128v2>::LDS_BYTES));
         // Plain instead of streaming loads of the pair words where the plan's K (66,560 B per patch) fits the 256 MiB Infinity Cache beside the
         // planes: measured (profiles/r04av) -6 % per apply at 72 MB of K, +6.6 % at 160 MB; RPSF_K_CACHED=0/1 overrides (tests run both forms).
         p->k_cached = (size_t)n_patches * Cfg128v2::G_PER_PATCH * sizeof(cf) <= ((size_t)96 << 20);
@@ -947,6 +949,12 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
                            16.0 * (double)p->planes_floats * b.frames > 256.0 * 1048576.0;  // (8 x 2048^2: 0.056 ms per frame side by side, 0.061 in turn)
         if (const char* e = std::getenv("RPSF_FRAME_MAJOR")) frame_major = frame_major && std::atoi(e) != 0;
         pp.frame_major = ts.frame_major = frame_major ? 1 : 0;
+        // Frames of a batch side by side keep the planes of ALL of them live at once (8 x 2048^2: 537 MB against a 256 MiB Infinity Cache): the 128-pixel
+        // kernels then store them with the streaming hint - 0.3156 -> 0.3009 ms (-4.7 %); a single frame loses 8 % that way, and so does the 256-pixel
+        // plan at either size (profiles/r04bd).  RPSF_PLANE_NT=0/1 overrides (development sweeps).
+        // (needs the plain-load form of K - a batch shares it - and planes of one and a half Infinity Caches: 4 x 2048^2, 268 MB, still loses 4 %)
+        pp.plane_nt = std::is_same_v<C, Cfg128v2> && p->k_cached && b.frames > 1 && !frame_major && 16.0 * (double)p->planes_floats * b.frames > 384.0 * 1048576.0;
+        if (const char* e = std::getenv("RPSF_PLANE_NT")) pp.plane_nt = std::atoi(e) != 0 && std::is_same_v<C, Cfg128v2> && p->k_cached;
         const int tune_frames = b.frames;  // (the settings of a single apply measured worse here: 0.203 vs 0.186 ms per frame at 8 x 4096^2)
         pp.sum_first = sum_first_for(p, tune_frames);
         ts.planes_frame_floats = 4 * p->planes_floats, ts.out_frame_floats = b.out_stride;
@@ -1045,7 +1053,9 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
               patch_kernel2_256w<<<dim3((unsigned)wgs), dim3(1024), Launch2<Cfg256v2>::LDS_BYTES, st>>>(pp);
             } else
 #endif
-            if (p->k_cached)
+            if (p->k_cached && pp.plane_nt)
+              PersistentKernel2<C>::fn_k_cached_planes_nt<<<dim3((unsigned)wgs), dim3(Launch2<C>::WG), Launch2<C>::LDS_BYTES, st>>>(pp);
+            else if (p->k_cached)
               PersistentKernel2<C>::fn_k_cached<<<dim3((unsigned)wgs), dim3(Launch2<C>::WG), Launch2<C>::LDS_BYTES, st>>>(pp);
             else
               PersistentKernel2<C>::fn<<<dim3((unsigned)wgs), dim3(Launch2<C>::WG), Launch2<C>::LDS_BYTES, st>>>(pp);

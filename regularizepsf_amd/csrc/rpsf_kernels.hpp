@@ -79,6 +79,11 @@ __device__ __forceinline__ rpsf_f4 plane_load16_wt(__amdgpu_buffer_rsrc_t r, siz
   const rpsf_i4 q = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(RPSF_PLANE_OFF(float_offset) * sizeof(float)), 0, RPSF_DEV_PLANE_AUX_LOAD);
   return rpsf_f4{__int_as_float(q.x), __int_as_float(q.y), __int_as_float(q.z), __int_as_float(q.w)};
 }
+template <int AUX>
+__device__ __forceinline__ void plane_store16_aux(__amdgpu_buffer_rsrc_t r, size_t float_offset, rpsf_f4 v) {
+  const rpsf_i4 q = {__float_as_int(v.x), __float_as_int(v.y), __float_as_int(v.z), __float_as_int(v.w)};
+  __builtin_amdgcn_raw_buffer_store_b128(q, r, (int)(RPSF_PLANE_OFF(float_offset) * sizeof(float)), 0, AUX);
+}
 __device__ __forceinline__ void plane_store16_wt(__amdgpu_buffer_rsrc_t r, size_t float_offset, rpsf_f4 v) {
   const rpsf_i4 q = {__float_as_int(v.x), __float_as_int(v.y), __float_as_int(v.z), __float_as_int(v.w)};
   __builtin_amdgcn_raw_buffer_store_b128(q, r, (int)(RPSF_PLANE_OFF(float_offset) * sizeof(float)), 0, RPSF_DEV_PLANE_AUX);
@@ -307,6 +312,7 @@ struct PatchParams {
   // persistent launch (patch_kernel2_256p): the grid is sum_first + 8 * persist workgroups; the resident ones start on
   // slots [0, persist) of their XCD's chunk and draw the later ones from xq[xcd * 32] (one counter per XCD on a line of its own)
   int frame_major;  // batches: queue position = frame * (slots of the XCD) + slot instead of slot * frames + frame
+  int plane_nt;     // (host side only: the launch takes patch_kernel2_128pcs - streaming plane stores - see rpsf.hip)
   int persist;
   uint32_t* xq;
   uint32_t xq_base[8];

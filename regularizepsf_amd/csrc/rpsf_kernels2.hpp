@@ -399,7 +399,7 @@ __device__ __forceinline__ void wide_transform_pp(int t, int tu, int dup, const 
 }
 #endif  // RPSF_DEV_WIDE
 
-template <class C, class REENTER, bool HOT = false, bool KNT = true>
+template <class C, class REENTER, bool HOT = false, bool KNT = true, bool PLANE_NT = false>
 __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reenter) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int T = C::T, N = C::N;
@@ -962,7 +962,11 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
 #if defined(RPSF2_ABL_NOSTORE)
         [=](float* a, f32x4 val) RPSF_AI { asm volatile("" ::"v"(val.x), "v"(val.y), "v"(val.z), "v"(val.w), "v"(a)); },
 #else
-        [=](float* a, f32x4 val) RPSF_AI { plane_store16_wt(rsrc, (size_t)(a - pbase), val); },
+        [=](float* a, f32x4 val) RPSF_AI {
+          // (PLANE_NT: the instantiation for batches of frames side by side, whose planes are live all at once - see rpsf.hip, plane_nt)
+          if constexpr (PLANE_NT) plane_store16_aux<16 | 2>(rsrc, (size_t)(a - pbase), val);
+          else plane_store16_wt(rsrc, (size_t)(a - pbase), val);
+        },
 #endif
         [](float* a, float val) RPSF_AI { __hip_atomic_store(reinterpret_cast<unsigned*>(a), __float_as_uint(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); });
 #if defined(RPSF_DEV_WIDE) && RPSF_DEV_WIDE >= 2
@@ -1023,6 +1027,9 @@ extern "C" __global__ __launch_bounds__(128, 2) void patch_kernel2_128p(PatchPar
 // everything else (rpsf.hip, k_cached): the next apply, or the next frame of a batch, finds K there.  2048^2: -6 % per kernel, 8 x 2048^2: -2.3 %;
 // from 3072^2 (160 MB of K) on the streaming form wins (+6 %), and the 256-pixel plan at 4096^2 loses 16 % with plain loads (profiles/r04av).
 extern "C" __global__ __launch_bounds__(128, 2) void patch_kernel2_128pc(PatchParams p);
+// ... and with streaming plane stores on top (k2_128pcs.hip), for batches of frames side by side whose planes - live all at once - exceed the Infinity Cache:
+// 8 x 2048^2 0.3244 -> 0.3096 ms; 2 ... 4 frames, single frames of any size and the 256-pixel plan lose 2 ... 8 % with them (profiles/r04bd)
+extern "C" __global__ __launch_bounds__(128, 2) void patch_kernel2_128pcs(PatchParams p);
 #if defined(RPSF_DEV_SPLIT)
 // Development: the split-patch timing skeleton (k2_256s.hip) - half patches (128 rows x 256 columns) on 256-thread workgroups, two per CU,
 // the same phases, K bytes, LDS traffic and plane stores per pixel as patch_kernel2_256p; results are wrong by design.
@@ -1036,12 +1043,14 @@ struct PersistentKernel2;
 template <>
 struct PersistentKernel2<Cfg256v2> {
   static constexpr auto fn = &patch_kernel2_256p;
-  static constexpr auto fn_k_cached = &patch_kernel2_256p;  // (no such form)
+  static constexpr auto fn_k_cached = &patch_kernel2_256p;  // (no such forms)
+  static constexpr auto fn_k_cached_planes_nt = &patch_kernel2_256p;
 };
 template <>
 struct PersistentKernel2<Cfg128v2> {
   static constexpr auto fn = &patch_kernel2_128p;
   static constexpr auto fn_k_cached = &patch_kernel2_128pc;
+  static constexpr auto fn_k_cached_planes_nt = &patch_kernel2_128pcs;
 };
 
 // K pack: the caller's full complex64 K (n, N, N) -> folded pair words in the stream layout [word][thread], plus the

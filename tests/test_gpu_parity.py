@@ -1034,10 +1034,11 @@ def test_fused_sum_of_tiles_the_image_clips_to_an_odd_width():
     assert np.array_equal(plan.apply(image, _native.PAD_MODES["symmetric"]), out)
 
 
-def test_both_forms_of_the_128_pixel_persistent_kernel():
-    """The 128-pixel persistent kernel exists twice: with streaming loads of the pair words of K (patch_kernel2_128p) and with plain ones
-    (patch_kernel2_128pc, chosen at plan creation when K fits the Infinity Cache beside the planes; RPSF_K_CACHED overrides).  Same frame,
-    same K, both forms, single frame and a batch of three that share K: against the oracle, and bit-identical to each other."""
+def test_every_form_of_the_128_pixel_persistent_kernel():
+    """The 128-pixel persistent kernel exists three times: with streaming loads of the pair words of K (patch_kernel2_128p), with plain ones
+    (patch_kernel2_128pc, chosen at plan creation when K fits the Infinity Cache beside the planes; RPSF_K_CACHED overrides) and with streaming
+    plane stores on top (patch_kernel2_128pcs, chosen per launch for large batches; RPSF_PLANE_NT overrides).  Same frame, same K, every form,
+    single frame and a batch of three that share K: against the oracle, and bit-identical to each other."""
     import os
 
     from regularizepsf_amd import _native
@@ -1062,3 +1063,10 @@ def test_both_forms_of_the_128_pixel_persistent_kernel():
         check(batch[2].astype(np.float64), orc.apply_transfer(frames[2], coords, k, pad_mode="symmetric"))
         outs[form] = (single, batch)
     assert np.array_equal(outs["0"][0], outs["1"][0]) and np.array_equal(outs["0"][1], outs["1"][1])
+    # the third form (patch_kernel2_128pcs: streaming plane stores, taken by large batches) on the same batch
+    os.environ["RPSF_PLANE_NT"] = "1"
+    try:
+        streamed = plan.apply_batch(frames, _native.PAD_MODES["symmetric"])
+    finally:
+        del os.environ["RPSF_PLANE_NT"]
+    assert np.array_equal(streamed, outs["1"][1])
