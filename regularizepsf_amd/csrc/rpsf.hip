@@ -884,7 +884,7 @@ enum OverlapKind { OV_ATOMIC = 0, OV_PLANES = 1, OV_DIRECT = 2 };
 static int sum_first_for(const rpsf_plan* p, int frames) {
   if (p->sum_first >= 0) return p->sum_first;
   const long work = (long)p->n_patches * frames;
-  if (p->N == 128) return work >= 2048 ? 128 : work >= 512 ? 8 : 0;
+  if (p->N == 128) return work >= 4096 ? 160 : work >= 2048 ? 128 : work >= 512 ? 8 : 0;  // (160 from 4096 patch-frames on: -2 ... -4 %, profiles/r04bf)
   return work >= 2048 ? 32 : work >= 1024 ? 16 : work >= 512 ? 8 : 0;
 }
 
@@ -952,8 +952,8 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
         // Frames of a batch side by side keep the planes of ALL of them live at once (8 x 2048^2: 537 MB against a 256 MiB Infinity Cache): the 128-pixel
         // kernels then store them with the streaming hint - 0.3156 -> 0.3009 ms (-4.7 %); a single frame loses 8 % that way, and so does the 256-pixel
         // plan at either size (profiles/r04bd).  RPSF_PLANE_NT=0/1 overrides (development sweeps).
-        // (needs the plain-load form of K - a batch shares it - and planes of one and a half Infinity Caches: 4 x 2048^2, 268 MB, still loses 4 %)
-        pp.plane_nt = std::is_same_v<C, Cfg128v2> && p->k_cached && b.frames > 1 && !frame_major && 16.0 * (double)p->planes_floats * b.frames > 384.0 * 1048576.0;
+        // (needs the plain-load form of K - a batch shares it - and planes well beyond the Infinity Cache: 4 x 2048^2, 268 MB, still loses 3 %; 6 x, 403 MB, gains 5 %)
+        pp.plane_nt = std::is_same_v<C, Cfg128v2> && p->k_cached && b.frames > 1 && !frame_major && 16.0 * (double)p->planes_floats * b.frames > 300.0 * 1048576.0;
         if (const char* e = std::getenv("RPSF_PLANE_NT")) pp.plane_nt = std::atoi(e) != 0 && std::is_same_v<C, Cfg128v2> && p->k_cached;
         const int tune_frames = b.frames;  // (the settings of a single apply measured worse here: 0.203 vs 0.186 ms per frame at 8 x 4096^2)
         pp.sum_first = sum_first_for(p, tune_frames);
