@@ -132,7 +132,7 @@ def build(force: bool = False, verbose: bool = True, defines: tuple[str, ...] = 
         obj = objdir / (src.stem + ".o")
         if not force and obj.exists() and obj.stat().st_mtime > max(src.stat().st_mtime, newest_header):
             return obj
-        cmd = [hipcc, *FLAGS, *defines, "-c", str(src), "-o", str(obj)]
+        cmd = [hipcc, *FLAGS, *os.environ.get("RPSF_EXTRA_HIPCC_FLAGS", "").split(), *defines, "-c", str(src), "-o", str(obj)]  # (development: e.g. -mllvm options)
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
