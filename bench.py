@@ -135,6 +135,30 @@ def cpu_baseline(image, coords, k, budget_s: float = 25.0):
     }
 
 
+def e2e_host_frames(plan, images, pad_mode, out_dtype=np.float64, reps=5):
+    """End to end, host arrays in and out ("report end-to-end (H2D + kernel + D2H) separately"): the path
+    ArrayPSFTransform.apply / apply_batch take.  `images`: (frames, H, W) host stack; the result stack is allocated (and its pages
+    touched) once, outside the clock, as a caller that reuses its buffers would.  Returns best-of-`reps` milliseconds for the
+    frame-by-frame loop (rpsf_apply_host per frame) and for the streamed call (rpsf_apply_frames_host), and the PCIe floor:
+    the time PCIe needs for one frame's float32 bytes in each direction at once (rpsf_pcie_probe, pinned memory, two streams)."""
+    from regularizepsf_amd import _native
+
+    frames, h, w = images.shape
+    out = np.zeros((frames, h, w), out_dtype)
+    loop_ms = stream_ms = float("inf")
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        for f in range(frames):
+            plan.apply_host(images[f], pad_mode, out=out[f])
+        loop_ms = min(loop_ms, 1e3 * (time.perf_counter() - t0))
+        if frames > 1:
+            t0 = time.perf_counter()
+            plan.apply_frames_host(images, pad_mode, out=out)
+            stream_ms = min(stream_ms, 1e3 * (time.perf_counter() - t0))
+    probe = _native.pcie_probe(h * w * 4, 5, plan.device)
+    return loop_ms / frames, (stream_ms / frames if frames > 1 else None), probe
+
+
 class GlooSeam:
     """Debug stand-in for regularizepsf_amd._native.Comm: same calls, seam rows travel through the host over gloo."""
 
@@ -223,6 +247,8 @@ def run_batch(args, rank, world, device, comm):
 
     h, w, n, seed = CONFIGS[5]
     frames = args.frames
+    # one process per GPU, next to it: host arrays allocated from here on live on the GPU's NUMA node (the streamed leg copies them)
+    bound_node = _native.bind_to_device_node(device) if args.streamed and not args.no_bind else -1
     coords = [tuple(int(v) for v in t) for t in orc.calculate_covering((h, w), n)]
     src = np.stack([orc.coma_psf(n, r, c, h, w) for r, c in coords])
     tgt = orc.psf_fft(orc.gaussian_psf(n, 1.8))[None]
@@ -269,14 +295,20 @@ def run_batch(args, rank, world, device, comm):
     step_ms = ms_per_step if world == 1 else float(np.mean(total_ms))
     achieved = alg_bytes / (step_ms * 1e-3) / 1e9
     achieved_kernel = alg_bytes / (kern_avg_ms * 1e-3) / 1e9
+    parity = None
     if args.verify:
         out = d_out.download((frames, h, w)).astype(np.float64)
+        worst = [0.0, 0.0]
         for f in (0, frames - 1):
             ref = orc.apply_transfer(images[f], coords, k, workers=-1)
             err = float(np.abs(out[f] - ref).max() / np.abs(ref).max())
-            print(f"[verify] rank {rank} frame {f}: max|d|/max|ref| = {err:.3e}", file=sys.stderr, flush=True)
-            if err > 1e-5:
+            err2 = float(np.linalg.norm(out[f] - ref) / np.linalg.norm(ref))
+            print(f"[verify] rank {rank} frame {f}: max|d|/max|ref| = {err:.3e}, rel L2 = {err2:.3e}", file=sys.stderr, flush=True)
+            if max(err, err2) > 1e-5:
                 raise SystemExit(f"verification failed on rank {rank}")
+            worst = [max(worst[0], err), max(worst[1], err2)]
+        parity = {"max_rel": float(f"{worst[0]:.3e}"), "l2_rel": float(f"{worst[1]:.3e}"), "bound": 1e-5,
+                  "against": "float64 NumPy/SciPy oracle (bit-identical restatement of the reference), first and last frame of the batch"}
     if comm is not None:
         import torch.distributed as dist
 
@@ -309,6 +341,31 @@ def run_batch(args, rank, world, device, comm):
             "apply_avg_ms_events": round(float(np.mean(total_ms)), 4),
         },
     }
+    if parity:
+        line["parity"] = parity
+    if args.streamed and world == 1:
+        # The same frames as host arrays, in and out, through the streamed entry point (three streams, persistent host pool), against
+        # the frame loop and against what PCIe gives a frame on this box; float32 frames in, float64 out is what the reference's
+        # users get (FITS frames are float32; transform.py:174-177 returns float64), float32 out skips the widening.
+        e2e = {}
+        for label, dt in (("f32_to_f64", np.float64), ("f32_to_f32", np.float32)):
+            loop_ms, stream_ms, probe = e2e_host_frames(plan, images, _native.PAD_MODES["symmetric"], dt)
+            e2e[label] = {"e2e_ms_per_frame": round(stream_ms, 4), "frame_loop_ms_per_frame": round(loop_ms, 4),
+                          "over_pcie_floor": round(stream_ms / probe["duplex_ms"], 3),
+                          "mpixels_per_s": round(h * w / stream_ms / 1e3, 1)}
+        long_images = np.stack([images[i % frames] for i in range(4 * frames)])  # the same path in steady state (start-up and drain amortised)
+        _, long_ms, _ = e2e_host_frames(plan, long_images, _native.PAD_MODES["symmetric"], np.float64, reps=3)
+        line["e2e_ms_per_frame"] = e2e["f32_to_f64"]["e2e_ms_per_frame"]
+        line["pcie_floor_ms"] = round(probe["duplex_ms"], 4)
+        line["e2e"] = {
+            "what": f"{frames} host frames float32 in, host frames out, rpsf_apply_frames_host (H2D || shared-K launch || D2H + widening on 3 streams, "
+                    f"persistent pool of {_native.host_threads()} host threads), best of 5; the floor = one frame's float32 bytes each way at once over PCIe "
+                    "(rpsf_pcie_probe: pinned memory, two streams)",
+            **e2e, "steady_state_ms_per_frame_f32_to_f64": round(long_ms, 4), "steady_state_frames": 4 * frames,
+            "steady_state_over_pcie_floor": round(long_ms / probe["duplex_ms"], 3),
+            "pcie": {k: round(v, 4) for k, v in probe.items()}, "frame_bytes": h * w * 4,
+            "process_bound_to_numa_node": bound_node, "device_numa_node": _native.device_numa_node(device),
+        }
     if not args.no_cpu and world == 1:
         line["cpu_baseline"] = cpu_baseline(images[0], coords, k)
     emit_json(line)
@@ -329,13 +386,18 @@ def main() -> None:
                     help="seam transport for N > 1; 'gloo' is a debug stand-in (host copies) used to exercise the "
                          "multi-rank flow on a box with fewer GPUs than ranks")
     ap.add_argument("--verify", action="store_true", default=None,
-                    help="check every rank's owned rows against the CPU oracle on one step outside the timed loops (default: on for N > 1)")
+                    help="check every rank's owned rows against the CPU oracle on one step outside the timed loops (default: on)")
     ap.add_argument("--no-verify", dest="verify", action="store_false")
     ap.add_argument("--second-leg-timeout", type=float, default=300.0,
                     help="N > 1: seconds the second seam leg may take before the headline line is emitted without it")
     ap.add_argument("--one-seam", action="store_true",
                     help="N > 1: time only the --seam mode (default: the other seam mode is timed as a second leg in the same process)")
     ap.add_argument("--frames", type=int, default=8, help="config 5: frames per GPU in one batch")
+    ap.add_argument("--streamed", action="store_true",
+                    help="config 5, N = 1: also time the frames as HOST arrays in and out through the streamed entry point "
+                         "(e2e_ms_per_frame, pcie_floor_ms in the line)")
+    ap.add_argument("--no-bind", action="store_true", help="do not bind the process to the GPU's NUMA node for the end-to-end legs")
+    ap.add_argument("--no-e2e", action="store_true", help="N = 1: skip the end-to-end (host arrays in and out) leg")
     ap.add_argument("--rotate", type=int, default=1,
                     help="N = 1 only: this many DIFFERENT device-resident frames (and output buffers) are corrected in rotation.  "
                          "Default 1: the same frame every step, as in every earlier round - it then stays in the 256 MB Infinity "
@@ -369,7 +431,7 @@ def main() -> None:
     if args.config is None:
         args.config = 3 if world == 1 or args.weak else 4
     if args.verify is None:
-        args.verify = world > 1
+        args.verify = True
 
     from oracle import regpsf_oracle as orc  # synthetic inputs + cpu_baseline only
     from regularizepsf_amd import _native
@@ -544,9 +606,10 @@ def main() -> None:
         worst = comm.allreduce_max(max(err, err2)) if comm is not None else max(err, err2)
         if worst > 1e-5:
             raise SystemExit(f"verification failed (seam={label}): {worst:.3e}")
+        parity[label] = {"max_rel": float(f"{err:.3e}"), "l2_rel": float(f"{err2:.3e}")}  # (rank 0's own rows)
         return worst
 
-    verified = {}
+    verified, parity = {}, {}
     if args.verify:
         verified[args.seam if world > 1 else "single"] = verify_owned_rows(shard, args.seam if world > 1 else "single")
 
@@ -650,10 +713,12 @@ def main() -> None:
                 line[f"scaling_{args.seam}_ms"] = round(ms_per_step, 4)
                 line[f"scaling_{other_seam}_ms"] = None
                 line["second_leg"] = f"seam={other_seam}: no result after {args.second_leg_timeout:.0f} s (watchdog); the headline leg is complete"
-                if verified:
-                    line["verify"] = {"max_error": max(verified.values()), "legs": sorted(verified), "bound": 1e-5}
+                line["verify"] = {"max_error": max(verified.values()) if verified else None, "legs": sorted(verified), "bound": 1e-5,
+                                  "failed_legs": [other_seam]}
                 emit_json(line)
-            os._exit(0)  # (kernels or collectives of the second leg may never return: no orderly shutdown)
+            # kernels or collectives of the second leg may never return: no orderly shutdown - and NOT exit code 0: the headline line is out,
+            # but a harness that looks at the return code must see that a leg hung
+            os._exit(3)
 
         dog = threading.Timer(args.second_leg_timeout, give_up)
         dog.daemon = True
@@ -683,6 +748,8 @@ def main() -> None:
         dist.barrier()
         dist.destroy_process_group()
     if rank != 0:
+        if second_leg_note is not None:  # (no orderly shutdown after a failed leg, and not exit code 0)
+            os._exit(3)
         return
     if world > 1:  # both seam modes of this run (the headline is config.seam), the transport, and what RCCL says about its communicator
         line["config"]["seam"] = args.seam
@@ -695,9 +762,13 @@ def main() -> None:
             line[f"scaling_{other_seam}_ms"] = round(other_ms, 4)
             line["seam_rows_transport"] = ("gloo (host copies: debugging stand-in)" if isinstance(comm, GlooSeam) else
                                            "RCCL ncclSend / ncclRecv in the timed region")
-    if verified:
-        line["verify"] = {"max_error": max(verified.values()), "legs": sorted(verified), "bound": 1e-5,
+    if verified or second_leg_note is not None:
+        line["verify"] = {"max_error": max(verified.values()) if verified else None, "legs": sorted(verified), "bound": 1e-5,
+                          "failed_legs": [other_seam] if second_leg_note is not None else [],
                           "what": "every rank's own output rows of one step against the float64 oracle (max|d|/max|ref| and relative L2)"}
+        first = parity.get(args.seam if world > 1 else "single")
+        if first:  # SURVEY 8d's parity metric on the very inputs of the timed loop: max|d| / max|ref| and ||d||2 / ||ref||2, bound 1e-5
+            line["parity"] = {**first, "bound": 1e-5, "against": "float64 NumPy/SciPy oracle (bit-identical restatement of the reference), same image and complex64 K"}
     if new_frames_ms is not None:  # same bytes, same plan, every step a frame the caches have not seen for args.new_frames - 1 applies
         line["roofline"]["ms_per_step_new_frames"] = round(new_frames_ms, 4)
         line["roofline"]["frac_new_frames"] = round(alg_bytes / (new_frames_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
@@ -706,6 +777,21 @@ def main() -> None:
             line["roofline"]["ms_per_step_new_frames_with_image_prefetch"] = round(new_frames_prefetch_ms, 4)
     if pipeline:  # the overlapped steps priced on the same bytes (not roofline.frac: SURVEY 8d's t is one device-resident apply)
         line["roofline"]["frac_steps_in_flight"] = round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    if world == 1 and not args.no_e2e:
+        # one host-array apply(), end to end: what every caller of the class API gets (float32 frame in, float64 out as the reference
+        # returns it; and float32 out); PCIe floor = the frame's float32 bytes in, then out (a single frame cannot overlap its own directions
+        # without being cut into row bands)
+        host_image = np.ascontiguousarray(band_image, np.float32)[None]
+        e2e = {}
+        for label, dt in (("f32_to_f64", np.float64), ("f32_to_f32", np.float32)):
+            ms, _, probe = e2e_host_frames(plan, host_image, _native.PAD_MODES[pad], dt)
+            e2e[label] = round(ms, 4)
+        line["e2e_ms"] = e2e["f32_to_f64"]
+        line["e2e"] = {"what": "one ArrayPSFTransform.apply-style call on host arrays (rpsf_apply_host: chunked staging on the persistent host pool, "
+                               "H2D, patch launch, D2H, widening), best of 5, result buffer reused",
+                       "ms": e2e, "pcie": {k: round(v, 4) for k, v in probe.items()},
+                       "pcie_floor_ms": round(probe["h2d_ms"] + probe["d2h_ms"], 4), "host_threads": _native.host_threads(),
+                       "over_pcie_floor": round(e2e["f32_to_f64"] / (probe["h2d_ms"] + probe["d2h_ms"]), 3)}
     traffic_file = ROOT / "profiles" / "traffic_latest.json"
     if world == 1 and args.config == 3 and traffic_file.exists():  # PMC counters cannot be read from inside the process
         tr = json.loads(traffic_file.read_text())
@@ -714,6 +800,9 @@ def main() -> None:
     if not args.no_cpu and world == 1:
         line["cpu_baseline"] = cpu_baseline(band_image, coords, kernel_for(list(range(len(coords)))))
     emit_json(line)
+    if second_leg_note is not None:  # the headline leg is complete and reported; the failed second leg must still show in the exit code
+        sys.stdout.flush()
+        os._exit(3)
 
 
 if __name__ == "__main__":

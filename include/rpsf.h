@@ -120,8 +120,10 @@ int rpsf_apply(rpsf_plan* plan, const float* image_host, int height, int width, 
                float* out_host);
 /* The same call for the dtypes ArrayPSFTransform.apply really sees: the image as float32 or float64
  * (image_is_f64; apply casts with astype, transform.py:117) and the result as float32 or float64
- * (out_is_f64; the reference returns float64, transform.py:174-177).  Conversions run on a few host threads,
- * chunk by chunk through pinned staging, overlapped with the PCIe copies. */
+ * (out_is_f64; the reference returns float64, transform.py:174-177).  The conversions run on the library's persistent
+ * worker pool (created at the first such call of the process, RPSF_HOST_THREADS wide, default min(16, cores); no
+ * thread or buffer is created per call), chunk by chunk through the plan's pinned staging, overlapped with the PCIe
+ * copies.  rpsf_apply above is this call with float32 on both sides. */
 int rpsf_apply_host(rpsf_plan* plan, const void* image_host, int image_is_f64, int height, int width, int pad_mode,
                     float pad_value, void* out_host, int out_is_f64);
 /* Same with image and output already resident on the plan's device; asynchronous on `stream`
@@ -131,20 +133,42 @@ int rpsf_apply_host(rpsf_plan* plan, const void* image_host, int image_is_f64, i
  * fine-grained or host-mapped memory does not support.  A plan serves one apply at a time: a call on a
  * different stream than the previous one waits for that one (the plan's scratch is shared). */
 int rpsf_apply_device(rpsf_plan* plan, const void* image_dev, void* out_dev, const rpsf_geometry* geom, void* stream);
-/* Run `iters` back-to-back device-resident applies on the plan's stream, timing each with HIP
- * events: total_ms[i] covers the whole apply (output clear + patch kernel), kernel_ms[i] the patch
- * kernel alone.  Either array may be NULL. */
+/* Run `iters` back-to-back device-resident applies on the plan's stream, each bracketed by HIP events of its own, one
+ * synchronisation at the end (the launches queue up as in a caller's loop): total_ms[i] covers the whole apply
+ * (output clear + patch kernel), kernel_ms[i] the patch kernel alone.  Either array may be NULL. */
 int rpsf_apply_device_timed(rpsf_plan* plan, const void* image_dev, void* out_dev, const rpsf_geometry* geom,
                             int iters, float* total_ms, float* kernel_ms);
 /* A batch of n_frames frames of identical geometry corrected with the plan's (shared) transfer kernel -
  * what a caller of the reference does with a Python loop over ArrayPSFTransform.apply
  * (transform.py:85-177) on a stack of exposures.  The frames of one patch are scheduled next to each other so
  * the packed transfer kernel is read from HBM once per batch, not once per frame.
- * Host variant: images_host / outs_host are (n_frames, height, width) float32, C-contiguous; the frames go one
- * by one through rpsf_apply (PCIe-bound; the shared-K launch below is for frames that already live on the
- * device). */
+ * Host variants - the STREAMED path: what a user of the reference runs is `[transform.apply(image) for image in images]`
+ * (docs/source/example.ipynb over transform.py:85-177), host arrays in and out, and every frame crosses PCIe twice, which
+ * costs several times the kernel.  The frames go through the plan's staging slots in groups, up to four groups in flight on
+ * three streams: H2D of group i + 1 || the shared-K launch of group i (rpsf_apply_batch_device's) || D2H of group i - 1, with
+ * the dtype conversions of both directions on the persistent worker pool - PCIe in both directions is kept busy and is what
+ * bounds the call (bench.py --config 5 --streamed reports it against rpsf_pcie_probe's floor).  Results are bit-identical to
+ * the frame-by-frame loop.
+ *   rpsf_apply_batch:        (n_frames, height, width) float32 stacks, C-contiguous;
+ *   rpsf_apply_batch_host:   the same with float32 or float64 on either side (as rpsf_apply_host);
+ *   rpsf_apply_frames_host:  one pointer per frame (a Python list of arrays needs no np.stack). */
 int rpsf_apply_batch(rpsf_plan* plan, const float* images_host, int n_frames, int height, int width, int pad_mode,
                      float pad_value, float* outs_host);
+int rpsf_apply_batch_host(rpsf_plan* plan, const void* images_host, int image_is_f64, int n_frames, int height, int width,
+                          int pad_mode, float pad_value, void* outs_host, int out_is_f64);
+int rpsf_apply_frames_host(rpsf_plan* plan, const void* const* images_host, int image_is_f64, int n_frames, int height,
+                           int width, int pad_mode, float pad_value, void* const* outs_host, int out_is_f64);
+/* Width of the worker pool the host-array entry points convert on (creates it if this is the first use).  The workers are
+ * pinned to cores of the NUMA node the (first) device hangs off, spread over its core complexes (RPSF_HOST_AFFINITY=0: not
+ * pinned; RPSF_HOST_THREADS: width). */
+int rpsf_host_threads(int* threads);
+/* That node (-1: unknown): a process that feeds the GPU from host arrays should run and allocate there - staging copies
+ * from the other socket run at a third of the rate (scripts/micro/host_copy.hip). */
+int rpsf_device_numa_node(int device, int* node);
+/* What PCIe gives `bytes` on this box, from and to pinned host memory: one direction at a time and both at once (two
+ * streams), best of `iters`, milliseconds.  The floor the streamed entry points are reported against (SURVEY 8d:
+ * end-to-end figures are reported separately from the device-resident ones).  Any pointer may be NULL. */
+int rpsf_pcie_probe(int device, size_t bytes, int iters, double* h2d_ms, double* d2h_ms, double* duplex_ms);
 /* Device variant: frame f is at images_dev + f * image_stride and outs_dev + f * out_stride (strides in
  * floats); asynchronous on `stream` (NULL: the plan's own).  The plan keeps 16 bytes of scratch per output
  * pixel per frame in flight (large batches are cut into groups internally). */

@@ -66,6 +66,11 @@ _PROTOTYPES = {
     "rpsf_apply_device": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(Geometry), c_void_p]),
     "rpsf_apply_device_timed": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(Geometry), c_int, c_void_p, c_void_p]),
     "rpsf_apply_batch": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "rpsf_apply_batch_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int]),
+    "rpsf_apply_frames_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int]),
+    "rpsf_host_threads": (c_int, [POINTER(c_int)]),
+    "rpsf_device_numa_node": (c_int, [c_int, POINTER(c_int)]),
+    "rpsf_pcie_probe": (c_int, [c_int, c_size_t, c_int, POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
     "rpsf_apply_batch_device": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_size_t, POINTER(Geometry),
                                         c_void_p]),
     "rpsf_apply_batch_device_timed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_size_t,
@@ -270,7 +275,7 @@ class Plan:
         return total, kern
 
     def apply_batch(self, images: np.ndarray, pad_mode: int, pad_value: float = 0.0) -> np.ndarray:
-        """(frames, H, W) host stack in, float32 stack out; the frames share the installed transfer kernel."""
+        """(frames, H, W) host stack in, float32 stack out; the frames share the installed transfer kernel (streamed)."""
         imgs = np.ascontiguousarray(images, dtype=np.float32)
         if imgs.ndim != 3:
             msg = "images must have shape (frames, H, W)"
@@ -279,6 +284,41 @@ class Plan:
         if imgs.shape[0]:
             check(lib().rpsf_apply_batch(self._handle, _ptr(imgs), imgs.shape[0], imgs.shape[1], imgs.shape[2], pad_mode,
                                          pad_value, _ptr(out)))
+        return out
+
+    def apply_frames_host(self, images, pad_mode: int, pad_value: float = 0.0, out_dtype=np.float64,
+                          out: np.ndarray | None = None) -> np.ndarray:
+        """The streamed host path (rpsf_apply_frames_host): ``images`` is a (frames, H, W) array or a sequence of 2-D arrays
+        of one shape; float32 / float64 frames are taken as they are (no stacking, no astype on the host side of the call),
+        anything else goes through float32.  Returns (or fills ``out``, C-contiguous float32 / float64) a (frames, H, W) stack.
+        H2D of the next frames, the shared-K launches and D2H + widening of the previous ones overlap on three streams."""
+        frames = [np.asarray(im) for im in images]
+        if not frames:
+            msg = "need at least one frame"
+            raise ValueError(msg)
+        shape = frames[0].shape
+        if len(shape) != 2 or any(f.shape != shape for f in frames):
+            msg = "frames must be two dimensional and of one shape"
+            raise ValueError(msg)
+        is_f64 = all(f.dtype == np.float64 for f in frames)
+        want = np.float64 if is_f64 else np.float32
+        frames = [np.ascontiguousarray(f if f.dtype == want and f.dtype.byteorder != ">" else f.astype(want)) for f in frames]
+        if out is not None:
+            if out.shape != (len(frames), *shape) or not out.flags.c_contiguous or not out.flags.writeable:
+                msg = "out must be a writeable C-contiguous array of shape (frames, H, W)"
+                raise ValueError(msg)
+            out_dtype = out.dtype
+        out_dtype = np.dtype(out_dtype)
+        if out_dtype not in (np.float32, np.float64):
+            msg = "out_dtype must be float32 or float64"
+            raise ValueError(msg)
+        if out is None:
+            out = np.empty((len(frames), *shape), out_dtype)
+        n = len(frames)
+        in_ptrs = (c_void_p * n)(*[f.ctypes.data for f in frames])
+        out_ptrs = (c_void_p * n)(*[out[i].ctypes.data for i in range(n)])
+        check(lib().rpsf_apply_frames_host(self._handle, in_ptrs, int(is_f64), n, shape[0], shape[1], pad_mode, pad_value,
+                                           out_ptrs, int(out_dtype == np.float64)))
         return out
 
     def apply_batch_device(self, images_ptr: c_void_p, outs_ptr: c_void_p, n_frames: int, image_stride: int,
@@ -373,6 +413,49 @@ def psf_model_fft_device(model: str, patch_size: int, params: np.ndarray, normal
         check(lib().rpsf_psf_model_fft_device(device, MODELS[model], patch_size, count, _ptr(q), int(bool(normalize)),
                                               values.ptr if values is not None else None, spectra.ptr))
     return values, spectra
+
+
+def host_threads() -> int:
+    """Width of the library's persistent host worker pool (dtype conversions and staging copies of the host-array entry points)."""
+    n = c_int(0)
+    check(lib().rpsf_host_threads(ctypes.byref(n)))
+    return n.value
+
+
+def device_numa_node(device: int = 0) -> int:
+    """NUMA node the device hangs off (-1: unknown)."""
+    n = c_int(-1)
+    check(lib().rpsf_device_numa_node(device, ctypes.byref(n)))
+    return n.value
+
+
+def bind_to_device_node(device: int = 0) -> int:
+    """Restrict the calling thread (and the threads it starts later) to the CPUs of the device's NUMA node, so that the arrays it
+    allocates from now on are first touched - and therefore placed - next to the GPU.  What `numactl --cpunodebind` does for a
+    one-process-per-GPU launcher; returns the node, or -1 if nothing was changed."""
+    node = device_numa_node(device)
+    if node < 0:
+        return -1
+    try:
+        text = open(f"/sys/devices/system/node/node{node}/cpulist").read().strip()
+        cpus = set()
+        for part in text.split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return -1
+        os.sched_setaffinity(0, cpus)
+    except OSError:
+        return -1
+    return node
+
+
+def pcie_probe(nbytes: int, iters: int = 5, device: int = 0) -> dict:
+    """Milliseconds PCIe takes for ``nbytes`` from / to pinned host memory: each direction alone and both at once."""
+    a, b, c = c_double(0), c_double(0), c_double(0)
+    check(lib().rpsf_pcie_probe(device, int(nbytes), int(iters), ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+    return {"h2d_ms": a.value, "d2h_ms": b.value, "duplex_ms": c.value}
 
 
 def saturation_fill(padded: np.ndarray, mask: np.ndarray, neighborhood_width: int) -> None:

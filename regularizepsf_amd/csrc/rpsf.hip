@@ -22,7 +22,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
-#include <barrier>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -34,6 +34,7 @@
 
 #define RPSF_HOST_TU 1
 #include "rpsf_device.hpp"
+#include "rpsf_hostpipe.hpp"
 
 RPSF_PLANS_V1(RPSF_DECL_V1)
 RPSF_PLANS_V2(RPSF_DECL_V2)
@@ -76,7 +77,6 @@ struct DevBuf {
 // ------------------------------------------------------------------------------------------------
 struct rpsf_plan {
   int device = 0, N = 0, n_patches = 0;
-  size_t stage_bytes = 0;
   int32_t* d_coords = nullptr;
   uint16_t* d_tab = nullptr;
   uint32_t* d_pairtab = nullptr;
@@ -84,8 +84,7 @@ struct rpsf_plan {
   float* d_win = nullptr;
   cf* d_g = nullptr;
   cf* d_gs = nullptr;
-  float* d_img = nullptr;  // staging for the host-pointer entry point
-  float* d_out = nullptr;
+  rpsf_host::HostPipe* pipe = nullptr;  // host-array entry points: staging slots, copy streams (rpsf_hostpipe.hpp)
   bool have_k = false;
   hipStream_t stream = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -158,11 +157,6 @@ struct rpsf_plan {
   float* d_win_generic = nullptr;
   void* fft_plan = nullptr;    // hipfftHandle for fft_chunk patches
   int fft_chunk = 0;
-  // rpsf_apply_host: whole-frame pinned staging (float32) for the input and the output, chunk events
-  float* h_pin_in = nullptr;
-  float* h_pin_out = nullptr;
-  size_t pin_bytes = 0;
-  hipEvent_t ev_chunk[16] = {};
   float* d_carry = nullptr;  // persistent launches: one half patch of private scratch per workgroup
   size_t carry_floats = 0;
   float* d_planes = nullptr;
@@ -721,8 +715,10 @@ extern "C" void rpsf_plan_destroy(rpsf_plan* p) {
   (void)hipFree(p->d_win);
   (void)hipFree(p->d_g);
   (void)hipFree(p->d_gs);
-  (void)hipFree(p->d_img);
-  (void)hipFree(p->d_out);
+  if (p->pipe) {
+    p->pipe->destroy();
+    delete p->pipe;
+  }
   (void)hipFree(p->d_cover);
   (void)hipFree(p->d_desc);
   (void)hipFree(p->d_stamps);
@@ -747,10 +743,6 @@ extern "C" void rpsf_plan_destroy(rpsf_plan* p) {
   if (p->ev_sum_done) (void)hipEventDestroy(p->ev_sum_done);
   if (p->st_sum) (void)hipStreamDestroy(p->st_sum);
   if (p->ev_busy) (void)hipEventDestroy(p->ev_busy);
-  (void)hipHostFree(p->h_pin_in);
-  (void)hipHostFree(p->h_pin_out);
-  for (auto& e : p->ev_chunk)
-    if (e) (void)hipEventDestroy(e);
   for (auto& e : p->ev)
     if (e) (void)hipEventDestroy(e);
   if (p->stream) (void)hipStreamDestroy(p->stream);
@@ -1350,31 +1342,6 @@ extern "C" int rpsf_apply_device(rpsf_plan* p, const void* image_dev, void* out_
   return launch_apply(p, reinterpret_cast<const float*>(image_dev), reinterpret_cast<float*>(out_dev), *geom, st, nullptr);
 }
 
-extern "C" int rpsf_apply(rpsf_plan* p, const float* image_host, int height, int width, int pad_mode, float pad_value,
-                          float* out_host) {
-  if (!p || !image_host || !out_host) return fail(RPSF_E_BADARG, "null argument");
-  if (!p->have_k) return fail(RPSF_E_STATE, "no transfer kernel installed (call rpsf_plan_set_transfer first)");
-  rpsf_geometry g{height, width, pad_mode, pad_value, 0, 0, 0, height, width, 0, height, width};
-  int rc = check_geometry(p, &g);
-  if (rc != RPSF_OK) return rc;
-  HIP_TRY(hipSetDevice(p->device));
-  const size_t bytes = (size_t)height * width * sizeof(float);
-  if (bytes > p->stage_bytes) {
-    (void)hipFree(p->d_img);
-    (void)hipFree(p->d_out);
-    p->d_img = p->d_out = nullptr;
-    p->stage_bytes = 0;
-    HIP_TRY(hipMalloc(&p->d_img, bytes));
-    HIP_TRY(hipMalloc(&p->d_out, bytes));
-    p->stage_bytes = bytes;
-  }
-  HIP_TRY(hipMemcpyAsync(p->d_img, image_host, bytes, hipMemcpyHostToDevice, p->stream));
-  rc = launch_apply(p, p->d_img, p->d_out, g, p->stream, nullptr);
-  if (rc != RPSF_OK) return rc;
-  HIP_TRY(hipMemcpyAsync(out_host, p->d_out, bytes, hipMemcpyDeviceToHost, p->stream));
-  HIP_TRY(hipStreamSynchronize(p->stream));
-  return RPSF_OK;
-}
 
 // Frames per launch group: the colour planes take 16 bytes per output pixel per frame in flight; keep
 // them under a quarter of the device memory.
@@ -1425,6 +1392,45 @@ extern "C" int rpsf_apply_batch_device(rpsf_plan* p, const void* images_dev, voi
                       image_stride, out_stride, *geom, st);
 }
 
+// `iters` applies BACK TO BACK on the plan's stream, each bracketed by its own events (four per iteration, created here and destroyed on
+// return), one synchronisation at the end: the launches queue up behind one another exactly as in a caller's loop, so the event times are
+// those of the loop's kernels (with a host synchronisation after every apply, as until round 4, every launch started on an idle device
+// and read 2 % longer than the wall-clock step that contains it).  total_ms[i]: the whole apply i, kernel_ms[i]: its patch-kernel launches.
+template <class Launch>
+static int timed_loop(rpsf_plan* p, int iters, float* total_ms, float* kernel_ms, Launch&& launch) {
+  std::vector<hipEvent_t> ev((size_t)4 * iters, nullptr);
+  auto cleanup = [&] {
+    for (auto e : ev)
+      if (e) (void)hipEventDestroy(e);
+  };
+  int rc = RPSF_OK;
+  hipError_t err = hipSuccess;
+  for (auto& e : ev)
+    if (err == hipSuccess) err = hipEventCreate(&e);
+  for (int i = 0; i < iters && err == hipSuccess && rc == RPSF_OK; ++i) {
+    err = hipEventRecord(ev[4 * i], p->stream);
+    if (err == hipSuccess) rc = launch(ev[4 * i + 1], ev[4 * i + 2]);
+    if (err == hipSuccess && rc == RPSF_OK) err = hipEventRecord(ev[4 * i + 3], p->stream);
+  }
+  if (err == hipSuccess && rc == RPSF_OK) err = hipStreamSynchronize(p->stream);
+  for (int i = 0; i < iters && err == hipSuccess && rc == RPSF_OK; ++i) {
+    float ms = 0.f;
+    if (total_ms) {
+      err = hipEventElapsedTime(&ms, ev[4 * i], ev[4 * i + 3]);
+      total_ms[i] = ms;
+    }
+    if (kernel_ms && err == hipSuccess) {
+      err = hipEventElapsedTime(&ms, ev[4 * i + 1], ev[4 * i + 2]);
+      kernel_ms[i] = ms;
+    }
+  }
+  if (err != hipSuccess || rc != RPSF_OK) (void)hipStreamSynchronize(p->stream);
+  cleanup();
+  if (rc != RPSF_OK) return rc;
+  if (err != hipSuccess) return fail(RPSF_E_HIP, std::string("timed applies: ") + hipGetErrorString(err));
+  return RPSF_OK;
+}
+
 extern "C" int rpsf_apply_batch_device_timed(rpsf_plan* p, const void* images_dev, void* outs_dev, int n_frames,
                                              size_t image_stride, size_t out_stride, const rpsf_geometry* geom, int iters,
                                              float* total_ms, float* kernel_ms) {
@@ -1432,139 +1438,324 @@ extern "C" int rpsf_apply_batch_device_timed(rpsf_plan* p, const void* images_de
   int rc = check_batch(p, images_dev, outs_dev, n_frames, image_stride, out_stride, geom);
   if (rc != RPSF_OK) return rc;
   HIP_TRY(hipSetDevice(p->device));
-  for (int i = 0; i < iters; ++i) {
-    HIP_TRY(hipEventRecord(p->ev[0], p->stream));
-    rc = launch_batch(p, reinterpret_cast<const float*>(images_dev), reinterpret_cast<float*>(outs_dev), n_frames,
-                      image_stride, out_stride, *geom, p->stream, p->ev[1], p->ev[2]);
-    if (rc != RPSF_OK) return rc;
-    HIP_TRY(hipEventRecord(p->ev[3], p->stream));
-    HIP_TRY(hipEventSynchronize(p->ev[3]));
-    float ms = 0.f;
-    if (total_ms) {
-      HIP_TRY(hipEventElapsedTime(&ms, p->ev[0], p->ev[3]));
-      total_ms[i] = ms;
+  return timed_loop(p, iters, total_ms, kernel_ms, [&](hipEvent_t k0, hipEvent_t k1) {
+    return launch_batch(p, reinterpret_cast<const float*>(images_dev), reinterpret_cast<float*>(outs_dev), n_frames, image_stride,
+                        out_stride, *geom, p->stream, k0, k1);
+  });
+}
+
+// ------------------------------------------------------------------------------------------------
+// Host arrays in, host arrays out (what ArrayPSFTransform.apply hands over and gets back: transform.py:117 astype on the
+// way in, :174-177 a float64 result on the way out).  Nothing below creates a thread or allocates per call once a plan
+// has seen its frame size: conversions run on the persistent pool, staging lives in the plan's HostPipe.
+// ------------------------------------------------------------------------------------------------
+using rpsf_host::HostPipe;
+using rpsf_host::HostPool;
+
+static int pipe_ensure(rpsf_plan* p, size_t slot_floats, int depth) {
+  if (!p->pipe) p->pipe = new HostPipe;
+  HostPipe& q = *p->pipe;
+  if (!q.st_in) {
+    HIP_TRY(hipStreamCreateWithFlags(&q.st_in, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&q.st_out, hipStreamNonBlocking));
+    for (auto* evs : {q.ev_in, q.ev_k, q.ev_out})
+      for (int s = 0; s < HostPipe::MAX_DEPTH; ++s) HIP_TRY(hipEventCreateWithFlags(&evs[s], hipEventDisableTiming));
+    for (auto& e : q.ev_chunk) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  if (slot_floats <= q.slot_floats && depth <= q.depth) return RPSF_OK;
+  // grow (every host entry point drains its own work before it returns: nothing is in flight on these buffers)
+  const size_t want = std::max(slot_floats, q.slot_floats);
+  const int d = std::max(depth, q.depth);
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  q.release_buffers();
+  for (int s = 0; s < d; ++s) {
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&q.h_in[s]), want * sizeof(float), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&q.h_out[s]), want * sizeof(float), hipHostMallocDefault));
+    HIP_TRY(hipMalloc(&q.d_in[s], want * sizeof(float)));
+    HIP_TRY(hipMalloc(&q.d_out[s], want * sizeof(float)));
+  }
+  q.depth = d, q.slot_floats = want;
+  return RPSF_OK;
+}
+
+// Parts of one pool job over `bytes` of staging: a few per thread, so that a thread on a slow core (or the caller's, which may
+// sit on the other socket) simply takes fewer of them; at least 128 KiB each
+static int host_parts_for(size_t bytes) {
+  return (int)std::min<size_t>((size_t)HostPool::get().width() * 4, std::max<size_t>(1, bytes >> 17));
+}
+
+static int drain_after_error(rpsf_plan* p, hipError_t err, const char* where) {
+  (void)hipStreamSynchronize(p->pipe->st_in);
+  (void)hipStreamSynchronize(p->stream);
+  (void)hipStreamSynchronize(p->pipe->st_out);
+  if (err == hipErrorUnknown && !g_err.empty()) return RPSF_E_HIP;  // launch_apply already set the message
+  return fail(RPSF_E_HIP, std::string(where) + ": " + hipGetErrorString(err));
+}
+
+// One frame.  The conversions run chunk by chunk (>= 4 MiB) on the pool, each chunk's H2D copy starts as soon as it is staged,
+// and on the way back each chunk is widened as soon as it has landed: conversion and PCIe overlap inside the frame.
+static int host_one_frame(rpsf_plan* p, const void* image, int in_f64, void* out, int out_f64, const rpsf_geometry& g) {
+  const size_t count = (size_t)g.height * g.width, bytes = count * sizeof(float);
+  int rc = pipe_ensure(p, count, 1);
+  if (rc != RPSF_OK) return rc;
+  HostPipe& q = *p->pipe;
+  HostPool& pool = HostPool::get(p->device);
+  const int T = host_parts_for(bytes / std::max<size_t>(1, std::min<size_t>(HostPipe::MAX_CHUNKS, std::max<size_t>(1, bytes >> 22))));
+  const int n_chunks = (int)std::min<size_t>(HostPipe::MAX_CHUNKS, std::max<size_t>(1, bytes >> 22));
+  const size_t per_chunk = ((count + n_chunks - 1) / n_chunks + 1023) & ~(size_t)1023;
+  auto chunk_range = [&](int c, size_t& lo, size_t& hi) { lo = std::min(count, c * per_chunk), hi = std::min(count, lo + per_chunk); };
+  hipError_t err = hipSuccess;
+  static const bool trace = std::getenv("RPSF_HOST_TRACE") != nullptr;  // development: where a host frame's milliseconds go (stderr)
+  const auto t_start = std::chrono::steady_clock::now();
+  auto ms_since = [&](std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  };
+  double t_conv_in = 0.0, t_conv_out = 0.0, t_wait_out = 0.0;
+  for (int c = 0; c < n_chunks && err == hipSuccess; ++c) {
+    size_t lo, hi;
+    chunk_range(c, lo, hi);
+    const auto t0 = std::chrono::steady_clock::now();
+    pool.run(T, [&](int t) {
+      size_t a, b;
+      rpsf_host::split_range(lo, hi, t, T, a, b);
+      rpsf_host::narrow_or_copy(q.h_in[0], image, in_f64 != 0, a, b);
+    });
+    t_conv_in += ms_since(t0);
+    if (hi > lo) err = hipMemcpyAsync(q.d_in[0] + lo, q.h_in[0] + lo, (hi - lo) * sizeof(float), hipMemcpyHostToDevice, q.st_in);
+  }
+  if (err == hipSuccess) err = hipEventRecord(q.ev_in[0], q.st_in);
+  if (err == hipSuccess) err = hipStreamWaitEvent(p->stream, q.ev_in[0], 0);
+  if (err == hipSuccess && launch_apply(p, q.d_in[0], q.d_out[0], g, p->stream, nullptr) != RPSF_OK) err = hipErrorUnknown;
+  if (err == hipSuccess) err = hipEventRecord(q.ev_k[0], p->stream);
+  if (err == hipSuccess) err = hipStreamWaitEvent(q.st_out, q.ev_k[0], 0);
+  for (int c = 0; c < n_chunks && err == hipSuccess; ++c) {
+    size_t lo, hi;
+    chunk_range(c, lo, hi);
+    if (hi > lo) err = hipMemcpyAsync(q.h_out[0] + lo, q.d_out[0] + lo, (hi - lo) * sizeof(float), hipMemcpyDeviceToHost, q.st_out);
+    if (err == hipSuccess) err = hipEventRecord(q.ev_chunk[c], q.st_out);
+  }
+  const double t_enqueued = ms_since(t_start);
+  double t_in_done = 0.0, t_kernel_done = 0.0;
+  if (trace && err == hipSuccess) {
+    (void)hipEventSynchronize(q.ev_in[0]);
+    t_in_done = ms_since(t_start);
+    (void)hipEventSynchronize(q.ev_k[0]);
+    t_kernel_done = ms_since(t_start);
+  }
+  for (int c = 0; c < n_chunks && err == hipSuccess; ++c) {
+    auto t0 = std::chrono::steady_clock::now();
+    err = hipEventSynchronize(q.ev_chunk[c]);
+    t_wait_out += ms_since(t0);
+    if (err != hipSuccess) break;
+    size_t lo, hi;
+    chunk_range(c, lo, hi);
+    t0 = std::chrono::steady_clock::now();
+    pool.run(T, [&](int t) {
+      size_t a, b;
+      rpsf_host::split_range(lo, hi, t, T, a, b);
+      rpsf_host::widen_or_copy(out, out_f64 != 0, q.h_out[0], a, b);
+    });
+    t_conv_out += ms_since(t0);
+  }
+  if (trace)
+    std::fprintf(stderr, "[rpsf host frame] %d chunks x %d threads: staged+enqueued %.3f ms (conversions %.3f), H2D done %.3f, kernel done %.3f, "
+                 "out: waits %.3f + conversions %.3f, total %.3f ms\n", n_chunks, T, t_enqueued, t_conv_in, t_in_done, t_kernel_done, t_wait_out,
+                 t_conv_out, ms_since(t_start));
+  if (err != hipSuccess) return drain_after_error(p, err, "host frame");
+  return RPSF_OK;
+}
+
+// Frames per group of the streamed pipeline: small frames go through the shared-K batch launch a few at a time (the packed K is
+// read once per group, and a launch / a copy of a few hundred KiB is all overhead); from 16 MiB per frame on (2048^2), where a
+// frame's copies take several times its kernel, one by one - a short batch then pays the shortest ramp.
+static int stream_group_frames(size_t frame_bytes, int n_frames) {
+  int g = (int)std::max<size_t>(1, std::min<size_t>(8, ((size_t)16 << 20) / std::max<size_t>(1, frame_bytes)));
+  if (const char* e = std::getenv("RPSF_STREAM_GROUP")) g = std::max(1, std::min(64, std::atoi(e)));  // development sweeps
+  return std::min(g, n_frames);
+}
+
+// A sequence of frames of one geometry: `depth` groups in flight.  The calling thread stages group i (conversion on the pool),
+// enqueues H2D(i) on the copy-in stream, the shared-K launch of the group on the plan's stream behind it, D2H(i) on the copy-out
+// stream behind that, and - in the same pool job as the staging of the next group - widens whichever earlier group has landed.
+// H2D of group i + 1, the kernel of group i and D2H of group i - 1 therefore run at the same time (PCIe is full duplex), and the
+// host conversions of both directions share the pool.
+static int host_frames(rpsf_plan* p, const void* const* images, int in_f64, void* const* outs, int out_f64, int n_frames,
+                       const rpsf_geometry& g) {
+  if (n_frames == 1) return host_one_frame(p, images[0], in_f64, outs[0], out_f64, g);
+  const size_t count = (size_t)g.height * g.width, bytes = count * sizeof(float);
+  const int G = stream_group_frames(bytes, n_frames);
+  const int n_groups = (n_frames + G - 1) / G;
+  int depth = bytes * G >= ((size_t)128 << 20) ? 3 : HostPipe::MAX_DEPTH;
+  if (const char* e = std::getenv("RPSF_STREAM_DEPTH")) depth = std::max(1, std::min((int)HostPipe::MAX_DEPTH, std::atoi(e)));
+  depth = std::min(depth, n_groups);
+  int rc = pipe_ensure(p, count * G, depth);
+  if (rc != RPSF_OK) return rc;
+  HostPipe& q = *p->pipe;
+  HostPool& pool = HostPool::get(p->device);
+  const int T = host_parts_for(bytes);
+  auto frames_of = [&](int grp) { return std::min(G, n_frames - grp * G); };
+  hipError_t err = hipSuccess;
+  int next_in = 0, next_out = 0;
+  while (next_out < n_groups && err == hipSuccess) {
+    const bool can_in = next_in < n_groups && next_in - next_out < depth;
+    bool out_ready = false;
+    if (next_out < next_in) {
+      const hipError_t qe = hipEventQuery(q.ev_out[next_out % depth]);
+      if (qe == hipSuccess) out_ready = true;
+      else if (qe != hipErrorNotReady) err = qe;
+      if (err == hipSuccess && !out_ready && !can_in) {  // nothing to stage: wait for the oldest group in flight
+        err = hipEventSynchronize(q.ev_out[next_out % depth]);
+        out_ready = err == hipSuccess;
+      }
     }
-    if (kernel_ms) {
-      HIP_TRY(hipEventElapsedTime(&ms, p->ev[1], p->ev[2]));
-      kernel_ms[i] = ms;
+    if (err != hipSuccess) break;
+    const int si = next_in % depth, so = next_out % depth;
+    const int fi = can_in ? frames_of(next_in) : 0, fo = out_ready ? frames_of(next_out) : 0;
+    pool.run(T, [&](int t) {
+      size_t a, b;
+      rpsf_host::split_range(0, count, t, T, a, b);
+      for (int f = 0; f < fi; ++f) rpsf_host::narrow_or_copy(q.h_in[si] + (size_t)f * count, images[next_in * G + f], in_f64 != 0, a, b);
+      for (int f = 0; f < fo; ++f) rpsf_host::widen_or_copy(outs[next_out * G + f], out_f64 != 0, q.h_out[so] + (size_t)f * count, a, b);
+    });
+    if (can_in) {
+      const size_t gb = (size_t)fi * bytes;
+      err = hipMemcpyAsync(q.d_in[si], q.h_in[si], gb, hipMemcpyHostToDevice, q.st_in);
+      if (err == hipSuccess) err = hipEventRecord(q.ev_in[si], q.st_in);
+      if (err == hipSuccess) err = hipStreamWaitEvent(p->stream, q.ev_in[si], 0);
+      if (err == hipSuccess && launch_batch(p, q.d_in[si], q.d_out[si], fi, count, count, g, p->stream) != RPSF_OK) err = hipErrorUnknown;
+      if (err == hipSuccess) err = hipEventRecord(q.ev_k[si], p->stream);
+      if (err == hipSuccess) err = hipStreamWaitEvent(q.st_out, q.ev_k[si], 0);
+      if (err == hipSuccess) err = hipMemcpyAsync(q.h_out[si], q.d_out[si], gb, hipMemcpyDeviceToHost, q.st_out);
+      if (err == hipSuccess) err = hipEventRecord(q.ev_out[si], q.st_out);
+      ++next_in;
     }
+    if (out_ready) ++next_out;
+  }
+  if (err != hipSuccess) return drain_after_error(p, err, "streamed frames");
+  return RPSF_OK;
+}
+
+static int check_host_call(rpsf_plan* p, const void* a, const void* b, int n_frames, int height, int width, int pad_mode, float pad_value,
+                           rpsf_geometry* g) {
+  if (!p || !a || !b) return fail(RPSF_E_BADARG, "null argument");
+  if (n_frames <= 0) return fail(RPSF_E_BADARG, "n_frames must be positive");
+  if (!p->have_k) return fail(RPSF_E_STATE, "no transfer kernel installed (call rpsf_plan_set_transfer first)");
+  *g = rpsf_geometry{height, width, pad_mode, pad_value, 0, 0, 0, height, width, 0, height, width};
+  int rc = check_geometry(p, g);
+  if (rc != RPSF_OK) return rc;
+  HIP_TRY(hipSetDevice(p->device));
+  return RPSF_OK;
+}
+
+extern "C" int rpsf_apply_frames_host(rpsf_plan* p, const void* const* images_host, int image_is_f64, int n_frames, int height,
+                                      int width, int pad_mode, float pad_value, void* const* outs_host, int out_is_f64) {
+  rpsf_geometry g;
+  int rc = check_host_call(p, images_host, outs_host, n_frames, height, width, pad_mode, pad_value, &g);
+  if (rc != RPSF_OK) return rc;
+  for (int f = 0; f < n_frames; ++f)
+    if (!images_host[f] || !outs_host[f]) return fail(RPSF_E_BADARG, "null frame pointer");
+  return host_frames(p, images_host, image_is_f64, outs_host, out_is_f64, n_frames, g);
+}
+
+extern "C" int rpsf_apply_batch_host(rpsf_plan* p, const void* images_host, int image_is_f64, int n_frames, int height, int width,
+                                     int pad_mode, float pad_value, void* outs_host, int out_is_f64) {
+  rpsf_geometry g;
+  int rc = check_host_call(p, images_host, outs_host, n_frames, height, width, pad_mode, pad_value, &g);
+  if (rc != RPSF_OK) return rc;
+  const size_t count = (size_t)height * width;
+  std::vector<const void*> in(n_frames);
+  std::vector<void*> out(n_frames);
+  for (int f = 0; f < n_frames; ++f) {
+    in[f] = static_cast<const char*>(images_host) + (size_t)f * count * (image_is_f64 ? 8 : 4);
+    out[f] = static_cast<char*>(outs_host) + (size_t)f * count * (out_is_f64 ? 8 : 4);
+  }
+  return host_frames(p, in.data(), image_is_f64, out.data(), out_is_f64, n_frames, g);
+}
+
+extern "C" int rpsf_apply_batch(rpsf_plan* p, const float* images_host, int n_frames, int height, int width, int pad_mode,
+                                float pad_value, float* outs_host) {
+  return rpsf_apply_batch_host(p, images_host, 0, n_frames, height, width, pad_mode, pad_value, outs_host, 0);
+}
+
+extern "C" int rpsf_apply_host(rpsf_plan* p, const void* image_host, int image_is_f64, int height, int width, int pad_mode,
+                               float pad_value, void* out_host, int out_is_f64) {
+  rpsf_geometry g;
+  int rc = check_host_call(p, image_host, out_host, 1, height, width, pad_mode, pad_value, &g);
+  if (rc != RPSF_OK) return rc;
+  return host_one_frame(p, image_host, image_is_f64, out_host, out_is_f64, g);
+}
+
+extern "C" int rpsf_apply(rpsf_plan* p, const float* image_host, int height, int width, int pad_mode, float pad_value,
+                          float* out_host) {
+  return rpsf_apply_host(p, image_host, 0, height, width, pad_mode, pad_value, out_host, 0);
+}
+
+// The NUMA node the device hangs off (-1: unknown / a single-node host): where a process that feeds this GPU from host arrays should
+// run and allocate (the pool's workers are placed there by themselves).
+extern "C" int rpsf_device_numa_node(int device, int* node) {
+  if (!node) return fail(RPSF_E_BADARG, "null argument");
+  *node = -1;
+  char bdf[64] = {};
+  HIP_TRY(hipDeviceGetPCIBusId(bdf, sizeof(bdf), device));
+  for (char* c = bdf; *c; ++c) *c = (char)std::tolower(*c);
+  const std::string path = std::string("/sys/bus/pci/devices/") + bdf + "/numa_node";
+  if (FILE* f = std::fopen(path.c_str(), "r")) {
+    if (std::fscanf(f, "%d", node) != 1) *node = -1;
+    std::fclose(f);
   }
   return RPSF_OK;
 }
 
-// Host frames in, host frames out: frame by frame through rpsf_apply (for float32 on both sides the runtime's own
-// pageable copies beat the threaded pinned staging of rpsf_apply_host on 16 MB frames: 1.5 vs 2.1 ms).
-// PCIe dominates here; the shared-K launch of rpsf_apply_batch_device is for frames that live on the device.
-extern "C" int rpsf_apply_batch(rpsf_plan* p, const float* images_host, int n_frames, int height, int width, int pad_mode,
-                                float pad_value, float* outs_host) {
-  rpsf_geometry g{height, width, pad_mode, pad_value, 0, 0, 0, height, width, 0, height, width};
-  const size_t frame_floats = (size_t)height * width;
-  int rc = check_batch(p, images_host, outs_host, n_frames, frame_floats, frame_floats, &g);
-  for (int f = 0; f < n_frames && rc == RPSF_OK; ++f)
-    rc = rpsf_apply(p, images_host + (size_t)f * frame_floats, height, width, pad_mode, pad_value,
-                    outs_host + (size_t)f * frame_floats);
-  return rc;
+extern "C" int rpsf_host_threads(int* threads) {
+  if (!threads) return fail(RPSF_E_BADARG, "null argument");
+  *threads = HostPool::get().width();
+  return RPSF_OK;
 }
 
-// Host frame in (float32 or float64), host frame out (float32 or float64) - what ArrayPSFTransform.apply
-// hands over and gets back (transform.py:117 astype, :174-177 float64 result).  The dtype conversions run on
-// a few host threads in chunks, through pinned staging, overlapped with the PCIe copies; fresh output pages are
-// first touched by all threads instead of one.
-extern "C" int rpsf_apply_host(rpsf_plan* p, const void* image_host, int image_is_f64, int height, int width,
-                               int pad_mode, float pad_value, void* out_host, int out_is_f64) {
-  if (!p || !image_host || !out_host) return fail(RPSF_E_BADARG, "null argument");
-  if (!p->have_k) return fail(RPSF_E_STATE, "no transfer kernel installed (call rpsf_plan_set_transfer first)");
-  rpsf_geometry g{height, width, pad_mode, pad_value, 0, 0, 0, height, width, 0, height, width};
-  int rc = check_geometry(p, &g);
-  if (rc != RPSF_OK) return rc;
-  HIP_TRY(hipSetDevice(p->device));
-  const size_t count = (size_t)height * width, bytes = count * sizeof(float);
-  if (bytes > p->stage_bytes) {
-    (void)hipFree(p->d_img);
-    (void)hipFree(p->d_out);
-    p->d_img = p->d_out = nullptr;
-    p->stage_bytes = 0;
-    HIP_TRY(hipMalloc(&p->d_img, bytes));
-    HIP_TRY(hipMalloc(&p->d_out, bytes));
-    p->stage_bytes = bytes;
-  }
-  if (bytes > p->pin_bytes) {
-    (void)hipHostFree(p->h_pin_in);
-    (void)hipHostFree(p->h_pin_out);
-    p->h_pin_in = p->h_pin_out = nullptr;
-    p->pin_bytes = 0;
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->h_pin_in), bytes, hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->h_pin_out), bytes, hipHostMallocDefault));
-    p->pin_bytes = bytes;
-  }
-  constexpr int MAXC = 16;
-  for (auto& e : p->ev_chunk)
-    if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  const int n_chunks = (int)std::min<size_t>(MAXC, std::max<size_t>(1, bytes >> 22));  // >= 4 MiB per chunk
-  const int n_threads = (int)std::min<size_t>({(size_t)16, (size_t)std::max(1u, std::thread::hardware_concurrency()),
-                                               std::max<size_t>(1, bytes >> 20)});
-  const size_t per_chunk = (count + n_chunks - 1) / n_chunks;
-  auto chunk_range = [&](int c, size_t& lo, size_t& hi) { lo = std::min(count, c * per_chunk), hi = std::min(count, lo + per_chunk); };
-  auto my_range = [&](size_t lo, size_t hi, int tid, size_t& a, size_t& b) {
-    const size_t span = (hi - lo + n_threads - 1) / n_threads;
-    a = std::min(hi, lo + tid * span), b = std::min(hi, a + span);
-  };
-  hipError_t err = hipSuccess;  // written by thread 0 only
-  std::barrier sync(n_threads);
-  auto worker = [&](int tid) {
-    // ---- in: convert / copy into pinned staging chunk by chunk; thread 0 starts each chunk's H2D
-    for (int c = 0; c < n_chunks; ++c) {
-      size_t lo, hi, a, b;
-      chunk_range(c, lo, hi);
-      my_range(lo, hi, tid, a, b);
-      if (image_is_f64) {
-        const double* src = static_cast<const double*>(image_host);
-        for (size_t i = a; i < b; ++i) p->h_pin_in[i] = (float)src[i];
-      } else if (b > a) {
-        std::memcpy(p->h_pin_in + a, static_cast<const float*>(image_host) + a, (b - a) * sizeof(float));
-      }
-      sync.arrive_and_wait();
-      if (tid == 0 && err == hipSuccess && hi > lo)
-        err = hipMemcpyAsync(p->d_img + lo, p->h_pin_in + lo, (hi - lo) * sizeof(float), hipMemcpyHostToDevice, p->stream);
+// What PCIe gives a frame on this box: `bytes` from pinned host memory to the device, back, and both at once on two streams,
+// `iters` times each (best).  The floor that the streamed entry points are measured against (end-to-end is reported
+// separately from the device-resident figure).
+extern "C" int rpsf_pcie_probe(int device, size_t bytes, int iters, double* h2d_ms, double* d2h_ms, double* duplex_ms) {
+  if (bytes == 0 || iters <= 0) return fail(RPSF_E_BADARG, "bad argument");
+  HIP_TRY(hipSetDevice(device));
+  struct Res {
+    void *h0 = nullptr, *h1 = nullptr;
+    DevBuf d0, d1;
+    hipStream_t s0 = nullptr, s1 = nullptr;
+    hipEvent_t e[4] = {};
+    ~Res() {
+      (void)hipHostFree(h0);
+      (void)hipHostFree(h1);
+      for (auto& x : e)
+        if (x) (void)hipEventDestroy(x);
+      if (s0) (void)hipStreamDestroy(s0);
+      if (s1) (void)hipStreamDestroy(s1);
     }
-    // ---- compute + chunked D2H, all enqueued by thread 0
-    if (tid == 0 && err == hipSuccess) {
-      if (launch_apply(p, p->d_img, p->d_out, g, p->stream, nullptr) != RPSF_OK) err = hipErrorUnknown;
-      for (int c = 0; c < n_chunks && err == hipSuccess; ++c) {
-        size_t lo, hi;
-        chunk_range(c, lo, hi);
-        if (hi > lo)
-          err = hipMemcpyAsync(p->h_pin_out + lo, p->d_out + lo, (hi - lo) * sizeof(float), hipMemcpyDeviceToHost, p->stream);
-        if (err == hipSuccess) err = hipEventRecord(p->ev_chunk[c], p->stream);
-      }
+  } r;
+  HIP_TRY(hipHostMalloc(&r.h0, bytes, hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc(&r.h1, bytes, hipHostMallocDefault));
+  std::memset(r.h0, 1, bytes);
+  std::memset(r.h1, 2, bytes);
+  HIP_TRY(r.d0.alloc(bytes));
+  HIP_TRY(r.d1.alloc(bytes));
+  HIP_TRY(hipStreamCreateWithFlags(&r.s0, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&r.s1, hipStreamNonBlocking));
+  for (auto& x : r.e) HIP_TRY(hipEventCreate(&x));
+  double best[3] = {1e30, 1e30, 1e30};
+  for (int mode = 0; mode < 3; ++mode)
+    for (int i = 0; i < iters + 1; ++i) {  // (the first pass of a mode is a warm-up)
+      HIP_TRY(hipDeviceSynchronize());
+      const auto t0 = std::chrono::steady_clock::now();
+      if (mode != 1) HIP_TRY(hipMemcpyAsync(r.d0.p, r.h0, bytes, hipMemcpyHostToDevice, r.s0));
+      if (mode != 0) HIP_TRY(hipMemcpyAsync(r.h1, r.d1.p, bytes, hipMemcpyDeviceToHost, r.s1));
+      HIP_TRY(hipStreamSynchronize(r.s0));
+      HIP_TRY(hipStreamSynchronize(r.s1));
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      if (i > 0) best[mode] = std::min(best[mode], ms);
     }
-    // ---- out: as each chunk lands, convert / copy it into the caller's array
-    for (int c = 0; c < n_chunks; ++c) {
-      if (tid == 0 && err == hipSuccess) err = hipEventSynchronize(p->ev_chunk[c]);
-      sync.arrive_and_wait();  // publishes err and the chunk
-      if (err != hipSuccess) continue;
-      size_t lo, hi, a, b;
-      chunk_range(c, lo, hi);
-      my_range(lo, hi, tid, a, b);
-      if (out_is_f64) {
-        double* dst = static_cast<double*>(out_host);
-        for (size_t i = a; i < b; ++i) dst[i] = (double)p->h_pin_out[i];
-      } else if (b > a) {
-        std::memcpy(static_cast<float*>(out_host) + a, p->h_pin_out + a, (b - a) * sizeof(float));
-      }
-    }
-  };
-  {
-    std::vector<std::thread> pool;
-    for (int t = 1; t < n_threads; ++t) pool.emplace_back(worker, t);
-    worker(0);
-    for (auto& t : pool) t.join();
-  }
-  if (err != hipSuccess) {
-    (void)hipStreamSynchronize(p->stream);
-    if (err == hipErrorUnknown && !g_err.empty()) return RPSF_E_HIP;  // launch_apply already set the message
-    return fail(RPSF_E_HIP, std::string("rpsf_apply_host: ") + hipGetErrorString(err));
-  }
+  if (h2d_ms) *h2d_ms = best[0];
+  if (d2h_ms) *d2h_ms = best[1];
+  if (duplex_ms) *duplex_ms = best[2];
   return RPSF_OK;
 }
 
@@ -1575,24 +1766,9 @@ extern "C" int rpsf_apply_device_timed(rpsf_plan* p, const void* image_dev, void
   int rc = check_geometry(p, geom);
   if (rc != RPSF_OK) return rc;
   HIP_TRY(hipSetDevice(p->device));
-  for (int i = 0; i < iters; ++i) {
-    HIP_TRY(hipEventRecord(p->ev[0], p->stream));
-    rc = launch_apply(p, reinterpret_cast<const float*>(image_dev), reinterpret_cast<float*>(out_dev), *geom,
-                      p->stream, p->ev[1], p->ev[2]);
-    if (rc != RPSF_OK) return rc;
-    HIP_TRY(hipEventRecord(p->ev[3], p->stream));
-    HIP_TRY(hipEventSynchronize(p->ev[3]));
-    float ms = 0.f;
-    if (total_ms) {
-      HIP_TRY(hipEventElapsedTime(&ms, p->ev[0], p->ev[3]));
-      total_ms[i] = ms;
-    }
-    if (kernel_ms) {  // the patch kernel alone
-      HIP_TRY(hipEventElapsedTime(&ms, p->ev[1], p->ev[2]));
-      kernel_ms[i] = ms;
-    }
-  }
-  return RPSF_OK;
+  return timed_loop(p, iters, total_ms, kernel_ms, [&](hipEvent_t k0, hipEvent_t k1) {
+    return launch_apply(p, reinterpret_cast<const float*>(image_dev), reinterpret_cast<float*>(out_dev), *geom, p->stream, k0, k1);
+  });
 }
 
 // ------------------------------------------------------------------------------------------------

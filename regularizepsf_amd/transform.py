@@ -277,52 +277,55 @@ class ArrayPSFTransform:
     #: pre-1.0 name of :meth:`apply` (the task description refers to it)
     correct_image = apply
 
-    def apply_batch(self, images: np.ndarray, workers: int | None = None, pad_mode: str = "symmetric",
+    def apply_batch(self, images, workers: int | None = None, pad_mode: str = "symmetric",
                     saturation_threshold: float = math.inf, saturation_dilation: int = 1,
-                    neighborhood_width: int = 7, dtype: type = np.float64) -> np.ndarray:
-        """Apply the transform to a stack of images ``(frames, H, W)``; returns a stack of the same shape.
+                    neighborhood_width: int = 7, dtype: type = np.float64, out: np.ndarray | None = None) -> np.ndarray:
+        """Apply the transform to a stack ``(frames, H, W)`` or a sequence of equally shaped images; returns a stack.
 
-        Equivalent to ``np.stack([self.apply(im, ...) for im in images])`` (what a user of the reference
-        writes) without the intermediate arrays: every frame goes through the threaded host path straight into
-        the result stack.  Frames that already live on the GPU should use ``_native.Plan.apply_batch_device``,
-        which corrects the whole stack in one launch and reads the transfer kernel once per batch.
-        ``dtype`` is the result dtype (the reference returns float64; ``np.float32`` skips the conversion).
+        Equivalent to ``np.stack([self.apply(im, ...) for im in images])`` - the loop a user of the reference writes
+        (docs/source/example.ipynb over transform.py:85-177) - and bit-identical to it, but streamed: while one group
+        of frames is corrected, the next one crosses PCIe to the device and the previous one comes back and is widened to
+        float64, on three streams and a persistent pool of host threads (``rpsf_apply_frames_host``).  Frames that already
+        live on the GPU should use ``_native.Plan.apply_batch_device``.  ``dtype`` is the result dtype (the reference
+        returns float64; ``np.float32`` skips the widening); ``out`` an existing C-contiguous stack to fill.
         Extension of the reference API - there is no ``apply_batch`` upstream.
         """
         with self._lock:
             return self._apply_batch_locked(images, workers, pad_mode, saturation_threshold, saturation_dilation,
-                                            neighborhood_width, dtype)
+                                            neighborhood_width, dtype, out)
 
     def _apply_batch_locked(self, images, workers, pad_mode, saturation_threshold, saturation_dilation, neighborhood_width,
-                            dtype) -> np.ndarray:
-        images = np.asarray(images)
-        if images.ndim != 3:
-            msg = f"images must have shape (frames, H, W), got {images.shape}"
-            raise ValueError(msg)
-        if saturation_threshold != math.inf or pad_mode not in _native.PAD_MODES or images.shape[0] == 0:
+                            dtype, out) -> np.ndarray:
+        if isinstance(images, np.ndarray):
+            if images.ndim != 3:
+                msg = f"images must have shape (frames, H, W), got {images.shape}"
+                raise ValueError(msg)
+            frames = list(images)
+            shape = images.shape[1:]
+        else:
+            frames = [np.asarray(im) for im in images]
+            shape = frames[0].shape if frames else (0, 0)
+            if any(f.ndim != 2 or f.shape != shape for f in frames):
+                msg = "images must be a sequence of two dimensional arrays of one shape"
+                raise ValueError(msg)
+        dtype = np.dtype(out.dtype if out is not None else dtype)
+        if (saturation_threshold != math.inf or pad_mode not in _native.PAD_MODES or not frames
+                or dtype not in (np.float32, np.float64)):
             outs = [self.apply(im, workers, pad_mode, saturation_threshold, saturation_dilation, neighborhood_width)
-                    for im in images]
-            return np.stack(outs).astype(dtype, copy=False) if outs else np.empty(images.shape, dtype)
+                    for im in frames]
+            res = np.stack(outs).astype(dtype, copy=False) if outs else np.empty((0, *shape), dtype)
+            if out is not None:
+                out[...] = res
+                return out
+            return res
         if len(self) == 0:
             msg = "need at least one array to stack"
             raise ValueError(msg)
         n = self._checked_patch_size()
         plan = self._device_plan()
-        _, height, width = images.shape
+        height, width = shape
         self._check_corners(n, height, width)
-        dtype = np.dtype(dtype)
-        if dtype not in (np.float32, np.float64):
-            return plan.apply_batch(images.astype(np.float32, copy=False), _native.PAD_MODES[pad_mode]).astype(dtype)
-        # Host arrays: PCIe and the dtype conversions dominate, and the threaded pinned-staging path of
-        # rpsf_apply_host moves a frame faster than the shared-K batch launch saves (32 frames of 2048^2: 68 ms
-        # against 85 ms).  The shared-K launch is for frames that already live on the device
-        # (_native.Plan.apply_batch_device / rpsf_apply_batch_device).
-        if images.dtype == np.float32 and dtype == np.float32:  # no conversion anywhere: the plain float32 entry point
-            return plan.apply_batch(images, _native.PAD_MODES[pad_mode])
-        out = np.empty(images.shape, dtype)
-        for f in range(images.shape[0]):
-            plan.apply_host(images[f], _native.PAD_MODES[pad_mode], out=out[f])
-        return out
+        return plan.apply_frames_host(frames, _native.PAD_MODES[pad_mode], out_dtype=dtype, out=out)
 
     # ------------------------------------------------------------------ persistence (transform.py:220-282)
     def save(self, path: pathlib.Path, overwrite: bool = False) -> None:

@@ -1,0 +1,91 @@
+"""Non-finite pixels and large pedestals on the default (no saturation) path.
+
+The reference poisons exactly the patches that contain a NaN / Inf pixel: `fft2(w * patch)` of such a patch is non-finite in every bin,
+so after `ifft2(. * K)` the whole patch is NaN and the overlap-add (regularizepsf/transform.py:163-169) spreads it over the four patches
+that cover the pixel - and, through np.pad's mirror, over the patches that read its reflection (transform.py:119-123).  Real PUNCH
+frames carry NaN masks; the kernels' window tables, rim selects and fused tile sums must reproduce that pattern, not launder it.
+"""
+
+import numpy as np
+import pytest
+
+import regularizepsf_amd as rp
+from oracle import regpsf_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5  # north_star: 1e-5 relative float32, on the finite pixels (SURVEY 8d metric)
+
+
+def _setup(n, shape, seed):
+    h, w = shape
+    coords, k = orc.synthetic_transfer(h, w, n, alpha=3.0, epsilon=0.1)
+    return coords, k, orc.starfield(h, w, seed)
+
+
+def _compare(out, ref):
+    assert out.dtype == np.float64 and out.shape == ref.shape
+    bad_ref, bad_out = ~np.isfinite(ref), ~np.isfinite(out)
+    assert np.array_equal(bad_out, bad_ref), f"non-finite pattern differs: {bad_out.sum()} vs {bad_ref.sum()} pixels"
+    assert np.array_equal(np.isnan(out), np.isnan(ref))
+    good = ~bad_ref
+    assert good.any()
+    d = out[good] - ref[good]
+    assert np.abs(d).max() <= TOL * np.abs(ref[good]).max()
+    assert np.linalg.norm(d) <= TOL * np.linalg.norm(ref[good])
+    return int(bad_ref.sum())
+
+
+CASES = [(32, (160, 192)), (64, (256, 320)), (128, (512, 640)), (256, (1024, 1280))]
+SPOTS = {  # where the bad pixel sits: inside, on the rim (np.pad mirrors it), in the image corner
+    "interior": lambda h, w, n: (h // 2 + 3, w // 2 - 5),
+    "rim": lambda h, w, n: (1, w // 2 + 1),
+    "corner": lambda h, w, n: (h - 1, w - 1),
+    "patch_seam": lambda h, w, n: (n // 2, n),
+}
+
+
+@pytest.mark.parametrize(("n", "shape"), CASES)
+@pytest.mark.parametrize("spot", sorted(SPOTS))
+@pytest.mark.parametrize("value", [np.nan, np.inf, -np.inf])
+def test_a_non_finite_pixel_poisons_exactly_the_patches_the_reference_poisons(n, shape, spot, value):
+    coords, k, image = _setup(n, shape, 7 + n)
+    r, c = SPOTS[spot](*shape, n)
+    image[r, c] = value
+    ref = orc.apply_transfer(image, coords, k)
+    out = rp.ArrayPSFTransform(rp.IndexedCube(coords, k)).apply(image)
+    poisoned = _compare(out, ref)
+    assert poisoned >= (n // 2) ** 2  # at least the lattice tile around the pixel
+
+
+@pytest.mark.parametrize(("n", "shape"), [(32, (160, 192)), (128, (512, 640)), (256, (1024, 1280))])
+def test_nan_mask_regions_in_a_batch_and_other_pad_modes(n, shape):
+    """A masked block (as a detector mask would be), several isolated NaNs, 'reflect' / 'constant' / 'wrap' padding, and the same
+    frames through the streamed batch path: the pattern is the reference's in every frame, and clean frames of the batch stay clean."""
+    coords, k, image = _setup(n, shape, 3 * n)
+    h, w = shape
+    masked = image.copy()
+    masked[h // 3 : h // 3 + 9, w // 4 : w // 4 + 17] = np.nan
+    masked[0, 0] = np.nan
+    masked[h - 2, 5] = np.inf
+    t = rp.ArrayPSFTransform(rp.IndexedCube(coords, k))
+    for pad_mode in ("reflect", "constant", "wrap"):
+        _compare(t.apply(masked, pad_mode=pad_mode), orc.apply_transfer(masked, coords, k, pad_mode=pad_mode))
+    batch = t.apply_batch(np.stack([image, masked, image[::-1].copy()]))
+    _compare(batch[1], orc.apply_transfer(masked, coords, k))
+    assert np.isfinite(batch[0]).all() and np.isfinite(batch[2]).all()
+    assert np.array_equal(batch[0], t.apply(image))
+
+
+@pytest.mark.parametrize(("n", "shape"), [(32, (160, 192)), (128, (512, 640)), (256, (768, 1024))])
+def test_float64_image_on_a_1e7_pedestal(n, shape):
+    """The reference computes in float64 (transform.py:117); the kernels narrow to float32.  A frame riding on a 1e7 pedestal (bias not
+    subtracted) must still meet the norm-relative bar, float64 in and float32 in alike."""
+    coords, k, image = _setup(n, shape, 11)
+    image64 = image.astype(np.float64) + 1.0e7
+    ref = orc.apply_transfer(image64, coords, k)
+    t = rp.ArrayPSFTransform(rp.IndexedCube(coords, k))
+    for frame in (image64, image64.astype(np.float32)):
+        out = t.apply(frame)
+        ref_f = ref if frame.dtype == np.float64 else orc.apply_transfer(frame, coords, k)
+        d = out - ref_f
+        assert np.abs(d).max() <= TOL * np.abs(ref_f).max() and np.linalg.norm(d) <= TOL * np.linalg.norm(ref_f)

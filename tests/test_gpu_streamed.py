@@ -1,0 +1,137 @@
+"""The streamed host path (rpsf_apply_frames_host / ArrayPSFTransform.apply_batch): host frames in, host frames out on three
+streams and the persistent worker pool - bit-identical to the frame-by-frame loop a user of the reference writes
+(`[transform.apply(image) for image in images]`, regularizepsf/transform.py:85-177), and against the oracle."""
+
+import threading
+
+import numpy as np
+import pytest
+
+import regularizepsf_amd as rp
+from oracle import regpsf_oracle as orc
+from regularizepsf_amd import _native
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5  # north_star: 1e-5 relative float32 (max|d| <= TOL max|ref| and rel. L2 <= TOL)
+
+
+def check(out, ref):
+    d = out.astype(np.float64) - ref
+    assert np.abs(d).max() <= TOL * np.abs(ref).max()
+    assert np.linalg.norm(d) <= TOL * np.linalg.norm(ref)
+
+
+def _case(n, shape, frames, seed):
+    rng = np.random.default_rng(seed)
+    coords = [tuple(int(v) for v in c) for c in rp.calculate_covering(shape, n)]
+    k = ((rng.standard_normal((len(coords), n, n)) + 1j * rng.standard_normal((len(coords), n, n))) * 0.2).astype(np.complex64)
+    images = (rng.standard_normal((frames, *shape)) * 10 + 100).astype(np.float32)
+    return coords, k, images
+
+
+def test_config5_eight_2048_frames_streamed_equals_the_loop_and_the_oracle():
+    """BASELINE config 5 (one GPU's share): 8 starfields of 2048^2, 128-px patches, one coma K - streamed == loop bit for bit,
+    first and last frame against the float64 oracle."""
+    h = w = 2048
+    n, frames = 128, 8
+    coords, k = orc.synthetic_transfer(h, w, n, alpha=3.0, epsilon=0.1)
+    images = np.stack([orc.starfield(h, w, 100 + i) for i in range(frames)])
+    t = rp.ArrayPSFTransform(rp.IndexedCube(coords, k))
+    streamed = t.apply_batch(images)
+    assert streamed.dtype == np.float64 and streamed.shape == images.shape
+    for f in range(frames):
+        assert np.array_equal(streamed[f], t.apply(images[f])), f
+    for f in (0, frames - 1):
+        check(streamed[f], orc.apply_transfer(images[f], coords, k, workers=-1))
+
+
+@pytest.mark.parametrize(("n", "shape", "frames", "group", "depth"), [
+    (32, (96, 80), 11, 1, 4), (32, (96, 80), 11, 3, 2), (64, (200, 256), 7, 2, 3), (128, (384, 512), 9, 1, 1),
+    (128, (384, 512), 9, 4, 4), (256, (512, 768), 5, 1, 4), (256, (512, 768), 5, 2, 2), (20, (50, 60), 6, 4, 3)])
+def test_streamed_groups_depths_and_dtypes(n, shape, frames, group, depth, monkeypatch):
+    """Every group size / pipeline depth (short last group, slots reused several times), float32 and float64 on either
+    side, stacks and lists of arrays: the streamed result is the loop's, bit for bit."""
+    monkeypatch.setenv("RPSF_STREAM_GROUP", str(group))
+    monkeypatch.setenv("RPSF_STREAM_DEPTH", str(depth))
+    coords, k, images = _case(n, shape, frames, 13 * n + frames)
+    t = rp.ArrayPSFTransform(rp.IndexedCube(coords, k))
+    loop = np.stack([t.apply(im) for im in images])
+    if n in _native.SUPPORTED_PATCH_SIZES:
+        same = np.array_equal
+    else:  # the hipFFT fallback adds with float atomics: the order of the four contributions differs from run to run
+        def same(a, b):
+            return np.abs(a - b).max() <= 2e-6 * np.abs(b).max()
+    assert same(t.apply_batch(images), loop)
+    assert same(t.apply_batch(images.astype(np.float64)), loop)  # float64 frames are narrowed inside the library
+    out32 = t.apply_batch(list(images), dtype=np.float32)
+    assert out32.dtype == np.float32 and same(out32, loop.astype(np.float32))
+    into = np.full(loop.shape, -1.0)
+    assert t.apply_batch([im for im in images], out=into) is into and same(into, loop)
+    check(loop[0], orc.apply_transfer(images[0], coords, k))
+    # a single apply between two batches on the same plan, and a batch of one
+    assert same(t.apply(images[1]), loop[1])
+    assert same(t.apply_batch(images[:1]), loop[:1])
+    assert same(t.apply_batch(images[2:]), loop[2:])
+
+
+def test_no_thread_is_created_per_call():
+    """The conversions run on the library's persistent pool: the thread count of the process stays where the first call left it."""
+    def threads():
+        for line in open("/proc/self/status"):
+            if line.startswith("Threads:"):
+                return int(line.split()[1])
+        return -1
+
+    coords, k, images = _case(64, (256, 256), 6, 3)
+    t = rp.ArrayPSFTransform(rp.IndexedCube(coords, k))
+    t.apply(images[0])
+    t.apply_batch(images)
+    before = threads()
+    for _ in range(10):
+        t.apply(images[0])
+        t.apply_batch(images)
+    assert threads() == before
+    assert 1 <= _native.host_threads() <= 256
+
+
+def test_two_plans_stream_from_two_threads():
+    """Distinct plans from distinct threads share the worker pool: jobs interleave, results stay the loop's."""
+    cases = [_case(64, (192, 256), 6, 5), _case(128, (256, 384), 5, 6)]
+    transforms = [rp.ArrayPSFTransform(rp.IndexedCube(c, k)) for c, k, _ in cases]
+    loops = [np.stack([t.apply(im) for im in case[2]]) for t, case in zip(transforms, cases)]
+    errors = []
+
+    def work(i):
+        try:
+            for _ in range(8):
+                if not np.array_equal(transforms[i].apply_batch(cases[i][2]), loops[i]):
+                    errors.append(f"plan {i}: streamed result differs")
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    pool = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for th in pool:
+        th.start()
+    for th in pool:
+        th.join()
+    assert not errors, errors
+
+
+def test_pcie_probe_reports_plausible_rates():
+    pr = _native.pcie_probe(16 << 20, 3)
+    for key in ("h2d_ms", "d2h_ms", "duplex_ms"):
+        assert 0.05 < pr[key] < 50.0, pr  # 16 MiB: 0.3 ms at 55 GB/s
+    assert pr["duplex_ms"] >= 0.8 * max(pr["h2d_ms"], pr["d2h_ms"])
+
+
+def test_streamed_errors_are_reported():
+    coords, k, images = _case(32, (64, 64), 3, 9)
+    t = rp.ArrayPSFTransform(rp.IndexedCube(coords, k))
+    with pytest.raises(ValueError):
+        t.apply_batch([images[0], images[1][:32]])
+    with pytest.raises(ValueError):
+        t.apply_batch(images[0])
+    plan = _native.Plan(32, coords)
+    with pytest.raises(_native.NativeError):  # no transfer kernel installed
+        plan.apply_frames_host(images, _native.PAD_MODES["symmetric"])
