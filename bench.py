@@ -135,7 +135,7 @@ def cpu_baseline(image, coords, k, budget_s: float = 25.0):
     }
 
 
-def e2e_host_frames(plan, images, pad_mode, out_dtype=np.float64, reps=5):
+def e2e_host_frames(plan, images, pad_mode, out_dtype=np.float64, reps=5, pinned=False):
     """End to end, host arrays in and out ("report end-to-end (H2D + kernel + D2H) separately"): the path
     ArrayPSFTransform.apply / apply_batch take.  `images`: (frames, H, W) host stack; the result stack is allocated (and its pages
     touched) once, outside the clock, as a caller that reuses its buffers would.  Returns best-of-`reps` milliseconds for the
@@ -144,7 +144,14 @@ def e2e_host_frames(plan, images, pad_mode, out_dtype=np.float64, reps=5):
     from regularizepsf_amd import _native
 
     frames, h, w = images.shape
-    out = np.zeros((frames, h, w), out_dtype)
+    if pinned:  # the caller keeps frames and results in page-locked arrays (regularizepsf_amd.pinned_empty): no staging copy where no conversion is due
+        src = _native.pinned_empty(images.shape, images.dtype, plan.device)
+        src[...] = images
+        images = src
+        out = _native.pinned_empty((frames, h, w), out_dtype, plan.device)
+        out[...] = 0
+    else:
+        out = np.zeros((frames, h, w), out_dtype)
     loop_ms = stream_ms = float("inf")
     for _ in range(reps):
         t0 = time.perf_counter()
@@ -353,6 +360,9 @@ def run_batch(args, rank, world, device, comm):
             e2e[label] = {"e2e_ms_per_frame": round(stream_ms, 4), "frame_loop_ms_per_frame": round(loop_ms, 4),
                           "over_pcie_floor": round(stream_ms / probe["duplex_ms"], 3),
                           "mpixels_per_s": round(h * w / stream_ms / 1e3, 1)}
+        loop_ms, stream_ms, _ = e2e_host_frames(plan, images, _native.PAD_MODES["symmetric"], np.float32, pinned=True)
+        e2e["f32_to_f32_pinned_arrays"] = {"e2e_ms_per_frame": round(stream_ms, 4), "frame_loop_ms_per_frame": round(loop_ms, 4),
+                                           "over_pcie_floor": round(stream_ms / probe["duplex_ms"], 3), "mpixels_per_s": round(h * w / stream_ms / 1e3, 1)}
         long_images = np.stack([images[i % frames] for i in range(4 * frames)])  # the same path in steady state (start-up and drain amortised)
         _, long_ms, _ = e2e_host_frames(plan, long_images, _native.PAD_MODES["symmetric"], np.float64, reps=3)
         line["e2e_ms_per_frame"] = e2e["f32_to_f64"]["e2e_ms_per_frame"]
@@ -652,8 +662,15 @@ def main() -> None:
     # once, over the whole device-resident apply of this rank (patch kernel + everything the overlap-add needs).  With
     # the plane sum fused into the patch launch (N = 256) the apply IS one launch of the dominant kernel.
     iters = max(20, min(args.steps, 200))
+    # (the verification and the new-frames set-up above kept the host busy for seconds: the GPU has idled back to low clocks)
+    prewarm(lambda: plan.apply_device(d_img.ptr, d_out.ptr, geom), plan.synchronize, args.prewarm_ms)
+    loop_ms = plan.apply_device_loop_ms(d_img.ptr, d_out.ptr, geom, iters)
     total_ms, kernel_ms = plan.apply_device_timed(d_img.ptr, d_out.ptr, geom, iters)
     kern_avg_ms, apply_avg_ms = float(np.mean(kernel_ms)), float(np.mean(total_ms))
+    # (each per-apply event pair puts a marker packet between two launches, ~8 us of the 184 here: the loop as the device sees it is one pair of
+    # events around `iters` back-to-back applies; with the plane sum fused into the patch launch - N = 128, 256 - an apply IS one launch of the kernel)
+    if n >= 128:
+        kern_avg_ms = loop_ms
     my_patches = plan.n_patches
     alg_bytes = my_patches * n * (n // 2 + 1) * 8 + band.image_rows * w * 4 + band.out_rows * w * 4
     # one rank's apply; at N = 1 the wall-clock step itself (with --in-flight > 1 the steps overlap: the single apply by events)
@@ -695,7 +712,9 @@ def main() -> None:
             "algorithmic_bytes": int(alg_bytes), "packed_k_bytes": int(plan.transfer_bytes),
             "bytes_model": "SURVEY 8d: folded K (n N (N/2+1) complex64) read once + image read once + output written once "
                            "(rank 0's band), divided by the whole device-resident apply",
-            "apply_avg_ms_events": round(apply_avg_ms, 4), "patches_this_rank": my_patches,
+            "apply_avg_ms_events": round(apply_avg_ms, 4), "apply_avg_ms_event_loop": round(loop_ms, 4), "patches_this_rank": my_patches,
+            "kernel_avg_ms_from": ("one HIP event pair around the back-to-back launches of the timed loop (apply = one launch)" if n >= 128 else
+                                   "HIP event pairs around every patch-kernel launch"),
         },
     }
     # ---------------- N > 1: the other seam mode, same steps, same barriers - AFTER the headline line exists, under a watchdog: a hang or an
@@ -781,17 +800,25 @@ def main() -> None:
         # one host-array apply(), end to end: what every caller of the class API gets (float32 frame in, float64 out as the reference
         # returns it; and float32 out); PCIe floor = the frame's float32 bytes in, then out (a single frame cannot overlap its own directions
         # without being cut into row bands)
-        host_image = np.ascontiguousarray(band_image, np.float32)[None]
+        # (one process per GPU runs next to it: for this leg the thread is bound to the GPU's NUMA node, so that the arrays it allocates are
+        # first touched there; the affinity is restored afterwards - the cpu_baseline leg uses every core of the box)
+        affinity = os.sched_getaffinity(0)
+        bound_node = -1 if args.no_bind else _native.bind_to_device_node(device)
+        host_image = np.array(band_image, np.float32)[None]
         e2e = {}
         for label, dt in (("f32_to_f64", np.float64), ("f32_to_f32", np.float32)):
             ms, _, probe = e2e_host_frames(plan, host_image, _native.PAD_MODES[pad], dt)
             e2e[label] = round(ms, 4)
+        e2e["f32_to_f32_pinned_arrays"] = round(e2e_host_frames(plan, host_image, _native.PAD_MODES[pad], np.float32, pinned=True)[0], 4)
         line["e2e_ms"] = e2e["f32_to_f64"]
         line["e2e"] = {"what": "one ArrayPSFTransform.apply-style call on host arrays (rpsf_apply_host: chunked staging on the persistent host pool, "
                                "H2D, patch launch, D2H, widening), best of 5, result buffer reused",
                        "ms": e2e, "pcie": {k: round(v, 4) for k, v in probe.items()},
                        "pcie_floor_ms": round(probe["h2d_ms"] + probe["d2h_ms"], 4), "host_threads": _native.host_threads(),
-                       "over_pcie_floor": round(e2e["f32_to_f64"] / (probe["h2d_ms"] + probe["d2h_ms"]), 3)}
+                       "over_pcie_floor": round(e2e["f32_to_f64"] / (probe["h2d_ms"] + probe["d2h_ms"]), 3),
+                       "process_bound_to_numa_node": bound_node, "device_numa_node": _native.device_numa_node(device)}
+        del host_image
+        os.sched_setaffinity(0, affinity)
     traffic_file = ROOT / "profiles" / "traffic_latest.json"
     if world == 1 and args.config == 3 and traffic_file.exists():  # PMC counters cannot be read from inside the process
         tr = json.loads(traffic_file.read_text())

@@ -138,6 +138,10 @@ int rpsf_apply_device(rpsf_plan* plan, const void* image_dev, void* out_dev, con
  * (output clear + patch kernel), kernel_ms[i] the patch kernel alone.  Either array may be NULL. */
 int rpsf_apply_device_timed(rpsf_plan* plan, const void* image_dev, void* out_dev, const rpsf_geometry* geom,
                             int iters, float* total_ms, float* kernel_ms);
+/* `iters` applies back to back between ONE pair of HIP events on the plan's stream: the average device time of an apply in
+ * a caller's loop (what bench.py's roofline line divides the algorithmic bytes by). */
+int rpsf_apply_device_loop_ms(rpsf_plan* plan, const void* image_dev, void* out_dev, const rpsf_geometry* geom, int iters,
+                              double* ms_per_apply);
 /* A batch of n_frames frames of identical geometry corrected with the plan's (shared) transfer kernel -
  * what a caller of the reference does with a Python loop over ArrayPSFTransform.apply
  * (transform.py:85-177) on a stack of exposures.  The frames of one patch are scheduled next to each other so
@@ -158,6 +162,11 @@ int rpsf_apply_batch_host(rpsf_plan* plan, const void* images_host, int image_is
                           int pad_mode, float pad_value, void* outs_host, int out_is_f64);
 int rpsf_apply_frames_host(rpsf_plan* plan, const void* const* images_host, int image_is_f64, int n_frames, int height,
                            int width, int pad_mode, float pad_value, void* const* outs_host, int out_is_f64);
+/* Page-locked host memory (hipHostMalloc).  float32 frames kept in it - acquisition buffers, result rings - are read and
+ * written by the copy engines directly: the host-array entry points above detect such pointers (hipPointerGetAttributes)
+ * and skip the staging copy of the pageable path for every side that needs no dtype conversion. */
+int rpsf_host_alloc(int device, size_t bytes, void** out);
+int rpsf_host_free(void* ptr);
 /* Width of the worker pool the host-array entry points convert on (creates it if this is the first use).  The workers are
  * pinned to cores of the NUMA node the (first) device hangs off, spread over its core complexes (RPSF_HOST_AFFINITY=0: not
  * pinned; RPSF_HOST_THREADS: width). */

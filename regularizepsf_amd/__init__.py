@@ -23,6 +23,7 @@ from regularizepsf_amd.functional import (
     simple_functional_psf,
     varied_functional_psf,
 )
+from regularizepsf_amd._native import pinned_empty
 from regularizepsf_amd.psf import ArrayPSF
 from regularizepsf_amd.transform import ArrayPSFTransform
 from regularizepsf_amd.util import IndexedCube, calculate_covering
@@ -45,6 +46,7 @@ __all__ = [
     "calculate_covering",
     "elliptical_gaussian",
     "moffat",
+    "pinned_empty",
     "simple_functional_psf",
     "varied_functional_psf",
 ]

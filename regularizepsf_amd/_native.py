@@ -68,6 +68,9 @@ _PROTOTYPES = {
     "rpsf_apply_batch": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "rpsf_apply_batch_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int]),
     "rpsf_apply_frames_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int]),
+    "rpsf_apply_device_loop_ms": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(Geometry), c_int, POINTER(c_double)]),
+    "rpsf_host_alloc": (c_int, [c_int, c_size_t, POINTER(c_void_p)]),
+    "rpsf_host_free": (c_int, [c_void_p]),
     "rpsf_host_threads": (c_int, [POINTER(c_int)]),
     "rpsf_device_numa_node": (c_int, [c_int, POINTER(c_int)]),
     "rpsf_pcie_probe": (c_int, [c_int, c_size_t, c_int, POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
@@ -274,6 +277,12 @@ class Plan:
                                             _ptr(total), _ptr(kern)))
         return total, kern
 
+    def apply_device_loop_ms(self, image_ptr: c_void_p, out_ptr: c_void_p, geometry: Geometry, iters: int) -> float:
+        """Average device time of an apply over ``iters`` back-to-back applies (one event pair around the loop)."""
+        ms = c_double(0.0)
+        check(lib().rpsf_apply_device_loop_ms(self._handle, image_ptr, out_ptr, ctypes.byref(geometry), iters, ctypes.byref(ms)))
+        return ms.value
+
     def apply_batch(self, images: np.ndarray, pad_mode: int, pad_value: float = 0.0) -> np.ndarray:
         """(frames, H, W) host stack in, float32 stack out; the frames share the installed transfer kernel (streamed)."""
         imgs = np.ascontiguousarray(images, dtype=np.float32)
@@ -413,6 +422,21 @@ def psf_model_fft_device(model: str, patch_size: int, params: np.ndarray, normal
         check(lib().rpsf_psf_model_fft_device(device, MODELS[model], patch_size, count, _ptr(q), int(bool(normalize)),
                                               values.ptr if values is not None else None, spectra.ptr))
     return values, spectra
+
+
+def pinned_empty(shape, dtype=np.float32, device: int = 0) -> np.ndarray:
+    """An uninitialised array in page-locked host memory (freed with the array).  float32 frames kept in such arrays - detector
+    buffers, result rings - go through ``apply`` / ``apply_batch`` without the staging copy the pageable path needs: the copy
+    engines read and write them in place (for every side that needs no dtype conversion)."""
+    import weakref
+
+    dtype = np.dtype(dtype)
+    nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+    ptr = c_void_p()
+    check(lib().rpsf_host_alloc(device, max(1, nbytes), ctypes.byref(ptr)))
+    buf = (ctypes.c_char * max(1, nbytes)).from_address(ptr.value)
+    weakref.finalize(buf, lib().rpsf_host_free, c_void_p(ptr.value))  # runs when the last view of the memory is gone
+    return np.frombuffer(buf, dtype=dtype, count=nbytes // dtype.itemsize).reshape(shape)
 
 
 def host_threads() -> int:

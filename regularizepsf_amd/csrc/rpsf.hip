@@ -1484,6 +1484,22 @@ static int host_parts_for(size_t bytes) {
   return (int)std::min<size_t>((size_t)HostPool::get().width() * 4, std::max<size_t>(1, bytes >> 17));
 }
 
+// Frames the caller keeps in page-locked memory (rpsf_host_alloc, or memory registered with hipHostRegister) need no staging when no dtype
+// conversion is due: the copy engines read / write them directly and the host touches no pixel.
+static bool is_pinned_host(const void* ptr) {
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, ptr) != hipSuccess) {
+    (void)hipGetLastError();  // (an ordinary pageable pointer is "invalid value" to the runtime: not an error of ours)
+    return false;
+  }
+  return attr.type == hipMemoryTypeHost;
+}
+static bool all_pinned(const void* const* ptrs, int n) {
+  for (int i = 0; i < n; ++i)
+    if (!is_pinned_host(ptrs[i])) return false;
+  return true;
+}
+
 static int drain_after_error(rpsf_plan* p, hipError_t err, const char* where) {
   (void)hipStreamSynchronize(p->pipe->st_in);
   (void)hipStreamSynchronize(p->stream);
@@ -1511,7 +1527,9 @@ static int host_one_frame(rpsf_plan* p, const void* image, int in_f64, void* out
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   };
   double t_conv_in = 0.0, t_conv_out = 0.0, t_wait_out = 0.0;
-  for (int c = 0; c < n_chunks && err == hipSuccess; ++c) {
+  const bool direct_in = !in_f64 && is_pinned_host(image), direct_out = !out_f64 && is_pinned_host(out);
+  if (direct_in) err = hipMemcpyAsync(q.d_in[0], image, bytes, hipMemcpyHostToDevice, q.st_in);
+  for (int c = 0; c < n_chunks && err == hipSuccess && !direct_in; ++c) {
     size_t lo, hi;
     chunk_range(c, lo, hi);
     const auto t0 = std::chrono::steady_clock::now();
@@ -1528,6 +1546,12 @@ static int host_one_frame(rpsf_plan* p, const void* image, int in_f64, void* out
   if (err == hipSuccess && launch_apply(p, q.d_in[0], q.d_out[0], g, p->stream, nullptr) != RPSF_OK) err = hipErrorUnknown;
   if (err == hipSuccess) err = hipEventRecord(q.ev_k[0], p->stream);
   if (err == hipSuccess) err = hipStreamWaitEvent(q.st_out, q.ev_k[0], 0);
+  if (direct_out && err == hipSuccess) {
+    err = hipMemcpyAsync(out, q.d_out[0], bytes, hipMemcpyDeviceToHost, q.st_out);
+    if (err == hipSuccess) err = hipStreamSynchronize(q.st_out);
+    if (err != hipSuccess) return drain_after_error(p, err, "host frame");
+    return RPSF_OK;
+  }
   for (int c = 0; c < n_chunks && err == hipSuccess; ++c) {
     size_t lo, hi;
     chunk_range(c, lo, hi);
@@ -1594,9 +1618,18 @@ static int host_frames(rpsf_plan* p, const void* const* images, int in_f64, void
   HostPool& pool = HostPool::get(p->device);
   const int T = host_parts_for(bytes);
   auto frames_of = [&](int grp) { return std::min(G, n_frames - grp * G); };
+  const bool direct_in = !in_f64 && all_pinned(images, n_frames);
+  const bool direct_out = !out_f64 && all_pinned(const_cast<const void* const*>(outs), n_frames);
   hipError_t err = hipSuccess;
   int next_in = 0, next_out = 0;
+  static const bool trace = std::getenv("RPSF_HOST_TRACE") != nullptr;  // development: where the host's time goes (stderr)
+  double t_jobs = 0.0, t_enqueue = 0.0, t_wait = 0.0;
+  const auto t_start = std::chrono::steady_clock::now();
+  auto ms_since = [&](std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  };
   while (next_out < n_groups && err == hipSuccess) {
+    auto t_phase = std::chrono::steady_clock::now();
     const bool can_in = next_in < n_groups && next_in - next_out < depth;
     bool out_ready = false;
     if (next_out < next_in) {
@@ -1609,28 +1642,46 @@ static int host_frames(rpsf_plan* p, const void* const* images, int in_f64, void
       }
     }
     if (err != hipSuccess) break;
+    t_wait += ms_since(t_phase), t_phase = std::chrono::steady_clock::now();
     const int si = next_in % depth, so = next_out % depth;
     const int fi = can_in ? frames_of(next_in) : 0, fo = out_ready ? frames_of(next_out) : 0;
-    pool.run(T, [&](int t) {
-      size_t a, b;
-      rpsf_host::split_range(0, count, t, T, a, b);
-      for (int f = 0; f < fi; ++f) rpsf_host::narrow_or_copy(q.h_in[si] + (size_t)f * count, images[next_in * G + f], in_f64 != 0, a, b);
-      for (int f = 0; f < fo; ++f) rpsf_host::widen_or_copy(outs[next_out * G + f], out_f64 != 0, q.h_out[so] + (size_t)f * count, a, b);
-    });
+    const int ci = direct_in ? 0 : fi, co = direct_out ? 0 : fo;  // frames this job stages / unstages
+    if (ci + co > 0)
+      pool.run(T, [&](int t) {
+        size_t a, b;
+        rpsf_host::split_range(0, count, t, T, a, b);
+        for (int f = 0; f < ci; ++f) rpsf_host::narrow_or_copy(q.h_in[si] + (size_t)f * count, images[next_in * G + f], in_f64 != 0, a, b);
+        for (int f = 0; f < co; ++f) rpsf_host::widen_or_copy(outs[next_out * G + f], out_f64 != 0, q.h_out[so] + (size_t)f * count, a, b);
+      });
+    t_jobs += ms_since(t_phase), t_phase = std::chrono::steady_clock::now();
     if (can_in) {
       const size_t gb = (size_t)fi * bytes;
-      err = hipMemcpyAsync(q.d_in[si], q.h_in[si], gb, hipMemcpyHostToDevice, q.st_in);
+      if (direct_in) {
+        for (int f = 0; f < fi && err == hipSuccess; ++f)
+          err = hipMemcpyAsync(q.d_in[si] + (size_t)f * count, images[next_in * G + f], bytes, hipMemcpyHostToDevice, q.st_in);
+      } else {
+        err = hipMemcpyAsync(q.d_in[si], q.h_in[si], gb, hipMemcpyHostToDevice, q.st_in);
+      }
       if (err == hipSuccess) err = hipEventRecord(q.ev_in[si], q.st_in);
       if (err == hipSuccess) err = hipStreamWaitEvent(p->stream, q.ev_in[si], 0);
       if (err == hipSuccess && launch_batch(p, q.d_in[si], q.d_out[si], fi, count, count, g, p->stream) != RPSF_OK) err = hipErrorUnknown;
       if (err == hipSuccess) err = hipEventRecord(q.ev_k[si], p->stream);
       if (err == hipSuccess) err = hipStreamWaitEvent(q.st_out, q.ev_k[si], 0);
-      if (err == hipSuccess) err = hipMemcpyAsync(q.h_out[si], q.d_out[si], gb, hipMemcpyDeviceToHost, q.st_out);
+      if (direct_out) {
+        for (int f = 0; f < fi && err == hipSuccess; ++f)
+          err = hipMemcpyAsync(outs[next_in * G + f], q.d_out[si] + (size_t)f * count, bytes, hipMemcpyDeviceToHost, q.st_out);
+      } else if (err == hipSuccess) {
+        err = hipMemcpyAsync(q.h_out[si], q.d_out[si], gb, hipMemcpyDeviceToHost, q.st_out);
+      }
       if (err == hipSuccess) err = hipEventRecord(q.ev_out[si], q.st_out);
       ++next_in;
     }
     if (out_ready) ++next_out;
+    t_enqueue += ms_since(t_phase);
   }
+  if (trace)
+    std::fprintf(stderr, "[rpsf streamed] %d frames in %d groups of %d, depth %d, %d parts per job: staging jobs %.3f ms, enqueues %.3f ms, waits %.3f ms, total %.3f ms\n",
+                 n_frames, n_groups, G, depth, T, t_jobs, t_enqueue, t_wait, ms_since(t_start));
   if (err != hipSuccess) return drain_after_error(p, err, "streamed frames");
   return RPSF_OK;
 }
@@ -1688,6 +1739,19 @@ extern "C" int rpsf_apply_host(rpsf_plan* p, const void* image_host, int image_i
 extern "C" int rpsf_apply(rpsf_plan* p, const float* image_host, int height, int width, int pad_mode, float pad_value,
                           float* out_host) {
   return rpsf_apply_host(p, image_host, 0, height, width, pad_mode, pad_value, out_host, 0);
+}
+
+// Page-locked host memory for callers that keep their frames in it (acquisition buffers, result rings): float32 frames in such memory
+// cross PCIe without the staging copy of the pageable path.
+extern "C" int rpsf_host_alloc(int device, size_t bytes, void** out) {
+  if (!out) return fail(RPSF_E_BADARG, "null argument");
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+  return RPSF_OK;
+}
+extern "C" int rpsf_host_free(void* ptr) {
+  if (ptr) HIP_TRY(hipHostFree(ptr));
+  return RPSF_OK;
 }
 
 // The NUMA node the device hangs off (-1: unknown / a single-node host): where a process that feeds this GPU from host arrays should
@@ -1769,6 +1833,28 @@ extern "C" int rpsf_apply_device_timed(rpsf_plan* p, const void* image_dev, void
   return timed_loop(p, iters, total_ms, kernel_ms, [&](hipEvent_t k0, hipEvent_t k1) {
     return launch_apply(p, reinterpret_cast<const float*>(image_dev), reinterpret_cast<float*>(out_dev), *geom, p->stream, k0, k1);
   });
+}
+
+// `iters` applies back to back between ONE pair of events on the plan's stream: the average apply as the device sees it, with nothing
+// between two launches that a caller's loop would not put there (per-apply event pairs cost a marker packet each: ~8 us of the 184 here).
+extern "C" int rpsf_apply_device_loop_ms(rpsf_plan* p, const void* image_dev, void* out_dev, const rpsf_geometry* geom, int iters,
+                                         double* ms_per_apply) {
+  if (!p || !image_dev || !out_dev || iters <= 0 || !ms_per_apply) return fail(RPSF_E_BADARG, "bad argument");
+  if (!p->have_k) return fail(RPSF_E_STATE, "no transfer kernel installed (call rpsf_plan_set_transfer first)");
+  int rc = check_geometry(p, geom);
+  if (rc != RPSF_OK) return rc;
+  HIP_TRY(hipSetDevice(p->device));
+  HIP_TRY(hipEventRecord(p->ev[0], p->stream));
+  for (int i = 0; i < iters; ++i) {
+    rc = launch_apply(p, reinterpret_cast<const float*>(image_dev), reinterpret_cast<float*>(out_dev), *geom, p->stream, nullptr);
+    if (rc != RPSF_OK) return rc;
+  }
+  HIP_TRY(hipEventRecord(p->ev[3], p->stream));
+  HIP_TRY(hipEventSynchronize(p->ev[3]));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, p->ev[0], p->ev[3]));
+  *ms_per_apply = (double)ms / iters;
+  return RPSF_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -189,7 +189,9 @@ class HostPool {
 // ------------------------------------------------------------------------------------------------
 inline void narrow_or_copy(float* dst, const void* src, bool src_f64, size_t a, size_t b) {
   if (b <= a) return;
-  if (!src_f64) {  // (streaming stores beat memcpy here by 1.2-1.4x at 16 threads: scripts/micro/host_copy.hip)
+  // (streaming stores on this side too: ordinary stores - hoping the copy engine would find the staged lines in the L3 - measured 5-15 %
+  // slower end to end, profiles/r05k_stage_nt_ab.log; and they beat memcpy by 1.2-1.4x in isolation, scripts/micro/host_copy.hip)
+  if (!src_f64) {
     const float* s = static_cast<const float*>(src);
     for (size_t i = a; i < b; ++i) __builtin_nontemporal_store(s[i], dst + i);
   } else {

@@ -1,9 +1,15 @@
 """Non-finite pixels and large pedestals on the default (no saturation) path.
 
 The reference poisons exactly the patches that contain a NaN / Inf pixel: `fft2(w * patch)` of such a patch is non-finite in every bin,
-so after `ifft2(. * K)` the whole patch is NaN and the overlap-add (regularizepsf/transform.py:163-169) spreads it over the four patches
-that cover the pixel - and, through np.pad's mirror, over the patches that read its reflection (transform.py:119-123).  Real PUNCH
+so after `ifft2(. * K)` the whole patch is non-finite and the overlap-add (regularizepsf/transform.py:163-169) spreads it over the four
+patches that cover the pixel - and, through np.pad's mirror, over the patches that read its reflection (transform.py:119-123).  Real PUNCH
 frames carry NaN masks; the kernels' window tables, rim selects and fused tile sums must reproduce that pattern, not launder it.
+
+What is compared: the SET of non-finite output pixels must be the reference's, always; for NaN pixels (the mask value in practice) the
+output is NaN exactly where the reference's is; everything else meets the usual tolerance.  For a +-Inf pixel WHICH of the poisoned
+pixels read +-Inf instead of NaN is an artefact of the FFT algorithm: where the pixel sits on patch-local row / column 0 or N/2 it meets
+only trivial twiddles, pocketfft hands that one pixel back as +-Inf (NaN around it), and a radix-2 network leaves +-Inf in a few other
+places of the same patches - every one of them inside the reference's poisoned set.
 """
 
 import numpy as np
@@ -22,11 +28,12 @@ def _setup(n, shape, seed):
     return coords, k, orc.starfield(h, w, seed)
 
 
-def _compare(out, ref):
+def _compare(out, ref, nan_exact=True):
     assert out.dtype == np.float64 and out.shape == ref.shape
     bad_ref, bad_out = ~np.isfinite(ref), ~np.isfinite(out)
     assert np.array_equal(bad_out, bad_ref), f"non-finite pattern differs: {bad_out.sum()} vs {bad_ref.sum()} pixels"
-    assert np.array_equal(np.isnan(out), np.isnan(ref))
+    if nan_exact:
+        assert np.array_equal(np.isnan(out), np.isnan(ref))
     good = ~bad_ref
     assert good.any()
     d = out[good] - ref[good]
@@ -53,7 +60,7 @@ def test_a_non_finite_pixel_poisons_exactly_the_patches_the_reference_poisons(n,
     image[r, c] = value
     ref = orc.apply_transfer(image, coords, k)
     out = rp.ArrayPSFTransform(rp.IndexedCube(coords, k)).apply(image)
-    poisoned = _compare(out, ref)
+    poisoned = _compare(out, ref, nan_exact=bool(np.isnan(value)) or spot != "patch_seam")
     assert poisoned >= (n // 2) ** 2  # at least the lattice tile around the pixel
 
 
@@ -66,7 +73,7 @@ def test_nan_mask_regions_in_a_batch_and_other_pad_modes(n, shape):
     masked = image.copy()
     masked[h // 3 : h // 3 + 9, w // 4 : w // 4 + 17] = np.nan
     masked[0, 0] = np.nan
-    masked[h - 2, 5] = np.inf
+    masked[h - 2, 5] = np.inf  # (off the patch seams: NaN wherever the reference has NaN)
     t = rp.ArrayPSFTransform(rp.IndexedCube(coords, k))
     for pad_mode in ("reflect", "constant", "wrap"):
         _compare(t.apply(masked, pad_mode=pad_mode), orc.apply_transfer(masked, coords, k, pad_mode=pad_mode))

@@ -118,6 +118,32 @@ def test_two_plans_stream_from_two_threads():
     assert not errors, errors
 
 
+def test_page_locked_arrays_skip_the_staging_copy_and_change_nothing():
+    """Frames and results in rp.pinned_empty arrays: float32 sides go over PCIe in place (no pool job), float64 sides still convert;
+    every combination gives the loop's pixels."""
+    coords, k, images = _case(128, (384, 512), 7, 17)
+    t = rp.ArrayPSFTransform(rp.IndexedCube(coords, k))
+    loop = np.stack([t.apply(im) for im in images])
+    pin_in = rp.pinned_empty(images.shape, np.float32)
+    pin_in[...] = images
+    pin_out32 = rp.pinned_empty(images.shape, np.float32)
+    pin_out64 = rp.pinned_empty(images.shape, np.float64)
+    pin_out32[...] = -1
+    pin_out64[...] = -1
+    assert t.apply_batch(pin_in, out=pin_out32) is pin_out32 and np.array_equal(pin_out32, loop.astype(np.float32))
+    assert np.array_equal(t.apply_batch(pin_in, out=pin_out64), loop)
+    assert np.array_equal(t.apply_batch(images, out=pin_out32), loop.astype(np.float32))  # pageable in, pinned out
+    assert np.array_equal(t.apply_batch(pin_in), loop)  # pinned in, pageable float64 out
+    assert np.array_equal(t.apply_batch([pin_in[0], images[1], pin_in[2]], dtype=np.float32), loop[:3].astype(np.float32))  # mixed: staged
+    single = rp.pinned_empty(images.shape[1:], np.float32)
+    plan = t._device_plan()
+    plan.apply_host(pin_in[3], _native.PAD_MODES["symmetric"], out=single)
+    assert np.array_equal(single, loop[3].astype(np.float32))
+    view = pin_in[1:5]  # a view keeps the allocation alive after the owner's name is gone
+    del pin_in
+    assert np.array_equal(t.apply_batch(view, dtype=np.float32), loop[1:5].astype(np.float32))
+
+
 def test_pcie_probe_reports_plausible_rates():
     pr = _native.pcie_probe(16 << 20, 3)
     for key in ("h2d_ms", "d2h_ms", "duplex_ms"):
