@@ -421,8 +421,11 @@ def main() -> None:
                          "one apply overlaps the tail of the previous one - the throughput of a frame pipeline.  Default 1: one "
                          "apply after the other, which is also what roofline.frac is always computed on")
     ap.add_argument("--no-overlap", action="store_true",
-                    help="--seam exchange: plain apply -> send/recv -> add on one stream instead of computing the spill rows "
-                         "first and sending them beside the rest of the band")
+                    help="--seam exchange: plain apply -> send/recv -> add on one stream (same as --exchange-mode plain)")
+    ap.add_argument("--exchange-mode", choices=["pipeline", "two-plans", "plain"], default="pipeline",
+                    help="how the seam exchange is overlapped: 'pipeline' (default) - one launch per step, the send / recv / add of step k on "
+                         "the exchange stream beside the launch of step k + 1; 'two-plans' - the band's last lattice row as a plan of its own, "
+                         "its rows sent beside the rest of the same step's band; 'plain' - apply -> send/recv -> add in sequence")
     ap.add_argument("--seam", choices=["recompute", "exchange"], default="recompute",
                     help="N > 1: 'recompute' (default) - every band also runs the lattice row above it that reaches into its rows and "
                          "the bands are cut so that own + recomputed patches balance (585 per rank at eight bands of the 8192-wide "
@@ -531,8 +534,9 @@ def main() -> None:
             comm = GlooSeam(rank, world, device)
     if args.config == 5:
         return run_batch(args, rank, world, device, comm)
+    overlap = False if args.no_overlap else {"pipeline": "pipeline", "two-plans": True, "plain": False}[args.exchange_mode]
     shard = ShardedApply(coords, kernel_for, n, height, w, rank, world, device, comm, pad_mode=pad, seam=args.seam,
-                         overlap=not args.no_overlap)
+                         overlap=overlap)
     # N > 1: BOTH seam modes run in this process - the --seam one is the headline (timed first), the other a second leg with its own
     # plans, K and buffers - so that the first run on a real multi-GPU node exercises the RCCL send / recv of the halo rows AND the
     # collective-free recompute, whichever of them is the default
@@ -540,7 +544,7 @@ def main() -> None:
     shard2 = None
     if world > 1 and not args.one_seam:
         shard2 = ShardedApply(coords, kernel_for, n, height, w, rank, world, device, comm, pad_mode=pad, seam=other_seam,
-                              overlap=not args.no_overlap)
+                              overlap=overlap)
     band = shard.band
     band_image = image_rows(band.image_row0, band.image_row0 + band.image_rows)
     shard.upload_rows(band_image)
@@ -772,6 +776,7 @@ def main() -> None:
         return
     if world > 1:  # both seam modes of this run (the headline is config.seam), the transport, and what RCCL says about its communicator
         line["config"]["seam"] = args.seam
+        line["config"]["exchange_mode"] = "plain" if overlap is False else "two-plans" if overlap is True else "pipeline"
         line["sync"] = "gloo" if isinstance(comm, GlooSeam) else "rccl"
         line["rccl_ranks"] = rccl_ranks
         line[f"scaling_{args.seam}_ms"] = round(ms_per_step, 4)

@@ -86,6 +86,14 @@ int rpsf_plan_set_stagger(rpsf_plan* plan, int microseconds);
  * enqueued beside it on another stream - RCCL's send/recv of the seam rows (rpsf_comm_seam_exchange) - would wait for the
  * first of them to finish.  `cus` CUs (0..128; 8 is what the sharded apply asks for) are left without a patch workgroup. */
 int rpsf_plan_set_reserved_cus(rpsf_plan* plan, int cus);
+/* Partition the chip between the plan and a caller's own stream: the plan's stream (and every launch on it) is confined to the compute
+ * units set in `mask` (bit i of word i / 32, hipExtStreamCreateWithCUMask's numbering; `words` uint32), its persistent launches are
+ * sized for them; rpsf_stream_create makes a stream masked to whatever the caller passes (NULL: unmasked).  The pipelined seam exchange
+ * gives RCCL's kernels and K4 a handful of CUs of their own this way (rpsf_plan_set_reserved_cus only leaves CUs unclaimed - a kernel
+ * dispatched a moment before the persistent launch still lands on CUs that launch is waiting for). */
+int rpsf_plan_set_cu_mask(rpsf_plan* plan, const uint32_t* mask, int words);
+int rpsf_stream_create(int device, const uint32_t* mask, int words, void** stream);
+int rpsf_stream_destroy(void* stream);
 /* Opt-in image prefetch for streams of NEW frames (256-pixel plan, single-frame applies; ignored elsewhere): the summing workgroups at
  * the head of the persistent launch touch the image tile by tile, in the order in which the patches will gather it, as a paced side
  * job.  A frame that was not corrected a moment ago is not in the memory-side cache, and its first gathers pay the HBM latency
@@ -257,9 +265,18 @@ void* rpsf_comm_stream(rpsf_comm* comm);
 int rpsf_comm_ranks(rpsf_comm* comm, int* ranks);
 /* Make `waiter` (a hipStream_t) wait for everything enqueued on `signaller` so far. */
 int rpsf_stream_wait(int device, void* waiter, void* signaller);
+/* Events (hipEvent_t without timing) for dependencies that span steps: record on one stream now, make another stream wait for
+ * it later (the sharded step's double-buffered seam rows). */
+int rpsf_event_create(int device, void** event);
+int rpsf_event_record(void* event, void* stream);
+int rpsf_stream_wait_event(void* stream, void* event);
+int rpsf_event_destroy(void* event);
 /* accum_dev[0:count] += src_dev[0:count] (float32, on `device`, asynchronous on stream): the add of the seam
  * exchange by itself, for callers that move the seam rows with their own transport. */
 int rpsf_add_rows(int device, void* accum_dev, const void* src_dev, size_t count, void* stream);
+/* The same add on at most max_workgroups workgroups of 256 threads: for a caller that runs it beside a persistent patch launch
+ * (the pipelined seam exchange of regularizepsf_amd/sharding.py), whose workgroups need whole CUs. */
+int rpsf_add_rows_narrow(int device, void* accum_dev, const void* src_dev, size_t count, int max_workgroups, void* stream);
 int rpsf_comm_barrier(rpsf_comm* comm, void* stream);
 /* max over ranks of one double (used for whole-job timing) */
 int rpsf_comm_allreduce_max(rpsf_comm* comm, double* value);

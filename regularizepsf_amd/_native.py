@@ -60,6 +60,9 @@ _PROTOTYPES = {
     "rpsf_plan_set_stagger": (c_int, [c_void_p, c_int]),
     "rpsf_plan_set_image_prefetch": (c_int, [c_void_p, c_int]),
     "rpsf_plan_set_reserved_cus": (c_int, [c_void_p, c_int]),
+    "rpsf_plan_set_cu_mask": (c_int, [c_void_p, c_void_p, c_int]),
+    "rpsf_stream_create": (c_int, [c_int, c_void_p, c_int, POINTER(c_void_p)]),
+    "rpsf_stream_destroy": (c_int, [c_void_p]),
     "rpsf_plan_debug_stamps": (c_int, [c_void_p, c_void_p, c_size_t]),
     "rpsf_apply": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "rpsf_apply_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int]),
@@ -99,7 +102,12 @@ _PROTOTYPES = {
     "rpsf_comm_stream": (c_void_p, [c_void_p]),
     "rpsf_comm_ranks": (c_int, [c_void_p, POINTER(ctypes.c_int)]),
     "rpsf_stream_wait": (c_int, [c_int, c_void_p, c_void_p]),
+    "rpsf_event_create": (c_int, [c_int, POINTER(c_void_p)]),
+    "rpsf_event_record": (c_int, [c_void_p, c_void_p]),
+    "rpsf_stream_wait_event": (c_int, [c_void_p, c_void_p]),
+    "rpsf_event_destroy": (c_int, [c_void_p]),
     "rpsf_add_rows": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rpsf_add_rows_narrow": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "rpsf_comm_barrier": (c_int, [c_void_p, c_void_p]),
     "rpsf_comm_allreduce_max": (c_int, [c_void_p, POINTER(c_double)]),
 }
@@ -226,6 +234,11 @@ class Plan:
     def set_reserved_cus(self, cus: int) -> None:
         """Persistent launches leave ``cus`` CUs free for kernels enqueued beside them (the RCCL seam exchange)."""
         check(lib().rpsf_plan_set_reserved_cus(self._handle, int(cus)))
+
+    def set_cu_mask(self, mask: np.ndarray) -> None:
+        """Confine the plan's stream to the compute units set in ``mask`` (uint32 words, bit i of word i // 32)."""
+        m = np.ascontiguousarray(mask, dtype=np.uint32)
+        check(lib().rpsf_plan_set_cu_mask(self._handle, _ptr(m), m.size))
 
     @property
     def transfer_bytes(self) -> int:
@@ -491,14 +504,87 @@ def saturation_fill(padded: np.ndarray, mask: np.ndarray, neighborhood_width: in
     check(lib().rpsf_saturation_fill(_ptr(padded), padded.shape[0], padded.shape[1], _ptr(m), int(neighborhood_width)))
 
 
-def add_rows(accum_ptr: c_void_p, src_ptr: c_void_p, count: int, device: int = 0, stream: c_void_p | None = None) -> None:
-    """accum[0:count] += src[0:count] on the device (kernel K4: the add of the seam exchange)."""
-    check(lib().rpsf_add_rows(device, accum_ptr, src_ptr, count, stream))
+def add_rows(accum_ptr: c_void_p, src_ptr: c_void_p, count: int, device: int = 0, stream: c_void_p | None = None,
+             max_workgroups: int = 0) -> None:
+    """accum[0:count] += src[0:count] on the device (kernel K4: the add of the seam exchange); ``max_workgroups`` > 0: on at
+    most that many workgroups (for running it beside a persistent patch launch)."""
+    if max_workgroups > 0:
+        check(lib().rpsf_add_rows_narrow(device, accum_ptr, src_ptr, count, max_workgroups, stream))
+    else:
+        check(lib().rpsf_add_rows(device, accum_ptr, src_ptr, count, stream))
 
 
 def stream_wait(waiter: c_void_p, signaller: c_void_p, device: int = 0) -> None:
     """Work enqueued on ``waiter`` from now on starts after everything enqueued on ``signaller`` so far."""
     check(lib().rpsf_stream_wait(device, waiter, signaller))
+
+
+def cu_masks(compute_units: int, carve: int, layout: str | None = None) -> tuple[np.ndarray, np.ndarray]:
+    """Two complementary CU masks over ``compute_units`` bits: (everything but the carved bits, the carved bits).  ``layout``:
+    "spread" - the carved CUs evenly spaced over the bit range (one per 32-bit word for 8 of 256: one per XCD if the numbering
+    is XCD-major); "tail" - the last ``carve`` bits (one per XCD if it is round-robin)."""
+    layout = layout or os.environ.get("RPSF_CU_MASK_LAYOUT", "tail")
+    words = (compute_units + 31) // 32
+    big, small = np.zeros(words, np.uint32), np.zeros(words, np.uint32)
+    if layout == "tail":
+        carved = set(range(compute_units - carve, compute_units))
+    else:
+        carved = {(k + 1) * compute_units // carve - 1 for k in range(carve)}
+    for i in range(compute_units):
+        (small if i in carved else big)[i // 32] |= np.uint32(1 << (i % 32))
+    return big, small
+
+
+class Stream:
+    """A HIP stream of the caller's own, optionally confined to the compute units of a mask."""
+
+    def __init__(self, device: int = 0, mask: np.ndarray | None = None) -> None:
+        self._handle = c_void_p()
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint32)
+        check(lib().rpsf_stream_create(device, None if m is None else _ptr(m), 0 if m is None else m.size, ctypes.byref(self._handle)))
+
+    @property
+    def ptr(self) -> c_void_p:
+        return self._handle
+
+    def close(self) -> None:
+        if self._handle is not None and self._handle.value:
+            lib().rpsf_stream_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self) -> None:
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+class Event:
+    """A HIP event (no timing): ``record(stream)`` now, ``make_wait(stream)`` later."""
+
+    def __init__(self, device: int = 0) -> None:
+        self._handle = c_void_p()
+        check(lib().rpsf_event_create(device, ctypes.byref(self._handle)))
+        self.recorded = False
+
+    def record(self, stream: c_void_p) -> None:
+        check(lib().rpsf_event_record(self._handle, stream))
+        self.recorded = True
+
+    def make_wait(self, stream: c_void_p) -> None:
+        if self.recorded:
+            check(lib().rpsf_stream_wait_event(stream, self._handle))
+
+    def close(self) -> None:
+        if self._handle is not None and self._handle.value:
+            lib().rpsf_event_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self) -> None:
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
 
 class Comm:

@@ -85,6 +85,15 @@ struct rpsf_plan {
   cf* d_g = nullptr;
   cf* d_gs = nullptr;
   rpsf_host::HostPipe* pipe = nullptr;  // host-array entry points: staging slots, copy streams (rpsf_hostpipe.hpp)
+  // Views: a plan over a subset of another plan's patches that shares its tables, its packed K (desc.z = the patch's index in the
+  // parent) and its stream - the row bands a single large host frame is cut into so that its upload, its patches and its download
+  // overlap (host_one_frame).  Owned by the parent, built for one frame shape.
+  rpsf_plan* parent = nullptr;
+  std::vector<int32_t> k_index;           // view: patch i of this plan is patch k_index[i] of the parent
+  std::vector<rpsf_plan*> bands;          // parent: its row-band views
+  std::vector<int> band_rows;             // bands.size() + 1 output row boundaries
+  std::vector<int> band_in_rows;          // per band: image rows [0, band_in_rows[b]) must be resident before it runs
+  int bands_h = 0, bands_w = 0, bands_mode = -1;
   bool have_k = false;
   hipStream_t stream = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -196,13 +205,17 @@ static int setup_lattice(rpsf_plan* p) {
   std::vector<uint8_t> cls(n, 0);
   std::vector<int32_t> cell;  // lattice cell -> patch (or -1)
   const int nli = nti - 1, nlj = ntj - 1;
+  const int par_i = ok && p->parent && p->parent->lattice ? ((r0 - p->parent->lat_r0) / half) & 1 : 0;
+  const int par_j = ok && p->parent && p->parent->lattice ? ((c0 - p->parent->lat_c0) / half) & 1 : 0;
   if (ok) {
     cell.assign((size_t)nli * nlj, -1);
     for (int i = 0; i < n && ok; ++i) {
       const int li = (p->h_coords[2 * i] - r0) / half, lj = (p->h_coords[2 * i + 1] - c0) / half;
       if (cell[(size_t)li * nlj + lj] >= 0) ok = false;  // duplicate corner: two patches in one plane cell
       cell[(size_t)li * nlj + lj] = i;
-      cls[i] = (uint8_t)(((li & 1) << 1) | (lj & 1));
+      // (a view takes its colours from the parent's lattice: the planes are summed in colour order, so a band's pixels then come out
+      // bit-identical to the whole-frame apply's)
+      cls[i] = (uint8_t)((((li + par_i) & 1) << 1) | ((lj + par_j) & 1));
     }
   }
   p->lattice = ok;
@@ -273,7 +286,7 @@ static int setup_lattice(rpsf_plan* p) {
     std::vector<int4> desc(n);
     for (int s2 = 0; s2 < n; ++s2) {
       int i = p->h_order[s2];
-      desc[s2] = make_int4(p->h_coords[2 * i], p->h_coords[2 * i + 1], i, ok ? cls[i] : 0);
+      desc[s2] = make_int4(p->h_coords[2 * i], p->h_coords[2 * i + 1], p->k_index.empty() ? i : p->k_index[i], ok ? cls[i] : 0);
     }
     HIP_TRY(hipMalloc(&p->d_desc, sizeof(int4) * n));
     HIP_TRY(hipMemcpy(p->d_desc, desc.data(), sizeof(int4) * n, hipMemcpyHostToDevice));
@@ -538,7 +551,9 @@ static void set_corner_extremes(rpsf_plan* p) {
     }
 }
 
-extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int n_patches, const int32_t* coords_rc) {
+// parent / k_index: a view of `parent` (shares its tables, packed K and stream; k_index[i] = the parent's index of patch i)
+static int plan_create_impl(rpsf_plan** out, int device, int patch_size, int n_patches, const int32_t* coords_rc, rpsf_plan* parent,
+                            const int32_t* k_index) {
   if (!out || !coords_rc) return fail(RPSF_E_BADARG, "null argument");
   if (n_patches <= 0) return fail(RPSF_E_BADARG, "n_patches must be positive");
   const int N = patch_size;
@@ -550,9 +565,16 @@ extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int
   auto* p = new rpsf_plan;
   p->device = device, p->N = N, p->n_patches = n_patches;
   p->generic = !compiled;
+  p->parent = parent;
+  if (parent) p->k_index.assign(k_index, k_index + n_patches);
   auto body = [&]() -> int {
     HIP_TRY(hipSetDevice(device));
-    HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    if (parent) {
+      if (p->generic) return fail(RPSF_E_UNSUPPORTED, "views need a compiled plan");
+      p->stream = parent->stream;
+    } else {
+      HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    }
     for (auto& e : p->ev) HIP_TRY(hipEventCreate(&e));
     if (p->generic) {
       HIP_TRY(hipMalloc(&p->d_coords, sizeof(int32_t) * 2 * n_patches));
@@ -620,7 +642,7 @@ extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int
                                     (int)Launch2<Cfg128v2>::LDS_BYTES));
         // Plain instead of streaming loads of the pair words where the plan's K (66,560 B per patch) fits the 256 MiB Infinity Cache beside the
         // planes: measured (profiles/r04av) -6 % per apply at 72 MB of K, +6.6 % at 160 MB; RPSF_K_CACHED=0/1 overrides (tests run both forms).
-        p->k_cached = (size_t)n_patches * Cfg128v2::G_PER_PATCH * sizeof(cf) <= ((size_t)96 << 20);
+        p->k_cached = (size_t)(parent ? parent->n_patches : n_patches) * Cfg128v2::G_PER_PATCH * sizeof(cf) <= ((size_t)96 << 20);
         if (const char* e = std::getenv("RPSF_K_CACHED")) p->k_cached = std::atoi(e) != 0;
       }
     }
@@ -669,6 +691,13 @@ extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int
     HIP_TRY(hipEventCreateWithFlags(&p->ev_busy, hipEventDisableTiming));
     rl = setup_lattice(p);
     if (rl != RPSF_OK) return rl;
+    if (parent) {  // tables and packed K are the parent's
+      p->d_tab = parent->d_tab, p->d_pairtab = parent->d_pairtab, p->d_tw = parent->d_tw, p->d_win = parent->d_win;
+      p->d_g = parent->d_g, p->d_gs = parent->d_gs, p->g_elems = parent->g_elems, p->gs_elems = parent->gs_elems;
+      p->have_k = parent->have_k;
+      p->overlap_mode = parent->overlap_mode, p->stagger_us = parent->stagger_us;
+      return RPSF_OK;
+    }
     if (p->v2)
       return dispatch_v2(N, [&]<class C>() -> int {
         int r2 = upload_tables2<C>(device, &p->d_tab, &p->d_tw, &p->d_win, &p->d_pairtab);
@@ -702,19 +731,27 @@ extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int
   return RPSF_OK;
 }
 
+extern "C" int rpsf_plan_create(rpsf_plan** out, int device, int patch_size, int n_patches, const int32_t* coords_rc) {
+  return plan_create_impl(out, device, patch_size, n_patches, coords_rc, nullptr, nullptr);
+}
+
 extern "C" void* rpsf_plan_stream(rpsf_plan* p) { return p ? (void*)p->stream : nullptr; }
 
 extern "C" void rpsf_plan_destroy(rpsf_plan* p) {
   if (!p) return;
   (void)hipSetDevice(p->device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
+  for (rpsf_plan* band : p->bands) rpsf_plan_destroy(band);
+  p->bands.clear();
   (void)hipFree(p->d_coords);
-  (void)hipFree(p->d_tab);
-  (void)hipFree(p->d_pairtab);
-  (void)hipFree(p->d_tw);
-  (void)hipFree(p->d_win);
-  (void)hipFree(p->d_g);
-  (void)hipFree(p->d_gs);
+  if (!p->parent) {
+    (void)hipFree(p->d_tab);
+    (void)hipFree(p->d_pairtab);
+    (void)hipFree(p->d_tw);
+    (void)hipFree(p->d_win);
+    (void)hipFree(p->d_g);
+    (void)hipFree(p->d_gs);
+  }
   if (p->pipe) {
     p->pipe->destroy();
     delete p->pipe;
@@ -745,8 +782,14 @@ extern "C" void rpsf_plan_destroy(rpsf_plan* p) {
   if (p->ev_busy) (void)hipEventDestroy(p->ev_busy);
   for (auto& e : p->ev)
     if (e) (void)hipEventDestroy(e);
-  if (p->stream) (void)hipStreamDestroy(p->stream);
+  if (p->stream && !p->parent) (void)hipStreamDestroy(p->stream);
   delete p;
+}
+
+static void drop_bands(rpsf_plan* p) {
+  for (rpsf_plan* band : p->bands) rpsf_plan_destroy(band);
+  p->bands.clear(), p->band_rows.clear(), p->band_in_rows.clear();
+  p->bands_h = p->bands_w = 0, p->bands_mode = -1;
 }
 
 static int pack_range(rpsf_plan* p, const cf* d_kfull, int first_patch, int count) {
@@ -798,6 +841,7 @@ extern "C" int rpsf_plan_set_transfer(rpsf_plan* p, const float* k_host) {
     }
   }
   if (rc == RPSF_OK) p->have_k = true;
+  for (rpsf_plan* band : p->bands) band->have_k = p->have_k;
   return rc;
 }
 
@@ -1270,6 +1314,7 @@ extern "C" int rpsf_plan_set_overlap_mode(rpsf_plan* p, int mode) {
   if (mode == 2 && !p->lattice) return fail(RPSF_E_STATE, "colour planes need a regular half-overlap lattice of patch corners");
   if (mode == 3 && !p->direct_ok) return fail(RPSF_E_STATE, "direct overlap-add needs a regular half-overlap lattice and a 128- or 256-pixel patch");
   p->overlap_mode = mode;
+  drop_bands(p);
   return RPSF_OK;
 }
 
@@ -1318,6 +1363,49 @@ extern "C" int rpsf_plan_set_reserved_cus(rpsf_plan* p, int cus) {
   return RPSF_OK;
 }
 
+// Confine the plan's own stream - and with it every launch the plan makes on it - to the compute units of `mask` (bit i of word i / 32:
+// hipExtStreamCreateWithCUMask's numbering), and size its persistent launches for that many.  With a second stream masked to the complement
+// (rpsf_stream_create) a caller gets two partitions of the chip that cannot take each other's CUs: the persistent patch launch needs whole
+// CUs, and small kernels dispatched beside it on an unmasked stream land on CUs its workgroups are waiting for (profiles/r05m).
+extern "C" int rpsf_plan_set_cu_mask(rpsf_plan* p, const uint32_t* mask, int words) {
+  if (!p || !mask || words <= 0) return fail(RPSF_E_BADARG, "bad argument");
+  if (p->parent) return fail(RPSF_E_STATE, "a view runs on its parent's stream");
+  int cus = 0;
+  for (int i = 0; i < words; ++i) cus += __builtin_popcount(mask[i]);
+  if (cus < 8) return fail(RPSF_E_BADARG, "the mask must leave the plan at least 8 compute units");
+  HIP_TRY(hipSetDevice(p->device));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  drop_bands(p);
+  hipStream_t masked = nullptr;
+  HIP_TRY(hipExtStreamCreateWithCUMask(&masked, (uint32_t)words, mask));
+  if (p->generic && g_hipfft.set_stream(p->fft_plan, masked) != 0) {
+    (void)hipStreamDestroy(masked);
+    return fail(RPSF_E_HIP, "hipfftSetStream failed");
+  }
+  (void)hipStreamDestroy(p->stream);
+  p->stream = masked;
+  p->busy_valid = false;
+  if (p->cu_count > 0) p->round_capacity = p->round_capacity / p->cu_count * cus;
+  p->cu_count = cus;
+  return RPSF_OK;
+}
+
+extern "C" int rpsf_stream_create(int device, const uint32_t* mask, int words, void** stream) {
+  if (!stream) return fail(RPSF_E_BADARG, "null argument");
+  HIP_TRY(hipSetDevice(device));
+  hipStream_t st = nullptr;
+  if (mask && words > 0)
+    HIP_TRY(hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask));
+  else
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  *stream = st;
+  return RPSF_OK;
+}
+extern "C" int rpsf_stream_destroy(void* stream) {
+  if (stream) HIP_TRY(hipStreamDestroy(reinterpret_cast<hipStream_t>(stream)));
+  return RPSF_OK;
+}
+
 extern "C" int rpsf_plan_set_image_prefetch(rpsf_plan* p, int on) {
   if (!p) return fail(RPSF_E_BADARG, "null plan");
   p->prefetch = on != 0;
@@ -1327,6 +1415,7 @@ extern "C" int rpsf_plan_set_image_prefetch(rpsf_plan* p, int on) {
 extern "C" int rpsf_plan_set_stagger(rpsf_plan* p, int microseconds) {
   if (!p || microseconds < 0 || microseconds > 1000) return fail(RPSF_E_BADARG, "stagger must be 0..1000 us");
   p->stagger_us = microseconds;
+  drop_bands(p);
   return RPSF_OK;
 }
 
@@ -1461,6 +1550,8 @@ static int pipe_ensure(rpsf_plan* p, size_t slot_floats, int depth) {
     for (auto* evs : {q.ev_in, q.ev_k, q.ev_out})
       for (int s = 0; s < HostPipe::MAX_DEPTH; ++s) HIP_TRY(hipEventCreateWithFlags(&evs[s], hipEventDisableTiming));
     for (auto& e : q.ev_chunk) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto* evs : {q.ev_band_in, q.ev_band_k})
+      for (int s = 0; s < HostPipe::MAX_BANDS; ++s) HIP_TRY(hipEventCreateWithFlags(&evs[s], hipEventDisableTiming));
   }
   if (slot_floats <= q.slot_floats && depth <= q.depth) return RPSF_OK;
   // grow (every host entry point drains its own work before it returns: nothing is in flight on these buffers)
@@ -1508,6 +1599,55 @@ static int drain_after_error(rpsf_plan* p, hipError_t err, const char* where) {
   return fail(RPSF_E_HIP, std::string(where) + ": " + hipGetErrorString(err));
 }
 
+// Row bands of one large host frame: the lattice rows are cut into `want` groups; band b owns the output rows from its first lattice
+// row to the next band's and runs every patch that reaches into them - its own lattice rows and the one above, which both neighbours
+// compute (the collective-free seam of regularizepsf_amd/sharding.py, on one GPU) - as a view of the plan.  A band can run as soon as the
+// image rows its patches read are on the device, and its rows can leave while the next band is still arriving: upload, patches and download
+// of one frame overlap.  Returns the number of bands (0: this plan / frame is not cut - the caller takes the whole-frame path).
+static int ensure_bands(rpsf_plan* p, const rpsf_geometry& g, int want) {
+  if (p->bands_h == g.height && p->bands_w == g.width && p->bands_mode == g.pad_mode) return (int)p->bands.size();
+  drop_bands(p);
+  p->bands_h = g.height, p->bands_w = g.width, p->bands_mode = g.pad_mode;  // (remembered also when the answer is "no bands")
+  if (p->generic || p->parent || !p->lattice || overlap_kind(p) != OV_PLANES || g.pad_mode == RPSF_PAD_WRAP || want < 2) return 0;
+  const int N = p->N, H = g.height;
+  std::vector<int> rows;
+  for (int i = 0; i < p->n_patches; ++i) rows.push_back(p->h_coords[2 * i]);
+  std::sort(rows.begin(), rows.end());
+  rows.erase(std::unique(rows.begin(), rows.end()), rows.end());
+  const int L = (int)rows.size();
+  const int B = std::min({want, (int)HostPipe::MAX_BANDS, L / 4});  // at least four lattice rows per band
+  if (B < 2) return 0;
+  std::vector<int> cut(B + 1);
+  for (int b = 0; b < B; ++b) cut[b] = b == 0 ? 0 : std::min(H, std::max(0, rows[(size_t)L * b / B]));
+  cut[B] = H;
+  for (int b = 0; b < B; ++b)
+    if (cut[b + 1] <= cut[b]) return 0;
+  std::vector<rpsf_plan*> bands;
+  std::vector<int> in_rows;
+  for (int b = 0; b < B; ++b) {
+    std::vector<int32_t> idx, coords;
+    int in_hi = 0;
+    for (int i = 0; i < p->n_patches; ++i) {
+      const int r = p->h_coords[2 * i];
+      if (r < cut[b + 1] && r + N > cut[b]) {
+        idx.push_back(i), coords.push_back(r), coords.push_back(p->h_coords[2 * i + 1]);
+        in_hi = std::max(in_hi, std::min(H, r + N));
+      }
+    }
+    rpsf_plan* view = nullptr;
+    // (every np.pad mode but 'wrap' maps a row beyond the image edge to a row within the patch's own reach, so rows [0, in_hi) suffice)
+    const int rc = idx.empty() ? fail(RPSF_E_STATE, "empty row band") :
+                                 plan_create_impl(&view, p->device, N, (int)idx.size(), coords.data(), p, idx.data());
+    if (rc != RPSF_OK) {
+      for (rpsf_plan* v : bands) rpsf_plan_destroy(v);
+      return 0;
+    }
+    bands.push_back(view), in_rows.push_back(std::max(in_hi, cut[b + 1]));
+  }
+  p->bands = bands, p->band_rows = cut, p->band_in_rows = in_rows;
+  return B;
+}
+
 // One frame.  The conversions run chunk by chunk (>= 4 MiB) on the pool, each chunk's H2D copy starts as soon as it is staged,
 // and on the way back each chunk is widened as soon as it has landed: conversion and PCIe overlap inside the frame.
 static int host_one_frame(rpsf_plan* p, const void* image, int in_f64, void* out, int out_f64, const rpsf_geometry& g) {
@@ -1528,6 +1668,57 @@ static int host_one_frame(rpsf_plan* p, const void* image, int in_f64, void* out
   };
   double t_conv_in = 0.0, t_conv_out = 0.0, t_wait_out = 0.0;
   const bool direct_in = !in_f64 && is_pinned_host(image), direct_out = !out_f64 && is_pinned_host(out);
+  // Large frames are cut into row bands (views of this plan) so that the upload of band b + 1, the patches of band b and the download of
+  // band b - 1 overlap (RPSF_HOST_BANDS=0: off, =n: that many).
+  int want_bands = bytes >= ((size_t)24 << 20) ? (int)(bytes >> 24) : 0;
+  if (const char* e = std::getenv("RPSF_HOST_BANDS")) want_bands = std::atoi(e);
+  const int B = ensure_bands(p, g, want_bands);
+  struct OutChunk {
+    size_t lo, hi;
+  };
+  std::vector<OutChunk> out_chunks;  // in the order their download was enqueued; event c is q.ev_chunk[c]
+  if (B >= 2) {
+    // chunks of whole rows, in row order; a band is launched behind the chunk that completes the rows it reads
+    const int W = g.width, H = g.height;
+    const int rows_per_chunk = (H + n_chunks - 1) / n_chunks;
+    const int sub = std::max(1, (int)HostPipe::MAX_CHUNKS / B);  // download pieces per band
+    int next_band = 0;
+    for (int r0 = 0; r0 < H && err == hipSuccess; r0 += rows_per_chunk) {
+      const int r1 = std::min(H, r0 + rows_per_chunk);
+      const size_t lo = (size_t)r0 * W, hi = (size_t)r1 * W;
+      if (!direct_in) {
+        const auto t0 = std::chrono::steady_clock::now();
+        pool.run(T, [&](int t) {
+          size_t a, b;
+          rpsf_host::split_range(lo, hi, t, T, a, b);
+          rpsf_host::narrow_or_copy(q.h_in[0], image, in_f64 != 0, a, b);
+        });
+        t_conv_in += ms_since(t0);
+      }
+      err = hipMemcpyAsync(q.d_in[0] + lo, (direct_in ? static_cast<const float*>(image) : q.h_in[0]) + lo, (hi - lo) * sizeof(float),
+                           hipMemcpyHostToDevice, q.st_in);
+      while (err == hipSuccess && next_band < B && p->band_in_rows[next_band] <= r1) {
+        const int b = next_band++;
+        const int R0 = p->band_rows[b], R1 = p->band_rows[b + 1];
+        rpsf_geometry gb = g;
+        gb.out_row0 = R0, gb.out_rows = R1 - R0;
+        err = hipEventRecord(q.ev_band_in[b], q.st_in);
+        if (err == hipSuccess) err = hipStreamWaitEvent(p->stream, q.ev_band_in[b], 0);
+        if (err == hipSuccess && launch_apply(p->bands[b], q.d_in[0], q.d_out[0] + (size_t)R0 * W, gb, p->stream, nullptr) != RPSF_OK)
+          err = hipErrorUnknown;
+        if (err == hipSuccess) err = hipEventRecord(q.ev_band_k[b], p->stream);
+        if (err == hipSuccess) err = hipStreamWaitEvent(q.st_out, q.ev_band_k[b], 0);
+        const int rows_per_piece = (R1 - R0 + sub - 1) / sub;
+        for (int s0 = R0; s0 < R1 && err == hipSuccess; s0 += rows_per_piece) {
+          const size_t plo = (size_t)s0 * W, phi = (size_t)std::min(R1, s0 + rows_per_piece) * W;
+          err = hipMemcpyAsync((direct_out ? static_cast<float*>(out) : q.h_out[0]) + plo, q.d_out[0] + plo, (phi - plo) * sizeof(float),
+                               hipMemcpyDeviceToHost, q.st_out);
+          if (err == hipSuccess) err = hipEventRecord(q.ev_chunk[out_chunks.size()], q.st_out);
+          out_chunks.push_back({plo, phi});
+        }
+      }
+    }
+  } else {
   if (direct_in) err = hipMemcpyAsync(q.d_in[0], image, bytes, hipMemcpyHostToDevice, q.st_in);
   for (int c = 0; c < n_chunks && err == hipSuccess && !direct_in; ++c) {
     size_t lo, hi;
@@ -1548,31 +1739,31 @@ static int host_one_frame(rpsf_plan* p, const void* image, int in_f64, void* out
   if (err == hipSuccess) err = hipStreamWaitEvent(q.st_out, q.ev_k[0], 0);
   if (direct_out && err == hipSuccess) {
     err = hipMemcpyAsync(out, q.d_out[0], bytes, hipMemcpyDeviceToHost, q.st_out);
-    if (err == hipSuccess) err = hipStreamSynchronize(q.st_out);
-    if (err != hipSuccess) return drain_after_error(p, err, "host frame");
-    return RPSF_OK;
+    if (err == hipSuccess) err = hipEventRecord(q.ev_chunk[0], q.st_out);
+    out_chunks.push_back({0, count});
   }
-  for (int c = 0; c < n_chunks && err == hipSuccess; ++c) {
+  for (int c = 0; c < n_chunks && err == hipSuccess && !direct_out; ++c) {
     size_t lo, hi;
     chunk_range(c, lo, hi);
     if (hi > lo) err = hipMemcpyAsync(q.h_out[0] + lo, q.d_out[0] + lo, (hi - lo) * sizeof(float), hipMemcpyDeviceToHost, q.st_out);
-    if (err == hipSuccess) err = hipEventRecord(q.ev_chunk[c], q.st_out);
+    if (err == hipSuccess) err = hipEventRecord(q.ev_chunk[out_chunks.size()], q.st_out);
+    out_chunks.push_back({lo, hi});
+  }
   }
   const double t_enqueued = ms_since(t_start);
   double t_in_done = 0.0, t_kernel_done = 0.0;
-  if (trace && err == hipSuccess) {
+  if (trace && err == hipSuccess && B < 2) {
     (void)hipEventSynchronize(q.ev_in[0]);
     t_in_done = ms_since(t_start);
     (void)hipEventSynchronize(q.ev_k[0]);
     t_kernel_done = ms_since(t_start);
   }
-  for (int c = 0; c < n_chunks && err == hipSuccess; ++c) {
+  for (size_t c = 0; c < out_chunks.size() && err == hipSuccess; ++c) {
     auto t0 = std::chrono::steady_clock::now();
     err = hipEventSynchronize(q.ev_chunk[c]);
     t_wait_out += ms_since(t0);
-    if (err != hipSuccess) break;
-    size_t lo, hi;
-    chunk_range(c, lo, hi);
+    if (err != hipSuccess || direct_out) continue;
+    const size_t lo = out_chunks[c].lo, hi = out_chunks[c].hi;
     t0 = std::chrono::steady_clock::now();
     pool.run(T, [&](int t) {
       size_t a, b;
@@ -1582,8 +1773,8 @@ static int host_one_frame(rpsf_plan* p, const void* image, int in_f64, void* out
     t_conv_out += ms_since(t0);
   }
   if (trace)
-    std::fprintf(stderr, "[rpsf host frame] %d chunks x %d threads: staged+enqueued %.3f ms (conversions %.3f), H2D done %.3f, kernel done %.3f, "
-                 "out: waits %.3f + conversions %.3f, total %.3f ms\n", n_chunks, T, t_enqueued, t_conv_in, t_in_done, t_kernel_done, t_wait_out,
+    std::fprintf(stderr, "[rpsf host frame] %d chunks x %d parts, %d bands: staged+enqueued %.3f ms (conversions %.3f), H2D done %.3f, kernel done %.3f, "
+                 "out: waits %.3f + conversions %.3f, total %.3f ms\n", n_chunks, T, B, t_enqueued, t_conv_in, t_in_done, t_kernel_done, t_wait_out,
                  t_conv_out, ms_since(t_start));
   if (err != hipSuccess) return drain_after_error(p, err, "host frame");
   return RPSF_OK;
@@ -2206,18 +2397,53 @@ extern "C" int rpsf_stream_wait(int device, void* waiter, void* signaller) {
   return RPSF_OK;
 }
 
+// Events for callers that order work across their streams at a distance (the sharded step: "this launch may start once the add of two
+// steps ago has read the buffer it writes" - a dependency that rpsf_stream_wait, which records at the time of the call, cannot express)
+extern "C" int rpsf_event_create(int device, void** event) {
+  if (!event) return fail(RPSF_E_BADARG, "null argument");
+  HIP_TRY(hipSetDevice(device));
+  hipEvent_t ev = nullptr;
+  HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  *event = ev;
+  return RPSF_OK;
+}
+extern "C" int rpsf_event_record(void* event, void* stream) {
+  if (!event) return fail(RPSF_E_BADARG, "null event");
+  HIP_TRY(hipEventRecord(reinterpret_cast<hipEvent_t>(event), reinterpret_cast<hipStream_t>(stream)));
+  return RPSF_OK;
+}
+extern "C" int rpsf_stream_wait_event(void* stream, void* event) {
+  if (!event) return fail(RPSF_E_BADARG, "null event");
+  HIP_TRY(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), reinterpret_cast<hipEvent_t>(event), 0));
+  return RPSF_OK;
+}
+extern "C" int rpsf_event_destroy(void* event) {
+  if (event) HIP_TRY(hipEventDestroy(reinterpret_cast<hipEvent_t>(event)));
+  return RPSF_OK;
+}
+
 // accum[0:count] += src[0:count] on `device` (kernel K4; the add of the seam exchange, exported for callers that move
 // the seam rows themselves)
-extern "C" int rpsf_add_rows(int device, void* accum_dev, const void* src_dev, size_t count, void* stream) {
+static int add_rows_impl(int device, void* accum_dev, const void* src_dev, size_t count, int max_workgroups, void* stream) {
   if (!accum_dev || !src_dev) return fail(RPSF_E_BADARG, "null argument");
   if (count == 0) return RPSF_OK;
   HIP_TRY(hipSetDevice(device));
   const int block = 256;
-  const size_t grid = ((count + 3) / 4 + block - 1) / block;
+  size_t grid = ((count + 3) / 4 + block - 1) / block;
+  if (max_workgroups > 0) grid = std::min<size_t>(grid, (size_t)max_workgroups);
   add_rows_kernel<<<dim3((unsigned)grid), dim3(block), 0, reinterpret_cast<hipStream_t>(stream)>>>(
       reinterpret_cast<float*>(accum_dev), reinterpret_cast<const float*>(src_dev), count);
   HIP_TRY(hipGetLastError());
   return RPSF_OK;
+}
+extern "C" int rpsf_add_rows(int device, void* accum_dev, const void* src_dev, size_t count, void* stream) {
+  return add_rows_impl(device, accum_dev, src_dev, count, 0, stream);
+}
+// The same add on at most `max_workgroups` workgroups (grid-stride): for callers that run it BESIDE a persistent patch launch (the pipelined
+// seam exchange) - a patch workgroup needs a whole CU, and a thousand small workgroups dispatched a moment before it would each hold one
+extern "C" int rpsf_add_rows_narrow(int device, void* accum_dev, const void* src_dev, size_t count, int max_workgroups, void* stream) {
+  if (max_workgroups <= 0) return fail(RPSF_E_BADARG, "max_workgroups must be positive");
+  return add_rows_impl(device, accum_dev, src_dev, count, max_workgroups, stream);
 }
 
 extern "C" int rpsf_comm_allreduce_max(rpsf_comm* c, double* value) {

@@ -223,7 +223,7 @@ inline void split_range(size_t lo, size_t hi, int t, int T, size_t& a, size_t& b
 // Owned by the plan, grown on demand, freed with it; no entry point allocates per call once the sizes have been seen.
 // ------------------------------------------------------------------------------------------------
 struct HostPipe {
-  static constexpr int MAX_DEPTH = 4, MAX_CHUNKS = 16;
+  static constexpr int MAX_DEPTH = 4, MAX_CHUNKS = 16, MAX_BANDS = 8;
   int depth = 0;
   size_t slot_floats = 0;
   hipStream_t st_in = nullptr, st_out = nullptr;
@@ -233,6 +233,7 @@ struct HostPipe {
   float* d_out[MAX_DEPTH] = {};
   hipEvent_t ev_in[MAX_DEPTH] = {}, ev_k[MAX_DEPTH] = {}, ev_out[MAX_DEPTH] = {};
   hipEvent_t ev_chunk[MAX_CHUNKS] = {};
+  hipEvent_t ev_band_in[MAX_BANDS] = {}, ev_band_k[MAX_BANDS] = {};  // a single frame cut into row bands (host_one_frame)
 
   void release_buffers() {
     for (int s = 0; s < MAX_DEPTH; ++s) {
@@ -253,6 +254,9 @@ struct HostPipe {
         if (evs[s]) (void)hipEventDestroy(evs[s]);
     for (auto& e : ev_chunk)
       if (e) (void)hipEventDestroy(e);
+    for (auto* evs : {ev_band_in, ev_band_k})
+      for (int s = 0; s < MAX_BANDS; ++s)
+        if (evs[s]) (void)hipEventDestroy(evs[s]);
     if (st_in) (void)hipStreamDestroy(st_in);
     if (st_out) (void)hipStreamDestroy(st_out);
   }

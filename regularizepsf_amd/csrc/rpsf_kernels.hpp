@@ -994,15 +994,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(8))) void sum_w
 
 // K4: accum[i] += src[i]
 // ------------------------------------------------------------------------------------------------
+// (grid-stride: a caller that runs it beside a persistent patch launch gives it a handful of workgroups, so that it lives on the CUs that
+// launch leaves free instead of spreading a thousand small workgroups over CUs the patch workgroups are waiting for)
 __global__ void add_rows_kernel(float* __restrict__ accum, const float* __restrict__ src, size_t count) {
-  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (i + 3 < count) {
-    float4 a = *reinterpret_cast<float4*>(accum + i);
-    float4 b = *reinterpret_cast<const float4*>(src + i);
-    a.x += b.x, a.y += b.y, a.z += b.z, a.w += b.w;
-    *reinterpret_cast<float4*>(accum + i) = a;
-  } else {
-    for (; i < count; ++i) accum[i] += src[i];
+  const size_t step = (size_t)gridDim.x * blockDim.x * 4;
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < count; i += step) {
+    if (i + 3 < count) {
+      float4 a = *reinterpret_cast<float4*>(accum + i);
+      float4 b = *reinterpret_cast<const float4*>(src + i);
+      a.x += b.x, a.y += b.y, a.z += b.z, a.w += b.w;
+      *reinterpret_cast<float4*>(accum + i) = a;
+    } else {
+      for (size_t j = i; j < count; ++j) accum[j] += src[j];
+    }
   }
 }
 

@@ -18,6 +18,7 @@ eight bands of the 4096-wide, 256-px configuration) against a 2 MiB send/recv pe
 
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -166,11 +167,20 @@ class ShardedApply:
 
     ``seam="exchange"`` with ``overlap=True`` (default) hides the transfer behind the band's own work: the spill rows depend
     only on the band's LAST lattice row of patches (in general: on every patch that reaches below the band's own rows), so
-    those run first, as a plan of their own on a stream of their own, straight into a spill buffer; the send (and the receive from the rank above) follows on that stream while the main plan -
-    all patches of the band, output cropped to the rows the band owns - is still running on the other.  The received rows
-    are added (K4) once both are done.  The last lattice row is computed twice (65 of 520 patches at eight bands of the
-    8192-wide configuration; they fit into the band's partial last round).  ``overlap=False`` is the plain sequence
-    apply -> exchange -> add on one stream.
+    those run first, as a plan of their own on a stream of their own, into a seam buffer that holds ALL their output rows: the
+    rows below the band's line are sent to the next rank (and the rows from the rank above received) on that stream while the
+    main plan - every OTHER patch of the band, output cropped to the rows the band owns - runs on the other; the seam patches'
+    rows above the line are added to the band's own rows (K4), and so are the received ones, once both are done.  Every patch
+    runs once (until round 4 the seam row ran twice, in both plans: 650 instead of 585 patches per band at eight bands of the
+    8192-wide configuration).  The seam buffer is double-buffered by step, so that the seam patches of step k + 1 may start
+    while the main plan of step k still runs.  ``overlap=False`` is the plain sequence apply -> exchange -> add on one stream.
+
+    ``overlap="pipeline"`` hides the transfer behind the NEXT step instead: one launch per step (all patches of the band, the
+    spill rows at the end of its buffer), and the send / receive / K4 add of step k run on the exchange stream while the launch
+    of step k + 1 runs on the main one (two output buffers in turn).  A stream of frames then pays one launch per step - a band
+    of 520 patches, fewer than `recompute`'s 585 - and nothing for the link; a single step takes apply + exchange + add in
+    sequence.  Measured band by band on one GPU (scripts/band_times.py, profiles/r05m_*): the two-plan form pays for its second
+    launch what the overlap saves.
     """
 
     def __init__(self, coordinates, kernel_for, patch_size: int, height: int, width: int, rank: int, world: int,
@@ -186,8 +196,11 @@ class ShardedApply:
         self.plan.set_transfer(kernel_for(b.patch_index))
         self.geometry = b.geometry(height, width, _native.PAD_MODES[pad_mode])
         self.comm = comm
-        self.overlap = bool(overlap and seam == "exchange" and world > 1 and b.send_rows + b.recv_rows > 0)
+        self.pipeline = overlap == "pipeline" and seam == "exchange" and world > 1 and b.send_rows + b.recv_rows > 0
+        self.overlap = bool(overlap and not self.pipeline and seam == "exchange" and world > 1 and b.send_rows + b.recv_rows > 0)
         self.seam_plan = None
+        self.seam_once = False
+        self.steps = 0
         self.d_img = _native.DeviceBuffer(b.image_rows * width * 4, device)
         self.d_recv = _native.DeviceBuffer(max(1, b.recv_rows) * width * 4, device)
         if self.overlap:
@@ -205,11 +218,50 @@ class ShardedApply:
                 # calculate_covering: the band's last lattice row; with a finer or irregular row spacing earlier rows too)
                 own_end = b.out_row0 + b.own_rows
                 seam_index = [i for i in b.patch_index if int(coordinates[i][0]) + patch_size > own_end]
+                seam_set = set(seam_index)
+                rest_index = [i for i in b.patch_index if i not in seam_set]
+                seam_top = min(int(coordinates[i][0]) for i in seam_index)
+                # The seam patches run ONCE when they are a run of rows at the end of the band: the main plan then takes the other
+                # patches, and the seam patches' rows above the band's line come back through K4 (rpsf_add_rows).
+                self.seam_once = bool(rest_index) and seam_top >= b.out_row0
                 self.seam_plan = _native.Plan(patch_size, [tuple(int(v) for v in coordinates[i]) for i in seam_index], device=device)
                 self.seam_plan.set_transfer(kernel_for(seam_index))
-                self.seam_geometry = _native.Geometry(height, width, pm, 0.0, 0, 0, b.image_row0, b.image_rows, width,
-                                                      b.out_row0 + b.own_rows, b.send_rows, width)
-                self.d_spill = _native.DeviceBuffer(b.send_rows * width * 4, device)
+                if self.seam_once:
+                    self.plan.close()
+                    self.plan = _native.Plan(patch_size, [tuple(int(v) for v in coordinates[i]) for i in rest_index], device=device)
+                    self.plan.set_transfer(kernel_for(rest_index))
+                    if comm is not None:
+                        self.plan.set_reserved_cus(8)
+                    self.seam_upper_rows = own_end - seam_top
+                    self.seam_geometry = _native.Geometry(height, width, pm, 0.0, 0, 0, b.image_row0, b.image_rows, width,
+                                                          seam_top, self.seam_upper_rows + b.send_rows, width)
+                    rows = self.seam_upper_rows + b.send_rows
+                    self.d_seam = [_native.DeviceBuffer(rows * width * 4, device) for _ in range(2)]
+                    self.seam_read = [_native.Event(device) for _ in range(2)]  # "the add of the step that used this buffer has read it"
+                    self.d_spill = None
+                else:
+                    self.seam_geometry = _native.Geometry(height, width, pm, 0.0, 0, 0, b.image_row0, b.image_rows, width,
+                                                          b.out_row0 + b.own_rows, b.send_rows, width)
+                    self.d_spill = _native.DeviceBuffer(b.send_rows * width * 4, device)
+        elif self.pipeline:
+            # The exchange of step k runs beside the persistent launch of step k + 1, whose workgroups need whole CUs: the chip is
+            # partitioned - the plan's stream keeps all but `carve` CUs, the exchange stream (RCCL's send / recv kernels, K4) gets those
+            carve = int(os.environ.get("RPSF_EXCHANGE_CUS", "8"))
+            cus, _ = _native.device_info(device)
+            self._xstream = None
+            if carve > 0:
+                main_mask, side_mask = _native.cu_masks(cus, carve)
+                self.plan.set_cu_mask(main_mask)
+                self._xstream = _native.Stream(device, side_mask)
+            else:
+                if comm is not None:
+                    self.plan.set_reserved_cus(8)
+                self._xstream = _native.Stream(device)
+            self.xstream = self._xstream.ptr
+            self.d_outs = [_native.DeviceBuffer(b.out_rows * width * 4, device) for _ in range(2)]
+            self.d_out = self.d_outs[0]
+            self.ev_applied = [_native.Event(device) for _ in range(2)]   # the launch of the step that used this buffer is done
+            self.ev_exchanged = [_native.Event(device) for _ in range(2)]  # ... and so are its send, its receive and its add
         else:
             self.d_out = _native.DeviceBuffer(b.out_rows * width * 4, device)
 
@@ -223,6 +275,24 @@ class ShardedApply:
     def step(self) -> None:
         """Enqueue one apply + seam exchange (asynchronous; ``synchronize`` waits for all of it)."""
         b, w = self.band, self.width
+        if self.pipeline:
+            slot = self.steps & 1
+            self.steps += 1
+            out = self.d_out = self.d_outs[slot]
+            self.ev_exchanged[slot].make_wait(self.plan.stream)  # the exchange of two steps ago has sent from / added into this buffer
+            self.plan.apply_device(self.d_img.ptr, out.ptr, self.geometry)
+            self.ev_applied[slot].record(self.plan.stream)
+            self.ev_applied[slot].make_wait(self.xstream)
+            if self.comm is not None:
+                # (d_recv is safe to overwrite: the previous step's add ran on this same stream)
+                self.comm.seam_exchange(out.at(b.send_offset_rows * w * 4), b.send_rows * w, self.d_recv.ptr, b.recv_rows * w, self.xstream)
+                if b.recv_rows > 0:
+                    # K4 on the CUs the persistent launch of the next step leaves free (a patch workgroup needs a whole CU: a thousand
+                    # small workgroups dispatched a moment before it cost that launch 16 us, profiles/r05m)
+                    _native.add_rows(out.ptr, self.d_recv.ptr, b.recv_rows * w, self.device, self.xstream,
+                                     max_workgroups=int(os.environ.get("RPSF_EXCHANGE_WGS", "64")))
+            self.ev_exchanged[slot].record(self.xstream)
+            return
         if not self.overlap:
             self.plan.apply_device(self.d_img.ptr, self.d_out.ptr, self.geometry)
             if self.comm is not None and self.world > 1 and b.send_rows + b.recv_rows > 0:
@@ -230,32 +300,67 @@ class ShardedApply:
                                             self.d_recv.ptr, b.recv_rows * w, self.d_out.ptr, self.plan.stream)
             return
         xstream = self.seam_plan.stream if self.seam_plan is not None else (self.comm.stream if self.comm is not None else None)
+        slot = self.steps & 1
+        self.steps += 1
         if self.seam_plan is not None:
-            # First in line, and not ordered against the main stream: the spill buffer is only ever touched on this stream (the
-            # previous step's send has read it by the time this apply runs), so the seam patches of step k + 1 may start while the
-            # main plan of step k still runs - they take the CUs it leaves free.  Two persistent launches side by side are safe:
-            # every slot of both is drawn from a queue by whichever workgroups are resident (rpsf.hip, launch_patches).
-            self.seam_plan.apply_device(self.d_img.ptr, self.d_spill.ptr, self.seam_geometry)
+            # First in line, and not ordered against the main stream's CURRENT work: the seam patches of step k + 1 may start while
+            # the main plan of step k still runs - they take the CUs it leaves free.  Two persistent launches side by side are safe:
+            # every slot of both is drawn from a queue by whichever workgroups are resident (rpsf.hip, launch_patches).  What the
+            # launch does have to wait for is the K4 add of two steps ago, which read the buffer it is about to overwrite (seam rows
+            # computed once: two buffers in turn); the spill buffer of the older scheme is only ever touched on this stream.
+            if self.seam_once:
+                self.seam_read[slot].make_wait(xstream)
+                self.seam_plan.apply_device(self.d_img.ptr, self.d_seam[slot].ptr, self.seam_geometry)
+            else:
+                self.seam_plan.apply_device(self.d_img.ptr, self.d_spill.ptr, self.seam_geometry)
         if xstream is not None and self.comm is not None and b.recv_rows > 0:
             # ... but the receive must not land before the previous step's add has read d_recv: the exchange waits for
             # everything enqueued on the main stream so far (its tail is that add; this step's main apply comes after this line)
             _native.stream_wait(xstream, self.plan.stream, self.device)
         self.plan.apply_device(self.d_img.ptr, self.d_out.ptr, self.geometry)
+        if self.seam_once:
+            # the seam patches' rows above the band's line: onto the band's own last rows, behind the main plan (the event is recorded
+            # on the seam stream here, behind the seam apply and in front of the exchange: the add does not wait for the link)
+            _native.stream_wait(self.plan.stream, xstream, self.device)
+            upper = self.seam_upper_rows
+            _native.add_rows(self.d_out.at((b.own_rows - upper) * w * 4), self.d_seam[slot].ptr, upper * w, self.device, self.plan.stream)
+            self.seam_read[slot].record(self.plan.stream)
         if self.comm is None:
             return
-        self.comm.seam_exchange(self.d_spill.ptr if self.seam_plan is not None else None, b.send_rows * w,
-                                self.d_recv.ptr, b.recv_rows * w, xstream)
+        if self.seam_plan is None:
+            send_ptr = None
+        elif self.seam_once:
+            send_ptr = self.d_seam[slot].at(self.seam_upper_rows * w * 4)
+        else:
+            send_ptr = self.d_spill.ptr
+        self.comm.seam_exchange(send_ptr, b.send_rows * w, self.d_recv.ptr, b.recv_rows * w, xstream)
         if b.recv_rows > 0:
             if xstream is not None:
                 _native.stream_wait(self.plan.stream, xstream, self.device)
             _native.add_rows(self.d_out.ptr, self.d_recv.ptr, b.recv_rows * w, self.device, self.plan.stream)
+
+    def spill_ptr(self):
+        """Device pointer of the rows the last ``step`` left for the next band (``send_rows * width`` floats)."""
+        b, w = self.band, self.width
+        if not self.overlap:
+            return self.d_out.at(b.send_offset_rows * w * 4)
+        if self.seam_plan is None:
+            return None
+        if self.seam_once:
+            return self.d_seam[(self.steps - 1) & 1].at(self.seam_upper_rows * w * 4)
+        return self.d_spill.ptr
 
     def spill_rows(self) -> np.ndarray:
         """The rows this band's last lattice row leaves for the next band (after ``step`` + ``synchronize``)."""
         b, w = self.band, self.width
         self.synchronize()
         if self.overlap:
-            return self.d_spill.download((b.send_rows, w)) if self.seam_plan is not None else np.zeros((0, w), np.float32)
+            if self.seam_plan is None:
+                return np.zeros((0, w), np.float32)
+            if self.seam_once:
+                last = self.d_seam[(self.steps - 1) & 1]
+                return last.download((b.send_rows, w), offset_bytes=self.seam_upper_rows * w * 4)
+            return self.d_spill.download((b.send_rows, w))
         return self.d_out.download((b.send_rows, w), offset_bytes=b.send_offset_rows * w * 4)
 
     def synchronize(self) -> None:

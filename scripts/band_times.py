@@ -1,7 +1,8 @@
 """Strong-scaling projection of BASELINE config 4 (one 8192^2 frame, 256-px patches) from ONE GPU: every row band of a world of
 1 / 2 / 4 / 8 ranks runs the product's own sharded step - ShardedApply.step(): the seam plan (the band's last lattice row, on
-its stream) beside the main plan (8 CUs left free, as with a communicator attached), the 128 spill rows moved on the seam
-stream, the receiver's stream waiting for them, K4 adding them - one band at a time, back to back, after a 100 ms prewarm.
+its stream, computed ONCE: its upper rows come back to the band through K4) beside the main plan (every other patch of the band, 8 CUs
+left free, as with a communicator attached), the 128 spill rows moved on the seam stream, the receiver's stream waiting for them, K4
+adding them - one band at a time, back to back, after a 100 ms prewarm.
 The link is replaced by a device-to-device hipMemcpyAsync of the same 4 MiB on the seam stream (`LocalLink`; what arrives is not
 what a neighbour would send - this script times, it does not verify).  Time per step = wall clock over the steps between two device
 synchronisations.  speedup = (world 1, same process, same clocks) / (slowest band).
@@ -24,6 +25,7 @@ from regularizepsf_amd.sharding import ShardedApply  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=60)
 ap.add_argument("--no-overlap", action="store_true")
+ap.add_argument("--pipeline", action="store_true", help="exchange mode: the send / recv / add of step k beside the launch of step k + 1")
 ap.add_argument("--worlds", default="1,2,4,8")
 ap.add_argument("--seam", choices=["exchange", "recompute"], default="exchange")
 ap.add_argument("--ranks", default="", help="development sweeps: only these ranks of every world (comma-separated; default all)")
@@ -42,8 +44,16 @@ class LocalLink:
         self._plan = _native.Plan(16, [(0, 0)])  # owns a stream for bands that have no seam plan
         self.stream = self._plan.stream
 
+    narrow = False  # --pipeline: the stand-in moves the rows with narrow grid-stride kernels, as RCCL's few send / recv channels do
+
     def seam_exchange(self, send_ptr, send_count, recv_ptr, recv_count, stream=None):
         st = stream if stream is not None else self.stream
+        if self.narrow:  # (adds instead of copies: the same bytes through the same few CUs)
+            if send_count:
+                _native.add_rows(self.scratch.ptr, send_ptr, send_count, 0, st, max_workgroups=64)
+            if recv_count:
+                _native.add_rows(recv_ptr, self.scratch.ptr, recv_count, 0, st, max_workgroups=64)
+            return
         if send_count:
             assert hip.hipMemcpyAsync(self.scratch.ptr, send_ptr, send_count * 4, 3, st) == 0
         if recv_count:
@@ -61,12 +71,13 @@ coords = [tuple(int(v) for v in t) for t in calculate_covering((h, w), n)]
 kk = (rng.standard_normal((585, n, n), dtype=np.float32) + 1j * rng.standard_normal((585, n, n), dtype=np.float32)).astype(np.complex64)
 image = rng.standard_normal((h, w), dtype=np.float32)
 link = LocalLink(128 * w)
+link.narrow = args.pipeline
 base = None
 for world in [int(v) for v in args.worlds.split(",")]:
     times = []
     for rank in ([r for r in (int(v) for v in args.ranks.split(",")) if r < world] if args.ranks else range(world)):
         sh = ShardedApply(coords, lambda idx: np.resize(kk, (len(idx), n, n)), n, h, w, rank, world, 0, link if world > 1 else None,
-                          seam=args.seam, overlap=not args.no_overlap)
+                          seam=args.seam, overlap="pipeline" if args.pipeline else not args.no_overlap)
         b = sh.band
         sh.upload_rows(image[b.image_row0:b.image_row0 + b.image_rows])
         t0 = time.perf_counter()
@@ -82,9 +93,12 @@ for world in [int(v) for v in args.worlds.split(",")]:
         times.append((len(b.patch_index), sh.seam_plan.n_patches if sh.seam_plan is not None else 0, round(us, 1)))
         if sh.seam_plan is not None:
             sh.seam_plan.close()
-            sh.d_spill.free()
-        sh.plan.close(); sh.d_img.free(); sh.d_out.free(); sh.d_recv.free()
+            for buf in ([sh.d_spill] if sh.d_spill is not None else sh.d_seam):
+                buf.free()
+        sh.plan.close(); sh.d_img.free(); sh.d_recv.free()
+        for buf in (sh.d_outs if sh.pipeline else [sh.d_out]):
+            buf.free()
     slowest = max(t for _, _, t in times)
     base = base or slowest
-    print(json.dumps({"world": world, "seam": args.seam, "overlap": not args.no_overlap and args.seam == "exchange", "bands (patches, seam patches, us per step)": times,
+    print(json.dumps({"world": world, "seam": args.seam, "overlap": ("pipeline" if args.pipeline else not args.no_overlap) if args.seam == "exchange" else False, "bands (patches, seam patches, us per step)": times,
                       "slowest_us": slowest, "speedup_vs_world_1": round(base / slowest, 2)}), flush=True)

@@ -186,7 +186,7 @@ def test_errors_follow_reference_conventions():
     assert out.dtype == np.float64
 
 
-@pytest.mark.parametrize("overlap", [False, True])
+@pytest.mark.parametrize("overlap", [False, True, "pipeline"])
 @pytest.mark.parametrize("world", [2, 3])
 def test_row_bands_on_one_gpu(world, overlap):
     """The multi-GPU band geometry (resident row windows, owned/spill rows) run band by band on ONE GPU;
@@ -203,7 +203,8 @@ def test_row_bands_on_one_gpu(world, overlap):
     for rank in range(world):
         sh = ShardedApply(coords, lambda idx: k[idx], n, h, w, rank, world, 0, None, overlap=overlap)
         b = sh.band
-        assert sh.overlap == overlap and (sh.seam_plan is not None) == (overlap and b.send_rows > 0)
+        assert sh.overlap == (overlap is True) and (sh.seam_plan is not None) == (overlap is True and b.send_rows > 0)
+        assert sh.pipeline == (overlap == "pipeline" and b.send_rows + b.recv_rows > 0)
         sh.upload_rows(image[b.image_row0 : b.image_row0 + b.image_rows])
         sh.step()
         own.append(sh.owned_rows().astype(np.float64))
@@ -212,7 +213,7 @@ def test_row_bands_on_one_gpu(world, overlap):
     for g in range(1, world):
         own[g][: bands[g].recv_rows] += spill[g - 1]
     check(np.concatenate(own), ref)
-    if overlap:
+    if overlap is not False:
         return
     # seam="recompute": every band also runs the patches above it that reach into its rows; nothing to add afterwards
     parts = []
@@ -630,7 +631,8 @@ def test_config4_8192_n256_eight_bands_both_seam_modes():
         if prev is not None:  # what the receiving rank does with the rows RCCL delivers: K4 on its own output
             psh, pb = prev
             assert psh.overlap and psh.seam_plan is not None  # spill rows computed first, by a plan of their own
-            _native.add_rows(sh.d_out.ptr, psh.d_spill.ptr, pb.send_rows * w)
+            assert psh.seam_once and psh.plan.n_patches + psh.seam_plan.n_patches == len(pb.patch_index)  # every patch runs once
+            _native.add_rows(sh.d_out.ptr, psh.spill_ptr(), pb.send_rows * w)
             sh.synchronize()
         out[b.out_row0 : b.out_row0 + b.own_rows] = sh.d_out.download((b.own_rows, w))
         prev = (sh, b)

@@ -112,7 +112,7 @@ def _check(results):
 
 
 @pytest.mark.timeout(900, method="thread")
-@pytest.mark.parametrize("overlap", [True, False])
+@pytest.mark.parametrize("overlap", [True, False, "pipeline"])
 def test_sharded_step_world_2_host_transport(overlap):
     _check(_run("gloo", overlap))
 

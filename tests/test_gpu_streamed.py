@@ -161,3 +161,36 @@ def test_streamed_errors_are_reported():
     plan = _native.Plan(32, coords)
     with pytest.raises(_native.NativeError):  # no transfer kernel installed
         plan.apply_frames_host(images, _native.PAD_MODES["symmetric"])
+
+
+@pytest.mark.parametrize(("n", "shape", "pad_mode"), [(256, (3072, 2048), "symmetric"), (128, (2560, 2304), "reflect"),
+                                                      (64, (2200, 3000), "constant"), (256, (4096, 4096), "symmetric")])
+def test_a_large_frame_cut_into_row_bands_is_bit_identical_to_the_whole_frame(n, shape, pad_mode, monkeypatch):
+    """Host frames of 24 MiB and more are cut into row bands (views of the plan that share its K) so that upload, patches and
+    download of ONE frame overlap; the bands take their plane colours from the whole lattice, so the result is the whole-frame
+    apply's bit for bit - with two, four or eight bands, odd shapes, and from page-locked arrays."""
+    coords, k, images = _case(n, shape, 1, 5 * n)
+    image = images[0]
+    t = rp.ArrayPSFTransform(rp.IndexedCube(coords, k))
+    monkeypatch.setenv("RPSF_HOST_BANDS", "0")
+    whole = t.apply(image, pad_mode=pad_mode)
+    check(whole, orc.apply_transfer(image, coords, k, pad_mode=pad_mode, workers=-1))
+    for bands in ("2", "4", "8"):
+        monkeypatch.setenv("RPSF_HOST_BANDS", bands)
+        t.invalidate()  # (a plan keeps the bands it built for a frame shape: a new plan per setting)
+        assert np.array_equal(t.apply(image, pad_mode=pad_mode), whole), bands
+        assert np.array_equal(t.apply(image.astype(np.float64), pad_mode=pad_mode), whole), bands
+    monkeypatch.delenv("RPSF_HOST_BANDS")
+    t.invalidate()
+    assert np.array_equal(t.apply(image, pad_mode=pad_mode), whole)  # the default choice for this size
+    pin = rp.pinned_empty(shape, np.float32)
+    pin[...] = image
+    pout = rp.pinned_empty(shape, np.float32)
+    plan = t._device_plan()
+    plan.apply_host(pin, _native.PAD_MODES[pad_mode], out=pout)
+    assert np.array_equal(pout, whole.astype(np.float32))
+    # the same plan on another frame shape afterwards (the bands are rebuilt for it: the corner list reaches beyond the smaller frame,
+    # which the reference allows as long as the corners stay inside its 2N pad), then the first shape again
+    small = np.ascontiguousarray(image[: shape[0] - n // 2, : shape[1] - n // 2])
+    check(t.apply(small, pad_mode=pad_mode), orc.apply_transfer(small, coords, k, pad_mode=pad_mode, workers=-1))
+    assert np.array_equal(t.apply(image, pad_mode=pad_mode), whole)
