@@ -15,7 +15,7 @@ import sys
 
 PKG = pathlib.Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
-SOURCES = [CSRC / n for n in ("rpsf.hip", "k1_256.hip", "k1_128.hip", "k1_small.hip", "k2_256.hip", "k2_256p.hip", "k2_128.hip", "k2_128p.hip", "k2_128pc.hip", "k2_128pcs.hip", "k2_256s.hip")]
+SOURCES = [CSRC / n for n in ("rpsf.hip", "k1_256.hip", "k1_128.hip", "k1_small.hip", "k2_256.hip", "k2_256p.hip", "k2_128.hip", "k2_128p.hip", "k2_128pc.hip", "k2_128pcs.hip")]
 HEADERS = [CSRC / n for n in ("rpsf_core.hpp", "rpsf_core2.hpp", "rpsf_kernels.hpp", "rpsf_kernels2.hpp", "rpsf_device.hpp", "rpsf_hostpipe.hpp")] + [
     PKG.parent / "include" / "rpsf.h"]
 TARGET = PKG / "librpsf_hip.so"
@@ -132,7 +132,10 @@ def build(force: bool = False, verbose: bool = True, defines: tuple[str, ...] = 
         obj = objdir / (src.stem + ".o")
         if not force and obj.exists() and obj.stat().st_mtime > max(src.stat().st_mtime, newest_header):
             return obj
-        cmd = [hipcc, *FLAGS, *os.environ.get("RPSF_EXTRA_HIPCC_FLAGS", "").split(), *defines, "-c", str(src), "-o", str(obj)]  # (development: e.g. -mllvm options)
+        # (development: e.g. -mllvm options - honoured for VARIANT builds only, never for the product library, whose objects carry no
+        # record of a stray environment variable)
+        extra = os.environ.get("RPSF_EXTRA_HIPCC_FLAGS", "").split() if (defines or target) else []
+        cmd = [hipcc, *FLAGS, *extra, *defines, "-c", str(src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
@@ -145,10 +148,6 @@ def build(force: bool = False, verbose: bool = True, defines: tuple[str, ...] = 
     check_reentry_contract(next(o for o in objs if o.stem == "k2_128p"), "patch_kernel2_128p")
     check_reentry_contract(next(o for o in objs if o.stem == "k2_128pc"), "patch_kernel2_128pc")
     check_reentry_contract(next(o for o in objs if o.stem == "k2_128pcs"), "patch_kernel2_128pcs")
-    if any(d.startswith("-DRPSF_DEV_SPLIT") for d in defines):
-        check_reentry_contract(next(o for o in objs if o.stem == "k2_256s"), "patch_kernel2_256s")
-    if any(d.startswith("-DRPSF_DEV_WIDE") for d in defines):
-        check_reentry_contract(next(o for o in objs if o.stem == "k2_256s"), "patch_kernel2_256w")
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(out), *[str(o) for o in objs], "-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)

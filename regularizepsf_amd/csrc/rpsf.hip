@@ -13,10 +13,8 @@
 //   add_rows_kernel        K4: seam accumulate for the multi-GPU row-band split.
 //   sum_planes_kernel      K5: output = sum of the four colour planes the patches of one parity class write.
 //   generic_*_kernel       gather / multiply / scatter around hipFFT for patch sizes without a plan.
-// Development-only build switches (never set by regularizepsf_amd/build.py): RPSF_STAMPS (per-phase
-// timestamps, scripts/stamps.py), RPSF_ABL_NOK / _NOLOAD / _NOSTORE / _NOATOMIC (traffic ablations: results
-// are wrong, timing only), RPSF_ONLY_N / RPSF_ONLY_CFG (single-plan library for quick A/B builds),
-// RPSF_KRING (K chunks in flight), RPSF_NOFUSE, RPSF_NO_NT.
+// Development-only build switches (never set by regularizepsf_amd/build.py): RPSF_STAMPS / RPSF_WAVE_STAMPS (per-phase
+// timestamps, scripts/stamps.py) and the RPSF2_ABL_* timing ablations of rpsf_kernels2.hpp (results are wrong, timing only).
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
@@ -127,17 +125,6 @@ struct rpsf_plan {
   // Persistent patch workgroups (patch_kernel2_256p; fused launches of the 256-pixel plan): per-XCD slot queues, never reset
   bool persist = false;
   bool k_cached = false;             // 128-pixel persistent launches take patch_kernel2_128pc (plain loads of the pair words): see rpsf_plan_create
-#if defined(RPSF_DEV_SPLIT)  // development: the split-patch timing skeleton (k2_256s.hip) and its tables
-  bool dev_split = false;
-  uint16_t* d_tab_s = nullptr;
-  uint32_t* d_ot_s = nullptr;
-  cf* d_tw_s = nullptr;
-  float* d_win_s = nullptr;
-#endif
-  // Co-resident summing waves (sum_waves_kernel): a second stream and the events that tie it to the apply's stream
-  bool cosum = false;
-  hipStream_t st_sum = nullptr;
-  hipEvent_t ev_sum_go = nullptr, ev_sum_done = nullptr;
   int reserved_cus = 0;              // persistent launches leave this many CUs without a patch workgroup (rpsf_plan_set_reserved_cus)
   uint32_t* d_xq = nullptr;          // 8 counters, one per 128-byte line
   uint32_t xq_base[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -166,8 +153,6 @@ struct rpsf_plan {
   float* d_win_generic = nullptr;
   void* fft_plan = nullptr;    // hipfftHandle for fft_chunk patches
   int fft_chunk = 0;
-  float* d_carry = nullptr;  // persistent launches: one half patch of private scratch per workgroup
-  size_t carry_floats = 0;
   float* d_planes = nullptr;
   size_t planes_floats = 0;  // per plane
   size_t planes_frames = 0;  // frames the allocation holds (4 planes each)
@@ -646,31 +631,6 @@ static int plan_create_impl(rpsf_plan** out, int device, int patch_size, int n_p
         if (const char* e = std::getenv("RPSF_K_CACHED")) p->k_cached = std::atoi(e) != 0;
       }
     }
-#if defined(RPSF_VGPR_CAP)  // (development builds only: the product's patch kernel takes all 512 registers of a SIMD lane)
-    p->cosum = p->persist && std::getenv("RPSF_COSUM") != nullptr;
-#endif
-#if defined(RPSF_DEV_WIDE)
-    if (p->persist && N == 256)
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_kernel2_256w), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)Launch2<Cfg256v2>::LDS_BYTES));
-#endif
-#if defined(RPSF_DEV_SPLIT)
-    if (p->persist && N == 256 && !(std::getenv("RPSF_DEV_SPLIT") && std::atoi(std::getenv("RPSF_DEV_SPLIT")) == 0)) {
-      p->dev_split = true;
-      int r3 = upload_tables2<Cfg256half>(device, &p->d_tab_s, &p->d_tw_s, &p->d_win_s, &p->d_ot_s);
-      if (r3 != RPSF_OK) return r3;
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_kernel2_256s), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)Launch2<Cfg256half>::LDS_BYTES));
-      int per_cu = 0;
-      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, patch_kernel2_256s, 256, Launch2<Cfg256half>::LDS_BYTES));
-      if (per_cu < 2) return fail(RPSF_E_STATE, "split skeleton: two workgroups per CU do not fit (" + std::to_string(per_cu) + ")");
-    }
-#endif
-    if (p->cosum) {
-      HIP_TRY(hipStreamCreateWithFlags(&p->st_sum, hipStreamNonBlocking));
-      HIP_TRY(hipEventCreateWithFlags(&p->ev_sum_go, hipEventDisableTiming));
-      HIP_TRY(hipEventCreateWithFlags(&p->ev_sum_done, hipEventDisableTiming));
-    }
     int rl = p->v2 ? dispatch_v2(N, [&]<class C>() -> int {
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_kernel2<C>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)Launch2<C>::LDS_BYTES));
@@ -765,7 +725,6 @@ extern "C" void rpsf_plan_destroy(rpsf_plan* p) {
   (void)hipFree(p->d_win_generic);
   if (p->fft_plan && g_hipfft.destroy) (void)g_hipfft.destroy(p->fft_plan);
   (void)hipFree(p->d_planes);
-  (void)hipFree(p->d_carry);
   (void)hipFree(p->d_prefetch_tiles);
   (void)hipFree(p->d_quads);
   (void)hipFree(p->d_tile_info);
@@ -776,9 +735,6 @@ extern "C" void rpsf_plan_destroy(rpsf_plan* p) {
   (void)hipFree(p->d_sum_order);
   (void)hipFree(p->d_sum_queue);
   (void)hipFree(p->d_xq);
-  if (p->ev_sum_go) (void)hipEventDestroy(p->ev_sum_go);
-  if (p->ev_sum_done) (void)hipEventDestroy(p->ev_sum_done);
-  if (p->st_sum) (void)hipStreamDestroy(p->st_sum);
   if (p->ev_busy) (void)hipEventDestroy(p->ev_busy);
   for (auto& e : p->ev)
     if (e) (void)hipEventDestroy(e);
@@ -928,9 +884,12 @@ static int sum_first_for(const rpsf_plan* p, int frames) {
 // of a patch - four pixels of one row starting at a column that is a multiple of 4 - maps under np.pad's index map to four consecutive
 // image columns (ascending or descending) or to the fill.  True for 'constant', 'symmetric' and 'wrap' when the width is a multiple of
 // 4 (no unit straddles an image edge or a reflection); 'reflect' and 'edge' tear units apart.  Other launches take patch_kernel2.
-static bool hot_geometry(const float* d_img, const rpsf_geometry& g, size_t im_stride) {
+// (self-contained: the patch columns themselves - lattice origin + origin_col - and the plane stride are checked here too, not left to the
+// `fused` predicate of launch_apply, so that relaxing that one can never hand the HOT kernels a unit they have no path for)
+static bool hot_geometry(const rpsf_plan* p, const float* d_img, const rpsf_geometry& g, size_t im_stride) {
   return (g.pad_mode == RPSF_PAD_CONSTANT || g.pad_mode == RPSF_PAD_SYMMETRIC || g.pad_mode == RPSF_PAD_WRAP) && g.width % 4 == 0 &&
-         g.ld_image % 4 == 0 && g.origin_col % 4 == 0 && im_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(d_img) & 15) == 0;
+         g.ld_image % 4 == 0 && g.origin_col % 4 == 0 && im_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(d_img) & 15) == 0 &&
+         p->lattice && ((long)p->lat_c0 + g.origin_col) % 4 == 0 && p->planes_floats % 4 == 0;
 }
 
 // fused: the plane sum runs in this launch (see rpsf_plan::d_tile_done)
@@ -1006,35 +965,13 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
           // i.e. when every remaining patch of the chunk is in the hands of a resident workgroup that does not wait for anything;
           // (2) summing workgroups wait (poll + s_sleep) only for tiles whose patches are drawn or will be drawn by (1).  So the
           // launch completes as soon as, for every chunk, ONE patch workgroup gets a CU: in dispatch order the first sum_first + 8
-          // workgroups.  The only workgroups that hold a CU without progress of their own are the sum_first (<= 32) head summing
-          // ones; concurrent persistent launches therefore cannot starve one another unless their head summing workgroups alone
-          // fill the chip (tests: test_two_persistent_plans_on_two_streams).
-          if (p->cosum) pp.sum_first = 0;  // the summing is done by waves beside the patch workgroups: every CU takes patches
+          // workgroups.  The only workgroups that hold a CU without progress of their own are the sum_first head summing ones (<= 32 of
+          // 512 threads for the 256-pixel plan; up to 160 of 128 threads - four to a CU, 40 CUs' worth - for the 128-pixel plan from 4096
+          // patch-frames on, sum_first_for); concurrent persistent launches therefore cannot starve one another unless their head summing
+          // workgroups alone fill the chip (tests: test_two_persistent_plans_on_two_streams, 256- and 128-pixel plans).
           // (queue positions of an XCD: chunk slots x frames, the frames of a slot side by side)
           const int rows = std::min(pp.chunk * b.frames, std::max(1, (p->round_capacity - pp.sum_first - p->reserved_cus) / 8));
-#if defined(RPSF_DEV_SPLIT)
-          if constexpr (std::is_same_v<C, Cfg256v2>)
-            if (p->dev_split && p->persist && rows > 0 && b.frames == 1 && hot_geometry(d_img, g, b.im_stride)) {
-              // queue positions are half patches, two 256-thread workgroups per CU (head summing workgroups are half the size too)
-              const int cap2 = 2 * p->round_capacity;
-              pp.sum_first *= 2;
-              const int rows2 = std::min(2 * pp.chunk, std::max(1, (cap2 - pp.sum_first - 2 * p->reserved_cus) / 8));
-              pp.persist = rows2, pp.xq = p->d_xq, pp.patch_blocks = 2 * (int)blocks, pp.stagger_blocks = cap2;
-              pp.tab = p->d_tab_s, pp.pairtab = p->d_ot_s, pp.head_patches = 0, pp.prefetch = 0;
-              if (p->stagger_us < 0 && p->n_patches >= 256) pp.stagger_ticks = 1200;
-              for (int x = 0; x < 8; ++x) {
-                pp.xq_base[x] = p->xq_base[x];
-                const int slots_x = 2 * std::min(pp.chunk, std::max(0, p->n_patches - x * pp.chunk));
-                p->xq_base[x] += (uint32_t)(slots_x + rows2);
-              }
-              const int wgs = pp.sum_first + 8 * rows2;
-              p->sum_queue_base += (uint32_t)(ts.count + wgs);
-              patch_kernel2_256s<<<dim3((unsigned)wgs), dim3(256), Launch2<Cfg256half>::LDS_BYTES, st>>>(pp);
-              HIP_TRY(hipGetLastError());
-              return RPSF_OK;
-            }
-#endif
-          if (p->persist && rows > 0 && hot_geometry(d_img, g, b.im_stride)) {
+          if (p->persist && rows > 0 && hot_geometry(p, d_img, g, b.im_stride)) {
             pp.persist = rows, pp.xq = p->d_xq;
             // a head summing workgroup would idle through the first patch period (no tile is complete before that): it computes one patch
             // of its XCD's chunk first (RPSF_HEAD_PATCHES=0: off)
@@ -1065,30 +1002,7 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
               p->xq_base[x] += (uint32_t)(std::max(0, slots_x - (pp.head_patches ? pp.sum_first / 8 : 0)) + rows);
             }
             const int wgs = pp.sum_first + 8 * rows;
-#if defined(RPSF_DEV_CARRY)
-            const size_t carry_need = (size_t)std::max(wgs, 512) * C::T * 64;
-            if (carry_need > p->carry_floats) {
-              HIP_TRY(hipDeviceSynchronize());
-              (void)hipFree(p->d_carry);
-              p->d_carry = nullptr, p->carry_floats = 0;
-              HIP_TRY(hipMalloc(&p->d_carry, carry_need * sizeof(float)));
-              HIP_TRY(hipMemset(p->d_carry, 0, carry_need * sizeof(float)));
-              p->carry_floats = carry_need;
-            }
-            pp.carry = p->d_carry;
-#endif
-            const int ncos = p->cosum ? p->cu_count : 0;  // one workgroup of summing waves per CU
-            p->sum_queue_base += (uint32_t)(ts.count + wgs + ncos);  // every workgroup draws one position past the end
-            if (ncos) {  // the summing waves may start once everything before this apply on `st` is done ...
-              HIP_TRY(hipEventRecord(p->ev_sum_go, st));
-              HIP_TRY(hipStreamWaitEvent(p->st_sum, p->ev_sum_go, 0));
-            }
-#if defined(RPSF_DEV_WIDE)  // development: the 1024-thread timing skeleton in place of the persistent 256-pixel kernel
-            if (std::is_same_v<C, Cfg256v2> && b.frames == 1 && !(std::getenv("RPSF_DEV_WIDE") && std::atoi(std::getenv("RPSF_DEV_WIDE")) == 0)) {
-              pp.prefetch = 0;
-              patch_kernel2_256w<<<dim3((unsigned)wgs), dim3(1024), Launch2<Cfg256v2>::LDS_BYTES, st>>>(pp);
-            } else
-#endif
+            p->sum_queue_base += (uint32_t)(ts.count + wgs);  // every workgroup draws one position past the end
             if (p->k_cached && pp.plane_nt)
               PersistentKernel2<C>::fn_k_cached_planes_nt<<<dim3((unsigned)wgs), dim3(Launch2<C>::WG), Launch2<C>::LDS_BYTES, st>>>(pp);
             else if (p->k_cached)
@@ -1096,14 +1010,6 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
             else
               PersistentKernel2<C>::fn<<<dim3((unsigned)wgs), dim3(Launch2<C>::WG), Launch2<C>::LDS_BYTES, st>>>(pp);
             HIP_TRY(hipGetLastError());
-            if (ncos) {  // ... and the apply is complete on `st` when they are
-#if defined(RPSF_VGPR_CAP)
-              sum_waves_kernel<<<dim3((unsigned)ncos), dim3(256), 16 << 10, p->st_sum>>>(pp.ts);
-#endif
-              HIP_TRY(hipGetLastError());
-              HIP_TRY(hipEventRecord(p->ev_sum_done, p->st_sum));
-              HIP_TRY(hipStreamWaitEvent(st, p->ev_sum_done, 0));
-            }
             return RPSF_OK;
           }
         }
@@ -1333,29 +1239,6 @@ extern "C" int rpsf_plan_debug_stamps(rpsf_plan* p, unsigned long long* host, si
   return RPSF_OK;
 }
 
-#if defined(RPSF_DEV_PROBE)
-// Development probe: do the workgroups of a small second kernel (<= 16 registers, 16 KiB of LDS, 4 waves) get CUs while the
-// persistent patch kernel holds one workgroup on every CU?  Every probe workgroup records when and where it started.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(8))) void probe_kernel(unsigned long long* out, int spin_us) {
-  extern __shared__ float probe_lds[];
-  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-  if (threadIdx.x == 0) {
-    unsigned hw = 0, xcc = 0;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    out[2 * blockIdx.x] = t0;
-    out[2 * blockIdx.x + 1] = ((unsigned long long)xcc << 32) | hw;
-    probe_lds[0] = 1.f;
-  }
-  while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)spin_us * 100) __builtin_amdgcn_s_sleep(16);
-}
-extern "C" int rpsf_dev_probe(int device, int blocks, int spin_us, void* out_dev, void* stream) {
-  HIP_TRY(hipSetDevice(device));
-  probe_kernel<<<dim3((unsigned)blocks), dim3(256), 16 << 10, reinterpret_cast<hipStream_t>(stream)>>>(static_cast<unsigned long long*>(out_dev), spin_us);
-  HIP_TRY(hipGetLastError());
-  return RPSF_OK;
-}
-#endif
 
 extern "C" int rpsf_plan_set_reserved_cus(rpsf_plan* p, int cus) {
   if (!p || cus < 0 || cus > 128) return fail(RPSF_E_BADARG, "reserved CUs must be 0..128");

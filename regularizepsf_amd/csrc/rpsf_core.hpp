@@ -42,7 +42,6 @@
 
 namespace rpsf {
 
-#if !defined(RPSF_PACKED_CF)
 // Scalar complex.  Measured on MI355X: v_pk_{add,mul,fma}_f32 issue at half the rate of the scalar
 // forms (no throughput gain) and need their operands in aligned register pairs, which cost the
 // packed build ~1800 v_mov and ~800 s_nop per thread; scalar code lets re/im be renamed freely.
@@ -55,52 +54,12 @@ RPSF_HD cf operator-(cf a, cf b) { return cf{a.x - b.x, a.y - b.y}; }
 RPSF_HD cf operator*(cf a, cf b) { return cf{a.x * b.x, a.y * b.y}; }
 RPSF_HD cf operator*(cf a, float b) { return cf{a.x * b, a.y * b}; }
 RPSF_HD cf operator-(cf a) { return cf{-a.x, -a.y}; }
-#else
-// Packed complex (development, RPSF_PACKED_CF): a value is an aligned register pair and the arithmetic is written on whole pairs -
-// element-wise fma / add / mul with swizzled and negated operands - so that the compiler emits v_pk_* with op_sel / neg modifiers and no
-// component moves (what sank the earlier packed builds: 490 ... 1,274 v_mov).  A twiddled butterfly is three v_pk_fma instead of six FMAs,
-// a complex product two instructions instead of four; by the issue table of profiles/r04d (4.6 ... 4.8 cycles per packed instruction against
-// 2.55 ... 3.5 per scalar one) that is ~14 % fewer cycles for the networks.
-typedef float cf __attribute__((ext_vector_type(2)));
-RPSF_HD cf pk_swap(cf a) { return __builtin_shufflevector(a, a, 1, 0); }
-RPSF_HD cf pk_fma(cf a, cf b, cf c) { return __builtin_elementwise_fma(a, b, c); }
-#endif
 
-#if !defined(RPSF_PACKED_CF)
 RPSF_HD cf cmul(cf a, cf b) { return cf{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
 RPSF_HD cf cmulc(cf a, cf b) { return cf{a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y}; }  // a * conj(b)
 RPSF_HD cf cconj(cf a) { return cf{a.x, -a.y}; }
 RPSF_HD cf mul_pi(cf a) { return cf{-a.y, a.x}; }   // a * (+i)
 RPSF_HD cf mul_mi(cf a) { return cf{a.y, -a.x}; }   // a * (-i)
-#else
-// a b = a (b.x, b.x) + swap(a) (-b.y, b.y);   a conj(b) = a (b.x, b.x) + swap(a) (b.y, -b.y).  With a run-time b the two instructions are written
-// out with their operand swizzles (the compiler builds the pair (-b.y, b.y) with moves otherwise); with a compile-time b it folds the constants itself.
-RPSF_HD cf cmul(cf a, cf b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  if (!(__builtin_constant_p(b.x) && __builtin_constant_p(b.y))) {
-    cf t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(b));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
-    return r;
-  }
-#endif
-  return pk_fma(pk_swap(a), cf{-b.y, b.y}, a * cf{b.x, b.x});
-}
-RPSF_HD cf cmulc(cf a, cf b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  if (!(__builtin_constant_p(b.x) && __builtin_constant_p(b.y))) {
-    cf t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(b));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
-    return r;
-  }
-#endif
-  return pk_fma(pk_swap(a), cf{b.y, -b.y}, a * cf{b.x, b.x});
-}
-RPSF_HD cf cconj(cf a) { return __builtin_shufflevector(a, -a, 0, 3); }
-RPSF_HD cf mul_pi(cf a) { return __builtin_shufflevector(a, -a, 3, 0); }   // (-a.y, a.x)
-RPSF_HD cf mul_mi(cf a) { return __builtin_shufflevector(a, -a, 1, 2); }   // (a.y, -a.x)
-#endif
 // select on VALUES: `c ? arr[i] : arr[j]` would become a load through a selected pointer and
 // push the whole register tile into scratch
 RPSF_HD cf sel(bool c, cf a, cf b) { return cf{c ? a.x : b.x, c ? a.y : b.y}; }
@@ -110,7 +69,7 @@ RPSF_HD cf sel(bool c, cf a, cf b) { return cf{c ? a.x : b.x, c ? a.y : b.y}; }
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 RPSF_HD void load_stream16(const void* p, cf& a, cf& b) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(RPSF_NO_NT)
+#if defined(__HIP_DEVICE_COMPILE__)
   f32x4 q = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
 #else
   f32x4 q = *reinterpret_cast<const f32x4*>(p);
@@ -131,7 +90,7 @@ RPSF_HD void load_k16(const void* p, cf& a, cf& b) {
 }
 RPSF_HD void store_stream8(void* p, cf v) {
   f32x2 q = {v.x, v.y};
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(RPSF_NO_NT)
+#if defined(__HIP_DEVICE_COMPILE__)
   __builtin_nontemporal_store(q, reinterpret_cast<f32x2*>(p));
 #else
   *reinterpret_cast<f32x2*>(p) = q;
@@ -173,25 +132,15 @@ RPSF_HD void butterfly_dit(cf e, cf o, cf& x, cf& y) {
   if constexpr (k == 0) {
     x = e + o, y = e - o;
   } else if constexpr (k == 16) {
-#if defined(RPSF_PACKED_CF)
-    const cf sgn = INV ? cf{-1.0f, 1.0f} : cf{1.0f, -1.0f};  // +-i o = swap(o) * sgn, folded into the two accumulations
-    x = pk_fma(pk_swap(o), sgn, e), y = pk_fma(pk_swap(o), -sgn, e);
-#else
     cf t = INV ? mul_pi(o) : mul_mi(o);
     x = e + t, y = e - t;
-#endif
   } else {
     constexpr float c = cos64(k);
     constexpr float s = INV ? sin64(k) : -sin64(k);  // W = c + i s
-#if defined(RPSF_PACKED_CF)
-    x = pk_fma(pk_swap(o), cf{-s, s}, pk_fma(o, cf{c, c}, e));
-    y = pk_fma(e, cf{2.0f, 2.0f}, -x);
-#else
     x.x = __builtin_fmaf(-s, o.y, __builtin_fmaf(c, o.x, e.x));
     x.y = __builtin_fmaf(c, o.y, __builtin_fmaf(s, o.x, e.y));
     y.x = __builtin_fmaf(2.0f, e.x, -x.x);
     y.y = __builtin_fmaf(2.0f, e.y, -x.y);
-#endif
   }
 }
 template <int LOG, bool INV>
@@ -248,11 +197,7 @@ struct Cfg {
   // behind the K stream); two in the N = 64 plan, which is compiled for one wave per SIMD (see Launch in
   // rpsf.hip) and has the registers: 2048^2 / N=64 81 -> 71.5 us, a depth of four gives nothing more.
   static constexpr int KDEPTH = (LOGN_ == 6 && A2_ + B2_ == 0) ? 2 : 1;
-#if defined(RPSF_NOFUSE)
-  static constexpr bool FUSE_LAST = false;
-#else
   static constexpr bool FUSE_LAST = true;  // the last stage runs slot by slot around the multiplication
-#endif
   static constexpr int T = N * NC / 64;       // threads per patch
   static constexpr int LQ = A1_ + A2_, Q = 1 << LQ, M = 1 << (B1_ + B2_), G = Q * M;  // kr = q + Q*k3, kc = m + M*l3
   static constexpr int NSPEC = (Q + M) / 2;   // slots whose groups have q == 0, m == 0 or are self-paired
@@ -306,11 +251,7 @@ struct Cfg {
   static constexpr int X1_ROW = 68;  // floats per X1 row: 16-byte aligned rows (wide reads), 4*lane + c mod 64 covers every bank once
   static constexpr int X1_FLOATS = S3 ? (T / 64) * 64 * X1_ROW : 0;
   static constexpr int X2_STRIDE = S3 ? G : G + 1;
-#if defined(RPSF_ONE_PASS_SPECIAL)
-  static constexpr bool TWO_PASS_SPECIAL = false;
-#else
   static constexpr bool TWO_PASS_SPECIAL = S3 && KCH == E;  // see special_pass1 (N = 256; at N = 128 a chunk holds four slots)
-#endif
   static constexpr int X2_FLOATS = E * X2_STRIDE;
   static constexpr int LDS_FLOATS0 = X1_FLOATS > X2_FLOATS ? X1_FLOATS : X2_FLOATS;
   // Parked special slot: thread-private LDS columns scratch[(h*E + e)*PARK_STRIDE + t].  Two-stage plans are
@@ -648,21 +589,6 @@ RPSF_HD void x2_last_write(const GroupIds<C>& gids, const cf* v, float* lds) {
 struct PairOut { cf a, b; };
 // two-sided: bins p (value za) and -p (value zb); ka = K'_h(p), kb = K'_h(p + (0,N/2)); w = W_N^kc(p)
 RPSF_HD PairOut pair_op(cf za, cf zb, cf ka, cf kb, cf w) {
-#if defined(RPSF_PACKED_CF)
-  // the same algebra on register pairs, sixteen packed instructions: conj / +-i are sign patterns of the accumulations
-  const cf e2 = pk_fma(zb, cf{1.0f, -1.0f}, za);           // za + conj(zb)
-  const cf d = pk_fma(zb, cf{-1.0f, 1.0f}, za);            // za - conj(zb);  o2 = -i d
-  const cf t = cmul(d, w);                                  // w o2 = -i t
-  const cf s1 = pk_fma(pk_swap(t), cf{1.0f, -1.0f}, e2);   // e2 + w o2
-  const cf s2 = pk_fma(pk_swap(t), cf{-1.0f, 1.0f}, e2);   // e2 - w o2
-  const cf y1 = cmul(s1, ka), y2 = cmul(s2, kb);
-  const cf ep2 = y1 + y2;
-  const cf op2 = cmulc(y1 - y2, w);
-  PairOut rr;
-  rr.a = pk_fma(pk_swap(op2), cf{-1.0f, 1.0f}, ep2);       // ep + i op
-  rr.b = pk_fma(ep2, cf{1.0f, -1.0f}, pk_swap(op2));       // conj(ep) + i conj(op)
-  return rr;
-#else
   cf zbc = cconj(zb);
   cf e2 = za + zbc;
   cf o2 = mul_mi(za - zbc);
@@ -675,7 +601,6 @@ RPSF_HD PairOut pair_op(cf za, cf zb, cf ka, cf kb, cf w) {
   r.a = ep + mul_pi(op);
   r.b = cconj(ep) + mul_pi(cconj(op));
   return r;
-#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -693,17 +618,10 @@ RPSF_HD PairOut pair_op(cf za, cf zb, cf ka, cf kb, cf w) {
 template <class C, int CI>
 RPSF_HD void load_k_chunk(int t, cf* k, const cf* __restrict__ g) {
   StaticFor<0, C::KCH>::run([&]<int I>() RPSF_AI {
-#if defined(RPSF_ABL_NOK)
-    k[2 * I] = cf{1.0f + (float)I, 0.5f};
-    k[2 * I + 1] = cf{0.25f, (float)t};
-#else
     load_stream16(g + ((size_t)(CI * C::KCH + I) * C::T + t) * 2, k[2 * I], k[2 * I + 1]);
-#endif
   });
 }
-#if !defined(RPSF_KRING)
 #define RPSF_KRING 1
-#endif
 template <class C>
 struct KRing {
   static constexpr int DEPTH = C::KDEPTH > RPSF_KRING ? C::KDEPTH : RPSF_KRING;  // chunks in flight

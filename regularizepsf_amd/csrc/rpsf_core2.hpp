@@ -32,16 +32,12 @@ struct alignas(16) cf2 {
   cf a, b;
 };
 
-// LOGR_ < LOGN_ (development, RPSF_DEV_SPLIT): a patch of 2^LOGR_ rows x N columns - the work unit of the split-patch timing skeleton
-// (two 256-thread workgroups per CU, each on half a 256-pixel patch; results are wrong by design, see rpsf_kernels2.hpp).
-template <int LOGN_, int A1_, int A2_, int AL_, int B1_, int B2_, int LOGR_ = LOGN_>
+template <int LOGN_, int A1_, int A2_, int AL_, int B1_, int B2_>
 struct Cfg2 {
-  static constexpr int LOGN = LOGN_, N = 1 << LOGN_, NC = N / 2, LOGR = LOGR_, ROWS = 1 << LOGR_;
-  static constexpr bool HALF = LOGR_ != LOGN_;
-  static constexpr bool WIDE = false;  // (development, RPSF_DEV_WIDE: see Cfg256wide)
+  static constexpr int LOGN = LOGN_, N = 1 << LOGN_, NC = N / 2, LOGR = LOGN_, ROWS = N;
   static constexpr int A1 = A1_, A2 = A2_, AL = AL_, B1 = B1_, B2 = B2_, BL = 1;
   static_assert(A1_ + B1_ == 5 && A2_ + B2_ == 5, "32 values per thread, half and stage");
-  static_assert(A1_ + A2_ + AL_ == LOGR_ && B1_ + B2_ + 1 == LOGN_ - 1, "digits must cover the index");
+  static_assert(A1_ + A2_ + AL_ == LOGN_ && B1_ + B2_ + 1 == LOGN_ - 1, "digits must cover the index");
   static_assert(A1_ >= 1 && B1_ >= 1, "the top row / column bits must be stage-1 register digits (quadrants)");
   static constexpr bool S3 = true;
   static constexpr int EA = 1 << AL_, EB = 2, E = EA * EB, P = 64 / E, NSLOT = P / 2;
@@ -410,7 +406,7 @@ template <class C, int H, bool INV>
 RPSF_HD void stage1h(int t, cf* v, const cf* __restrict__ tw) {
   constexpr int NR = 1 << C::A1, NCOL = 1 << C::B1;
   ThreadPos2<C> tp(t);
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(RPSF_DEV_KEEP_TW_ADDR)
+#if defined(__HIP_DEVICE_COMPILE__)
   // The inverse stage recomputes its twiddle addresses (two integer instructions each): left to itself the compiler keeps the forward stage's fifteen
   // alive across the whole pass and spills three of them - scratch reloads in the last stage of the chain, behind the in-order vector-memory pipe.
   // (256-pixel plan: 3 spilled VGPRs / 16 B of scratch -> none, timing unchanged, profiles/r04x; the 128-pixel plan never spilled them)
@@ -667,77 +663,6 @@ RPSF_HD void freq_b(int t, const GroupIds<C>& gids, cf* v, cf* k, const cf* __re
   });
 }
 
-// Two K chunks in flight (development, RPSF_KDEPTH2; SPLIT_ROWS plans only: one slot per thread): k0 holds chunk 0 and k1 chunk 1 on entry; each later
-// chunk is requested into the buffer its predecessor-but-one has just freed, one chunk of pair words ahead of its use.
-template <class C>
-RPSF_HD void freq_b_depth2(int t, const GroupIds<C>& gids, cf* v, cf* k0, cf* k1, const cf* __restrict__ g, const cf* __restrict__ tw, const cf* park) {
-  static_assert(C::SPLIT_ROWS && C::NCHUNK == 4, "one slot, four chunks");
-#if defined(__HIP_DEVICE_COMPILE__)
-#define RPSF_PIN() __builtin_amdgcn_sched_barrier(0)  // (the scheduler otherwise sinks a chunk's loads below the pair words in front of them)
-#else
-#define RPSF_PIN() ((void)0)
-#endif
-  RPSF_PIN();
-  pair_words<C, 0, 0 * C::KCH, C::KCH>(gids, v, k0, tw);
-  RPSF_PIN();
-  load_k_chunk2<C, 2>(t, k0, g);
-  RPSF_PIN();
-  pair_words<C, 0, 1 * C::KCH, C::KCH>(gids, v, k1, tw);
-  RPSF_PIN();
-  load_k_chunk2<C, 3>(t, k1, g);
-  RPSF_PIN();
-  pair_words<C, 0, 2 * C::KCH, C::KCH>(gids, v, k0, tw);
-  pair_words<C, 0, 3 * C::KCH, C::KCH>(gids, v, k1, tw);
-  if (t < 64) self_unpark<C>(t, v, park);
-  stage3_cols<C, true, 0>(v);
-}
-
-// K staged through the exchange buffer (RPSF_KSTAGE2): the buffer is idle between the last forward and the first inverse exchange,
-// so the pair words of chunks 1 and 2 (2 x KCH words per thread: 128 KiB at N = 256) are requested by LDS-DMA as soon as the last
-// forward read is done - no registers needed for data in flight - and chunk 3 takes the registers chunk 0 frees.  One deep request
-// instead of three dependent round trips of one chunk each.  kst: the staged words, [word - KCH][thread] 16-byte units.
-template <class C>
-RPSF_HD void freq_b_staged(int t, const GroupIds<C>& gids, cf* v, cf* k, const cf* __restrict__ g, const cf* __restrict__ tw,
-                           const cf* park, const cf* kst) {
-  static_assert(C::NCHUNK == 4, "chunk 0 and 3 through registers, 1 and 2 through LDS");
-  StaticFor<0, C::NCHUNK>::run([&]<int CI>() RPSF_AI {
-    constexpr int S = CI * C::KCH / C::E, E0 = CI * C::KCH % C::E;
-    if constexpr (E0 == 0 && S > 0) {
-      stage3_rows<C, false, 0, S>(t, gids, v);
-      stage3_rows<C, false, 1, S>(t, gids, v);
-      stage3_cols<C, false, S>(v);
-    }
-    if constexpr (CI == 0 || CI == 3) {
-      pair_words<C, S, E0, C::KCH>(gids, v, k, tw);
-      if constexpr (CI == 0) {
-        load_k_chunk2<C, 3>(t, k, g);
-#if defined(__HIP_DEVICE_COMPILE__)
-        // the staged words were requested before these KCH loads and vector memory returns in order: at most KCH outstanding
-        // operations means the LDS-DMA of this wave has landed (a thread reads only words its own wave requested)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::KCH) : "memory");
-#endif
-      }
-    } else {
-      cf kk[2 * C::KCH];
-      StaticFor<0, C::KCH>::run([&]<int I>() RPSF_AI {
-        const cf2 w2 = *reinterpret_cast<const cf2*>(kst + ((size_t)((CI - 1) * C::KCH + I) * C::T + t) * 2);
-        kk[2 * I] = w2.a, kk[2 * I + 1] = w2.b;
-      });
-      pair_words<C, S, E0, C::KCH>(gids, v, kk, tw);
-    }
-    if constexpr (E0 + C::KCH == C::E) {
-      if constexpr (S == 0) {
-        if (t < 64) self_unpark<C>(t, v, park);
-      }
-      stage3_cols<C, true, S>(v);
-      if constexpr (!(C::SPLIT_ROWS && S == 0)) {
-        stage3_rows<C, true, 0, S>(t, gids, v);
-        stage3_rows<C, true, 1, S>(t, gids, v);
-      }
-    }
-  });
-}
-
 // Value of the packed K stream at (thread t, word w, side b)
 template <class C>
 RPSF_HD cf pack_value2(const cf* __restrict__ kfull, const uint16_t* __restrict__ tab, int t, int w, int b) {
@@ -785,11 +710,7 @@ RPSF_HD void load_raw2(int t, cf* v, const ImageView& im, int pr, int pc, bool f
     StaticFor<0, NR>::run([&]<int R1>() RPSF_AI {
       StaticFor<0, NCOL>::run([&]<int C1>() RPSF_AI {
         const int cp = (C1 << C::B2) + tp.c2;
-#if defined(RPSF_DEV_GATHER_NT)  // development: pixel gather with the streaming hint
-        const f32x4 q = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base + R1 * rstep + 4 * cp));
-#else
         const f32x4 q = *reinterpret_cast<const f32x4*>(base + R1 * rstep + 4 * cp);
-#endif
         v[2 * (R1 * NCOL + C1)] = cf{q.x, q.y};
         v[2 * (R1 * NCOL + C1) + 1] = cf{q.z, q.w};
       });
@@ -857,13 +778,8 @@ RPSF_HD void window_patch2(int t, cf* v, const float* __restrict__ win) {
       const f32x4 w4 = *reinterpret_cast<const f32x4*>(win + 4 * cp);
       cf& a = v[2 * (R1 * NCOL + C1)];
       cf& b = v[2 * (R1 * NCOL + C1) + 1];
-#if defined(RPSF_PACKED_CF)
-      a = a * (cf{w4.x, w4.y} * wr);
-      b = b * (cf{w4.z, w4.w} * wr);
-#else
       a = cf{a.x * (w4.x * wr), a.y * (w4.y * wr)};
       b = cf{b.x * (w4.z * wr), b.y * (w4.w * wr)};
-#endif
     });
   });
 }
@@ -915,17 +831,8 @@ RPSF_HD void store_patch2(int t, const cf* v, const OutView& pv, const OutView& 
         const float wr = win[r];
         const f32x4 w4 = *reinterpret_cast<const f32x4*>(win + 4 * cp);
         const cf a = v[2 * (R1 * NCOL + C1)], b = v[2 * (R1 * NCOL + C1) + 1];
-#if defined(RPSF_PACKED_CF)
-        const cf pa = a * (cf{w4.x, w4.y} * wr), pb = b * (cf{w4.z, w4.w} * wr);
-        f32x4 val = {pa.x, pa.y, pb.x, pb.y};
-#else
         f32x4 val = {a.x * (w4.x * wr), a.y * (w4.y * wr), b.x * (w4.z * wr), b.y * (w4.w * wr)};
-#endif
         if (!qw || quad_mode(qw[QD]) == QUAD_SIDE) {
-#if defined(RPSF_DEV_QUAD)  // timing experiment (results are wrong): the plane traffic of 2 x 2 patches whose overlaps were summed on chip -
-          // of the 16 quadrants of such a group 9 reach a plane
-          if (!(((plane == 0 ? 1 : plane == 1 ? 3 : plane == 2 ? 5 : 15) >> QD) & 1)) return;
-#endif
           pstore4(prow_t + R1 * pstep + 4 * cp, val);
         } else if (quad_mode(qw[QD]) == QUAD_DIRECT) {
           val += old[U];
@@ -986,56 +893,8 @@ RPSF_HD void store_patch2(int t, const cf* v, const OutView& pv, const OutView& 
   });
 }
 
-// Development (RPSF_DEV_CARRY, timing experiment): interior patches only.  carry: [R1][thread] 16-byte units, private to the workgroup.
-#if defined(RPSF_DEV_CARRY_AUX_LD) || defined(RPSF_DEV_CARRY)
-#if !defined(RPSF_DEV_CARRY_NT)
-#define RPSF_DEV_CARRY_NT 0
-#endif
-template <class C, class CLOAD, class PSTORE4>
-RPSF_HD void store_patch2_carry(int t, const cf* v, const OutView& pv, int plane, int pr, int pc, const float* __restrict__ win,
-                                const float* carry_in, float* carry_out, CLOAD&& cload, PSTORE4&& pstore4) {
-  ThreadPos2<C> tp(t);
-  constexpr int NR = 1 << C::A1, NCOL = 1 << C::B1;
-  static_assert(NCOL == 2, "left and right half");
-  float* prow0 = pv.out + (size_t)plane * pv.plane_stride + (size_t)(pr - pv.row0) * pv.ld + pc;
-  const f32x4* ci = reinterpret_cast<const f32x4*>(carry_in) + t;
-  f32x4* cb = reinterpret_cast<f32x4*>(carry_out) + t;
-  f32x4 cin[NR];
-  StaticFor<0, NR>::run([&]<int R1>() RPSF_AI {
-    cin[R1] = cload(ci + R1 * C::T);
-  });
-  StaticFor<0, NR>::run([&]<int R1>() RPSF_AI {
-    const int r = (R1 << (C::A2 + C::AL)) + tp.r_low, cp = (1 << C::B2) + tp.c2;
-    const float wr = win[r];
-    const f32x4 w4 = *reinterpret_cast<const f32x4*>(win + 4 * cp);
-    const cf a = v[2 * (R1 * NCOL + 1)], b = v[2 * (R1 * NCOL + 1) + 1];
-    const f32x4 val = {a.x * (w4.x * wr), a.y * (w4.y * wr), b.x * (w4.z * wr), b.y * (w4.w * wr)};
-#if RPSF_DEV_CARRY_NT & 2
-    __builtin_nontemporal_store(val, cb + R1 * C::T);
-#else
-    cb[R1 * C::T] = val;
-#endif
-  });
-  StaticFor<0, NR>::run([&]<int R1>() RPSF_AI {
-    const int r = (R1 << (C::A2 + C::AL)) + tp.r_low, cp = tp.c2;
-    const float wr = win[r];
-    const f32x4 w4 = *reinterpret_cast<const f32x4*>(win + 4 * cp);
-    const cf a = v[2 * (R1 * NCOL)], b = v[2 * (R1 * NCOL) + 1];
-    f32x4 val = {a.x * (w4.x * wr), a.y * (w4.y * wr), b.x * (w4.z * wr), b.y * (w4.w * wr)};
-    val += cin[R1];
-    pstore4(prow0 + (size_t)r * pv.ld + 4 * cp, val);
-  });
-}
-#endif
-
 // Plans compiled into the library
 using Cfg256v2 = Cfg2<8, 4, 0, 4, 1, 5>;
 using Cfg128v2 = Cfg2<7, 4, 1, 2, 1, 4>;
-using Cfg256half = Cfg2<8, 4, 0, 3, 1, 5, 7>;
-// development (RPSF_DEV_WIDE): the timing skeleton of a 1024-thread / 32-values-per-thread layout of the 256-pixel plan - four waves per SIMD
-// at 128 registers.  Thread tu and thread tu + 512 both stand in for thread tu % 512 of Cfg256v2 and each does half of its work.
-struct Cfg256wide : Cfg2<8, 4, 0, 4, 1, 5> {
-  static constexpr bool WIDE = true;
-};  // development (RPSF_DEV_SPLIT): 128 rows x 256 columns, 256 threads
 
 }  // namespace rpsf

@@ -57,36 +57,25 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const float* base) 
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
   return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((uint64_t)hi << 32) | lo), 0, -1, 0x00020000);
 }
-// Development-only timing experiments (results are wrong): RPSF_DEV_PLANE_WRAP=<bits> folds the plane offsets onto a window of
-// 2^bits floats (would planes that stay resident in the Infinity Cache be cheaper?); RPSF_DEV_PLANE_AUX overrides the cache policy.
-#if defined(RPSF_DEV_PLANE_WRAP)
-#define RPSF_PLANE_OFF(o) ((o) & ((size_t(1) << RPSF_DEV_PLANE_WRAP) - 1))
-#else
-#define RPSF_PLANE_OFF(o) (o)
-#endif
 // Cache policy of the fused mode's plane accesses.  Both are sc1 (write-through stores, L1/L2-bypassing loads: what makes them
 // visible across XCDs).  The stores are NOT marked streaming: a plane line is read by the sum a few tens of microseconds after it was
 // written, and without `nt` it is still in the Infinity Cache then; the loads ARE (each line is read once).  Measured
 // (profiles/r02av): 4096^2 0.2066 -> 0.192 ms; with nt on both, or on the stores only, or on neither: 0.207 / 0.215 / 0.212 ms;
 // 8192^2, whose planes are four times the cache, unchanged.
-#if !defined(RPSF_DEV_PLANE_AUX)
-#define RPSF_DEV_PLANE_AUX 16 /* sc1 */
-#endif
-#if !defined(RPSF_DEV_PLANE_AUX_LOAD)
-#define RPSF_DEV_PLANE_AUX_LOAD (16 | 2) /* sc1 | nt */
-#endif
+constexpr int PLANE_AUX_STORE = 16;     /* sc1 */
+constexpr int PLANE_AUX_LOAD = 16 | 2;  /* sc1 | nt */
 __device__ __forceinline__ rpsf_f4 plane_load16_wt(__amdgpu_buffer_rsrc_t r, size_t float_offset) {
-  const rpsf_i4 q = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(RPSF_PLANE_OFF(float_offset) * sizeof(float)), 0, RPSF_DEV_PLANE_AUX_LOAD);
+  const rpsf_i4 q = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(float_offset * sizeof(float)), 0, PLANE_AUX_LOAD);
   return rpsf_f4{__int_as_float(q.x), __int_as_float(q.y), __int_as_float(q.z), __int_as_float(q.w)};
 }
 template <int AUX>
 __device__ __forceinline__ void plane_store16_aux(__amdgpu_buffer_rsrc_t r, size_t float_offset, rpsf_f4 v) {
   const rpsf_i4 q = {__float_as_int(v.x), __float_as_int(v.y), __float_as_int(v.z), __float_as_int(v.w)};
-  __builtin_amdgcn_raw_buffer_store_b128(q, r, (int)(RPSF_PLANE_OFF(float_offset) * sizeof(float)), 0, AUX);
+  __builtin_amdgcn_raw_buffer_store_b128(q, r, (int)(float_offset * sizeof(float)), 0, AUX);
 }
 __device__ __forceinline__ void plane_store16_wt(__amdgpu_buffer_rsrc_t r, size_t float_offset, rpsf_f4 v) {
   const rpsf_i4 q = {__float_as_int(v.x), __float_as_int(v.y), __float_as_int(v.z), __float_as_int(v.w)};
-  __builtin_amdgcn_raw_buffer_store_b128(q, r, (int)(RPSF_PLANE_OFF(float_offset) * sizeof(float)), 0, RPSF_DEV_PLANE_AUX);
+  __builtin_amdgcn_raw_buffer_store_b128(q, r, (int)(float_offset * sizeof(float)), 0, PLANE_AUX_STORE);
 }
 
 // UN: groups in flight per thread (4 x UN sixteen-byte loads);  KNOWN_FUSED: the caller is a fused launch (the persistent kernels), so the
@@ -97,7 +86,7 @@ __device__ __forceinline__ void sum_tile(const TileSum& p0, uint32_t entry_any_l
   // The entry is the same in every lane (the whole workgroup sums one tile), but it comes out of LDS or a strided loop, so the compiler has to assume
   // otherwise - and then the tile's coverage mask is a vector value and every "is this plane present" choice of the 32 loads a v_cndmask on VCC, which
   // gfx950 issues at 23 cycles apiece (scripts/micro/valu_mix.hip, profiles/r04y).  Saying that it is uniform makes them scalar selects.
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(RPSF_DEV_SUM_VECTOR_COV)
+#if defined(__HIP_DEVICE_COMPILE__)
   const uint32_t entry = __builtin_amdgcn_readfirstlane(entry_any_lane);
 #else
   const uint32_t entry = entry_any_lane;
@@ -109,14 +98,7 @@ __device__ __forceinline__ void sum_tile(const TileSum& p0, uint32_t entry_any_l
   if (p.done) p.done += (size_t)frame * p0.n_tiles;
   const int ti = tile / p.ntj, tj = tile % p.ntj;
   const int cov_all = p.cover[tile];
-#if defined(RPSF_DEV_CARRY)  // timing experiment: two planes by lattice-row parity (results are wrong)
-  const int cov = (cov_all | (cov_all >> 1)) & 5;
-#elif defined(RPSF_DEV_QUAD)  // timing experiment: the planes a tile would be read from if 2 x 2 groups of patches were pre-summed on chip
-  const int c0_ = ((ti & 1) << 1) | (tj & 1);
-  const int cov = cov_all & ((1 << c0_) | ((tj & 1) ? 0 : 1 << (c0_ ^ 1)) | ((ti & 1) ? 0 : 1 << (c0_ ^ 2)) | (((ti | tj) & 1) ? 0 : 1 << (c0_ ^ 3)));
-#else
   const int cov = cov_all;
-#endif
   const bool fused = KNOWN_FUSED || p.done != nullptr;
   if (fused && !known_complete) {  // wait until every contributor of the tile has published its stores
     if (tid == 0) {
@@ -131,14 +113,9 @@ __device__ __forceinline__ void sum_tile(const TileSum& p0, uint32_t entry_any_l
   const bool vec = ((x0 | x1 | p.ld_planes | p.ld_out) & 3) == 0 && (p.plane_stride & 3) == 0 &&
                    ((reinterpret_cast<uintptr_t>(p.planes) | reinterpret_cast<uintptr_t>(p.out)) & 15) == 0;
   const int gw = (x1 - x0) >> 2;
-#if defined(RPSF_DEV_SUM_DIVIDE)  // development: A/B against an integer division per element
-  constexpr bool POW2 = false;
-  const bool wide_path = vec;
-#else
   // (a tile is 2^k groups of four pixels wide except where the image clips its last column to something else - those few tiles go pixel by pixel)
   constexpr bool POW2 = true;
   const bool wide_path = vec && (gw & (gw - 1)) == 0;
-#endif
   if (wide_path) {
     const __amdgpu_buffer_rsrc_t rsrc = plane_rsrc(p.planes);
     const int total = gw * (y1 - y0);
@@ -169,11 +146,7 @@ __device__ __forceinline__ void sum_tile(const TileSum& p0, uint32_t entry_any_l
 #pragma unroll
           for (int k = 0; k < 4; ++k)
             if ((cov >> k) & 1) acc += v[u][k];
-#if defined(RPSF_DEV_OUT_PLAIN)  // development: output stores of the tile sum without the streaming hint
-          *reinterpret_cast<f4*>(p.out + (size_t)(y0 + row_of(i) - p.row0) * p.ld_out + x0 + (col_of(i) << 2)) = acc;
-#else
           __builtin_nontemporal_store(acc, reinterpret_cast<f4*>(p.out + (size_t)(y0 + row_of(i) - p.row0) * p.ld_out + x0 + (col_of(i) << 2)));
-#endif
         }
       }
     }
@@ -207,13 +180,10 @@ __device__ __forceinline__ void sum_tiles_worker(const TileSum& p, int block, in
     for (int i = block; i < p.count; i += nblocks) sum_tile<UN, KNOWN_FUSED>(p, p.tiles[i], threadIdx.x, blockDim.x);
     return;
   }
-#if !defined(RPSF_DEV_SUM_BLOCKING)
   // A workgroup holds up to SUM_LOOKAHEAD drawn tiles and sums whichever of them is complete first, instead of waiting for the
   // head of the (predicted) order while later tiles are complete already - with the plane stores kept in the Infinity Cache,
   // the sooner a complete tile is summed the likelier its planes are still there.  Thread 0 keeps the list.
-#if !defined(RPSF_SUM_LOOKAHEAD)
 #define RPSF_SUM_LOOKAHEAD 4
-#endif
   constexpr int SUM_LOOKAHEAD = RPSF_SUM_LOOKAHEAD;
   __shared__ uint32_t pend[SUM_LOOKAHEAD];
   __shared__ uint32_t pick;
@@ -257,17 +227,6 @@ __device__ __forceinline__ void sum_tiles_worker(const TileSum& p, int block, in
     if (tile == 0xfffffffeu) continue;
     sum_tile<UN, KNOWN_FUSED>(p, tile, threadIdx.x, blockDim.x, true);
   }
-#else
-  __shared__ uint32_t next;
-  for (;;) {
-    if (threadIdx.x == 0) next = __hip_atomic_fetch_add(p.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.queue_base;
-    __syncthreads();
-    const uint32_t i = next;
-    __syncthreads();
-    if (i >= (uint32_t)p.count) return;
-    sum_tile<UN, KNOWN_FUSED>(p, sum_entry(p, i), threadIdx.x, blockDim.x);
-  }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -320,7 +279,6 @@ struct PatchParams {
   const uint32_t* prefetch_tiles;  // per chunk: the lattice tiles of the image in the order the chunk's patches first need them ...
   uint32_t prefetch_first[9];      // ... chunk x owns entries [prefetch_first[x], prefetch_first[x + 1])
   int head_patches;  // persistent launches: the summing workgroups at the head of the grid compute this many (0 or 1) patches before they turn to summing
-  float* carry;  // development (RPSF_DEV_CARRY): one half patch of private scratch per persistent workgroup
 };
 
 template <class C>
@@ -486,10 +444,6 @@ __global__ __launch_bounds__(Launch<C>::WG, Launch<C>::WAVES_PER_SIMD) void patc
   const int pr = dsc.x + p.origin_row, pc = dsc.y + p.origin_col;
   const cf* g = p.g + (size_t)patch * C::G_PER_PATCH;
   cf v[64];
-#if defined(RPSF_ABL_NOLOAD)
-#pragma unroll
-  for (int j = 0; j < 64; ++j) v[j] = cf{(float)(t + j), (float)(t - j)};
-#endif
   const bool fast = patch_inside<C>(pr, pc, im.H, im.W, im.row0, im.rows) && pairs_aligned(im.img, im.ld, pc);
   // twiddle and window tables live in LDS: their reads must not queue behind the patch's global loads
   cf* tw = reinterpret_cast<cf*>(smem);
@@ -502,7 +456,6 @@ __global__ __launch_bounds__(Launch<C>::WG, Launch<C>::WAVES_PER_SIMD) void patc
   for (int i = threadIdx.x; i < C::PT_WORDS; i += Launch<C>::WG) pt[i] = p.pairtab[i];
   GroupIds<C> gids;
   gids.load(p.tab, t);
-#if !defined(RPSF_ABL_NOLOAD)
   {
     int* maps = reinterpret_cast<int*>(lds);
     if (!fast) build_pad_maps<C>(t, maps, im, pr, pc);
@@ -512,7 +465,6 @@ __global__ __launch_bounds__(Launch<C>::WG, Launch<C>::WAVES_PER_SIMD) void patc
     load_patch<C>(t, v, im, pr, pc, win, fast, maps);
     lds_barrier();  // the maps share LDS with the exchange buffer
   }
-#endif
   STAMP(1);
   stage1<C, false>(t, v, tw);
   STAMP(2);
@@ -574,16 +526,6 @@ __global__ __launch_bounds__(Launch<C>::WG, Launch<C>::WAVES_PER_SIMD) void patc
   STAMP(12);
   if (active) {
     const int plane = ov.plane_stride ? dsc.w : 0;
-#if defined(RPSF_ABL_NOSTORE)
-    {  // keep every value live but store (almost) nothing
-      float acc = 0.f;
-#pragma unroll
-      for (int j = 0; j < 64; ++j) acc += v[j].x * v[j].y;
-      if (acc == 123456.789f) ov.out[threadIdx.x] = acc;
-    }
-#elif defined(RPSF_ABL_NOATOMIC)
-    store_patch<C>(t, v, ov, plane, pr, pc, win, [](float* a, float val) { *a = val; });
-#else
     if constexpr (C::S3) {
       if (p.dv.out) {
         direct_store<C>(p, t, v, ov, frame, seq, plane, pr, pc, win, reinterpret_cast<uint32_t*>(lds));
@@ -592,7 +534,6 @@ __global__ __launch_bounds__(Launch<C>::WG, Launch<C>::WAVES_PER_SIMD) void patc
       }
     }
     store_patch<C>(t, v, ov, plane, pr, pc, win, [](float* a, float val) { unsafeAtomicAdd(a, val); });
-#endif
   }
   STAMP(13);
 }
@@ -935,62 +876,6 @@ __global__ __launch_bounds__(256) void rasterize_kernel(int model, int n, const 
   for (int e = threadIdx.x; e < n * n; e += 256) dst[e] = (float)(psf_model_value(model, q, (double)(e % n), (double)(e / n)) * scale);
 }
 
-#if defined(RPSF_VGPR_CAP)
-// K5c (development builds with -DRPSF_VGPR_CAP=124 only; measured, not adopted - DESIGN.md 5.1): the plane sum as waves that run
-// BESIDE the persistent patch kernel (fused launches of the 256-pixel plan).  With the cap that kernel is
-// built at 248 registers, which leaves 16 per lane and SIMD - one more wave - and 19 KiB of LDS on every CU; a workgroup of this
-// kernel is four such waves (<= 16 registers, 16 KiB of LDS: exactly one fits beside a patch workgroup), launched on a second
-// stream, and the dispatcher places one on every CU (scripts/probe_coresidency.py).  It draws tiles from the same queue as the
-// summing workgroups of the patch launch and waits for a tile's contributors the same way; the plane values travel global -> LDS
-// by LDS-DMA (no registers for data in flight: 4 KiB per wave and pass) and are added in the fixed colour order, so the result is
-// bit-identical to every other form of the sum.  Geometry as for the fused sum: image edges and lattice origin multiples of 32 floats.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(8))) void sum_waves_kernel(TileSum p) {
-  typedef float f4 __attribute__((ext_vector_type(4)));
-  extern __shared__ __attribute__((aligned(16))) float sw_stage[];  // [wave][plane][64 lanes x 4 floats]
-  __shared__ uint32_t sw_next;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* mine = sw_stage + wave * (4 * 256);
-  for (;;) {
-    if (threadIdx.x == 0) sw_next = __hip_atomic_fetch_add(p.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.queue_base;
-    __syncthreads();
-    const uint32_t i = __builtin_amdgcn_readfirstlane(sw_next);
-    __syncthreads();
-    if (i >= (uint32_t)p.count) return;
-    const uint32_t tile = __builtin_amdgcn_readfirstlane(p.tiles[i]);
-    const int cov = __builtin_amdgcn_readfirstlane((int)p.cover[tile]);
-    if (threadIdx.x == 0) {
-      const uint32_t want = p.epoch * (uint32_t)__builtin_popcount(cov & 15);
-      while (__hip_atomic_load(p.done + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) __builtin_amdgcn_s_sleep(8);
-    }
-    __syncthreads();
-    const int ti = tile / p.ntj, tj = tile % p.ntj;
-    const int y0 = max(p.lat_r0 + ti * p.half, p.row0), y1 = min(p.lat_r0 + (ti + 1) * p.half, p.row0 + p.rows);
-    const int x0 = max(p.lat_c0 + tj * p.half, 0), x1 = min(p.lat_c0 + (tj + 1) * p.half, p.W);
-    if (y0 >= y1 || x0 >= x1) continue;
-    const int x = x0 + ((lane & 31) << 2);
-    for (int yb = y0 + 2 * wave; yb < y1; yb += 8) {  // wave-uniform trip count; lanes 0-31 take row yb, lanes 32-63 row yb + 1
-      const int y = yb + (lane >> 5);
-      const bool on = y < y1 && x < x1;
-      const uint32_t off = (uint32_t)(y - p.row0) * (uint32_t)p.ld_planes + (uint32_t)x;  // floats (the planes of a fused launch are < 4 GiB)
-      if (on) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if ((cov >> k) & 1)
-            __builtin_amdgcn_global_load_lds(p.planes + k * p.plane_stride + off, (__attribute__((address_space(3))) float*)(mine + k * 256), 16, 0,
-                                             /*sc1 | nt*/ 16 | 2);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (on) {
-        f4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if ((cov >> k) & 1) acc += *reinterpret_cast<const f4*>(mine + k * 256 + lane * 4);
-        __builtin_nontemporal_store(acc, reinterpret_cast<f4*>(p.out + (size_t)(y - p.row0) * p.ld_out + x));
-      }
-    }
-  }
-}
-#endif  // RPSF_VGPR_CAP
 
 // K4: accum[i] += src[i]
 // ------------------------------------------------------------------------------------------------

@@ -23,12 +23,39 @@ __device__ __forceinline__ f32x4 load16_sc1(const float* base, size_t span_bytes
 // Development-only timing ablations (results are wrong; never set by regularizepsf_amd/build.py):
 //   RPSF2_ABL_NOGATHER / _NOK / _NOSTORE: no pixel loads / no K loads / no output stores;
 //   RPSF2_ABL_NOLDS: no LDS exchanges (barriers stay); RPSF2_ABL_NOBAR: no workgroup barriers either;
-//   RPSF2_ABL_NOVALU: no butterflies and no pair operations.
+//   RPSF2_ABL_NOVALU: no butterflies and no pair operations;
+//   RPSF_STAMPS (+ RPSF_WAVE_STAMPS): per-phase timestamps (rpsf_kernels.hpp, STAMP).
 // (In a fused / persistent launch RPSF2_ABL_NOSTORE turns the plane stores into no-ops that keep the values live, so that the protocol runs on.)
-// Other development switches of this file, all measured in round 4 (profiles/r04*):
-//   RPSF_DEV_SPLIT / RPSF_DEV_WIDE[=2]: timing skeletons of other structures (split patch; 1024 threads per patch, lock-step or ping-pong) - k2_256s.hip;
-//   RPSF_DEV_LATE_DRAW, RPSF_DEV_DESC_AHEAD, RPSF_KDEPTH2: protocol / K-stream variants;  RPSF_DEV_SLEEP_ALL / _W0 / _REST: chain-sensitivity naps;
-//   RPSF_WAVE_STAMPS (with RPSF_STAMPS): lane 0 of every wave stamps;  RPSF_PACKED_CF (rpsf_core.hpp): hand-packed complex arithmetic.
+// Inside the kernels these are `if constexpr (dev::...)` branches - every build parses them; tests/test_cabi.py compiles the ablation
+// set so that they cannot rot.  The switches of the closed round-2 ... round-4 experiments (split / wide skeletons, carry buffers, K
+// depth, naps, packed arithmetic ...) are gone from the sources; what they measured is in DESIGN.md 5.1-5.5 and profiles/r02* ... r04*.
+namespace dev {
+#if defined(RPSF2_ABL_NOGATHER)
+constexpr bool NOGATHER = true;
+#else
+constexpr bool NOGATHER = false;
+#endif
+#if defined(RPSF2_ABL_NOK)
+constexpr bool NOK = true;
+#else
+constexpr bool NOK = false;
+#endif
+#if defined(RPSF2_ABL_NOSTORE)
+constexpr bool NOSTORE = true;
+#else
+constexpr bool NOSTORE = false;
+#endif
+#if defined(RPSF2_ABL_NOVALU)
+constexpr bool NOVALU = true;
+#else
+constexpr bool NOVALU = false;
+#endif
+#if defined(RPSF_STAMPS)
+constexpr bool STAMPS = true;
+#else
+constexpr bool STAMPS = false;
+#endif
+}  // namespace dev
 #if defined(RPSF2_ABL_NOLDS)
 #define ABL_LDS(...) ((void)0)
 #else
@@ -153,281 +180,27 @@ struct ImagePrefetch {
 // checked (hot_geometry, rpsf.hip): no float atomics, no direct mode, no pixel-by-pixel rim paths in the code (they cost the 256-pixel
 // kernel 29 spilled SGPRs and half of its 200 KB).  Everything else runs the one-patch-per-workgroup kernel patch_kernel2.
 
-#if defined(RPSF_DEV_WIDE)
-// ------------------------------------------------------------------------------------------------
-// Development: timing skeleton of a 1024-thread / 32-values-per-thread layout of the 256-pixel plan (Cfg256wide, patch_kernel2_256w):
-// 16 waves per CU, four per SIMD, 128 registers each.  Threads tu and tu + 512 both stand in for thread t = tu % 512 of Cfg256v2 and
-// each does HALF of its work with the same per-thread phase functions: the butterflies, twiddles and LDS exchanges of column parity 0
-// only (so two threads x one parity = the arithmetic and the LDS bytes of one thread x two parities), half of the pixel units, half
-// of the pair words (chunks of four words instead of eight: a quarter of the K registers), half of the stores - plus the 32 lane swaps
-// per direction that turn 16-byte global units into per-lane column parities in such a layout.  LDS holds one parity at a time
-// (128 KiB) as in the product, so the two halves of the workgroup (dup = tu / 512, wave-uniform) take turns in every exchange.
-// Same bytes, same arithmetic, same LDS traffic per patch; RESULTS ARE WRONG BY DESIGN.
-// ------------------------------------------------------------------------------------------------
-template <class C>
-__device__ __forceinline__ void wide_gather(int t, int dup, cf* v, const ImageView& im, int pr, int pc) {
-  ThreadPos2<C> tp(t);
-  // (rim patches: the skeleton reads a patch-sized block that lies inside the image)
-  const int prc = min(max(pr, im.row0), im.row0 + im.rows - C::N), pcc = min(max(pc, 0), im.W - C::N);
-  const float* base = im.img + (size_t)(prc - im.row0) * im.ld + pcc;
-  StaticFor<0, 8>::run([&]<int I>() RPSF_AI {
-    const int r = ((2 * I + dup) << (C::A2 + C::AL)) + tp.r_low;
-    StaticFor<0, 2>::run([&]<int C1>() RPSF_AI {
-      const int cp = (C1 << C::B2) + tp.c2;
-      const f32x4 q = *reinterpret_cast<const f32x4*>(base + (size_t)r * im.ld + 4 * cp);
-      v[2 * (4 * I + 2 * C1)] = cf{q.x, q.y};
-      v[2 * (4 * I + 2 * C1 + 1)] = cf{q.z, q.w};
-    });
-  });
-}
-// what re-sorting 16-byte units into per-lane column parities costs: one v_permlane32_swap per register pair
-template <class C>
-__device__ __forceinline__ void wide_swap(cf* v) {
-  StaticFor<0, 16>::run([&]<int I>() RPSF_AI {
-    auto sw = [](float& a, float& b) RPSF_AI {
-      const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-      a = __uint_as_float(r[0]), b = __uint_as_float(r[1]);
-    };
-    sw(v[2 * (2 * I)].x, v[2 * (2 * I + 1)].x);
-    sw(v[2 * (2 * I)].y, v[2 * (2 * I + 1)].y);
-  });
-}
-template <class C>
-__device__ __forceinline__ void wide_window(int t, int dup, cf* v, const float* __restrict__ win) {
-  ThreadPos2<C> tp(t);
-  StaticFor<0, 8>::run([&]<int I>() RPSF_AI {
-    const float wr = win[((2 * I + dup) << (C::A2 + C::AL)) + tp.r_low];
-    StaticFor<0, 2>::run([&]<int C1>() RPSF_AI {
-      const f32x4 w4 = *reinterpret_cast<const f32x4*>(win + 4 * ((C1 << C::B2) + tp.c2));
-      cf& a = v[2 * (4 * I + 2 * C1)];
-      cf& b = v[2 * (4 * I + 2 * C1 + 1)];
-      a = cf{a.x * (w4.x * wr), a.y * (w4.y * wr)};
-      b = cf{b.x * (w4.z * wr), b.y * (w4.w * wr)};
-    });
-  });
-}
-template <class C, class PSTORE4>
-__device__ __forceinline__ void wide_store(int t, int dup, const cf* v, const OutView& pv, int plane, int pr, int pc, const float* __restrict__ win,
-                                           PSTORE4&& pstore4) {
-  ThreadPos2<C> tp(t);
-  float* pbase = pv.out + (size_t)plane * pv.plane_stride;
-  StaticFor<0, 8>::run([&]<int I>() RPSF_AI {
-    const int r = ((2 * I + dup) << (C::A2 + C::AL)) + tp.r_low;
-    const float wr = win[r];
-    const int y = pr + r, yl = y - pv.row0;
-    const bool row_ok = y >= 0 && y < pv.H && yl >= 0 && yl < pv.rows;
-    StaticFor<0, 2>::run([&]<int C1>() RPSF_AI {
-      const int cp = (C1 << C::B2) + tp.c2, x = pc + 4 * cp;
-      if (row_ok && x >= 0 && x + 4 <= pv.W) {
-        const f32x4 w4 = *reinterpret_cast<const f32x4*>(win + 4 * cp);
-        const cf a = v[2 * (4 * I + 2 * C1)], b = v[2 * (4 * I + 2 * C1 + 1)];
-        pstore4(pbase + (size_t)yl * pv.ld + x, f32x4{a.x * (w4.x * wr), a.y * (w4.y * wr), b.x * (w4.z * wr), b.y * (w4.w * wr)});
-      }
-    });
-  });
-}
-template <class C, int CI>
-__device__ __forceinline__ void wide_load_k(int tu, cf* k, const cf* __restrict__ g) {
-  StaticFor<0, 4>::run([&]<int I>() RPSF_AI {
-#if defined(RPSF2_ABL_NOK)
-    k[2 * I] = cf{1.0f + (float)I, 0.5f};
-    k[2 * I + 1] = cf{0.25f, (float)tu};
-    return;
-#endif
-    load_stream16(g + ((size_t)(CI * 4 + I) * (2 * C::T) + tu) * 2, k[2 * I], k[2 * I + 1]);
-  });
-}
-// the transform of one patch: forward, pair words, inverse (v[2 j]: the 32 values of this thread)
-template <class C, class COUNT>
-__device__ __forceinline__ void wide_transform(int t, int tu, int dup, const GroupIds<C>& gids, cf* v, const cf* tw, cf* lds, const cf* g, COUNT&& count_previous) {
-  // ---- forward ----
-  ABL_VALU(stage1h<C, 0, false>(t, v, tw));
-  if (dup == 0) {
-    ABL_LDS(x1_write2<C, 0>(t, v, lds));
-    wave_lds_sync();
-    ABL_LDS(x1_read2<C, 0>(t, v, lds));
-  }
-  ABL_BAR();  // the X1 regions change hands
-  if (dup == 1) {
-    ABL_LDS(x1_write2<C, 0>(t, v, lds));
-    wave_lds_sync();
-    ABL_LDS(x1_read2<C, 0>(t, v, lds));
-  }
-  ABL_VALU(stage2h<C, 0, false>(t, v, tw));
-  cf k[8];
-  wide_load_k<C, 0>(tu, k, g);
-  ABL_BAR();  // every wave has left its X1 region
-  count_previous();
-  if (dup == 0) ABL_LDS(x2_mid_write2<C, 0>(t, v, lds));
-  ABL_BAR();
-  if (dup == 0) ABL_LDS(x2_last_read2<C, 0>(gids, v, lds));
-  ABL_BAR();
-  if (dup == 1) ABL_LDS(x2_mid_write2<C, 0>(t, v, lds));
-  if (dup == 0) ABL_VALU(stage3_rows<C, false, 0, 0>(t, gids, v));
-  ABL_BAR();
-  if (dup == 1) {
-    ABL_LDS(x2_last_read2<C, 0>(gids, v, lds));
-    ABL_VALU(stage3_rows<C, false, 0, 0>(t, gids, v));
-  }
-  // ---- frequency step: the 2-point column DFTs of 32 values, 16 pair words in chunks of 4 ----
-  ABL_VALU(fft_axis<1, 2, 16, 4, false, 0>(v));
-#if !defined(RPSF2_ABL_NOVALU)
-  {
-    int qa, ma;
-    gid_to_qm2<C>(gids[0], qa, ma);
-    const cf w0 = tw[ma], w1 = tw[ma + C::M];
-    StaticFor<0, 4>::run([&]<int CI>() RPSF_AI {
-      StaticFor<0, 4>::run([&]<int I>() RPSF_AI {
-        constexpr int EE = CI * 4 + I;
-        const PairOut o = pair_op(v[2 * EE], v[62 - 2 * EE], k[2 * I], k[2 * I + 1], (EE & 1) ? w1 : w0);
-        v[2 * EE] = o.a, v[62 - 2 * EE] = o.b;
-      });
-      if constexpr (CI + 1 < 4) wide_load_k<C, CI + 1>(tu, k, g);
-    });
-  }
-#else
-  StaticFor<1, 4>::run([&]<int CI>() RPSF_AI {
-    cf acc = k[0];
-    StaticFor<1, 8>::run([&]<int I>() RPSF_AI { acc = acc + k[I]; });
-    v[2 * CI] = v[2 * CI] + acc;
-    wide_load_k<C, CI>(tu, k, g);
-  });
-  v[0] = v[0] + k[0] + k[7];
-#endif
-  ABL_VALU(fft_axis<1, 2, 16, 4, true, 0>(v));
-  // ---- inverse ----
-  ABL_VALU(stage3_rows<C, true, 0, 0>(t, gids, v));
-  ABL_BAR();  // (the second half's forward reads are done)
-  if (dup == 0) ABL_LDS(x2_last_write2<C, 0>(gids, v, lds));
-  ABL_BAR();
-  if (dup == 0) ABL_LDS(x2_mid_read2<C, 0>(t, v, lds));
-  ABL_BAR();
-  if (dup == 1) ABL_LDS(x2_last_write2<C, 0>(gids, v, lds));
-  if (dup == 0) ABL_VALU(stage2h<C, 0, true>(t, v, tw));
-  ABL_BAR();
-  if (dup == 1) {
-    ABL_LDS(x2_mid_read2<C, 0>(t, v, lds));
-    ABL_VALU(stage2h<C, 0, true>(t, v, tw));
-  }
-  ABL_BAR();  // X1 regions alias the X2 image
-  if (dup == 0) {
-    ABL_LDS(x1_write2<C, 0>(t, v, lds));
-    wave_lds_sync();
-    ABL_LDS(x1_read2<C, 0>(t, v, lds));
-  }
-  ABL_BAR();
-  if (dup == 1) {
-    ABL_LDS(x1_write2<C, 0>(t, v, lds));
-    wave_lds_sync();
-    ABL_LDS(x1_read2<C, 0>(t, v, lds));
-  }
-  ABL_VALU(stage1h<C, 0, true>(t, v, tw));
-}
-
-// ... and the same work as a PING-PONG between the two halves of the workgroup (RPSF_DEV_WIDE=2): in every segment between two workgroup barriers one
-// half (8 waves, two per SIMD: the SIMD's full issue rate) runs a stage's arithmetic while the other half moves its values through LDS, then they
-// swap - arithmetic beside LDS traffic by construction, which the lock-step kernels only get where the column-parity halves leapfrog.
-template <class C, int PART>
-__device__ __forceinline__ void wide_freq(int t, int tu, const GroupIds<C>& gids, cf* v, cf* k, const cf* tw, const cf* g) {
-  if constexpr (PART == 0) {
-    ABL_VALU(stage3_rows<C, false, 0, 0>(t, gids, v));
-    ABL_VALU(fft_axis<1, 2, 16, 4, false, 0>(v));
-  }
-#if !defined(RPSF2_ABL_NOVALU)
-  int qa, ma;
-  gid_to_qm2<C>(gids[0], qa, ma);
-  const cf w0 = tw[ma], w1 = tw[ma + C::M];
-  StaticFor<2 * PART, 2 * PART + 2>::run([&]<int CI>() RPSF_AI {
-    StaticFor<0, 4>::run([&]<int I>() RPSF_AI {
-      constexpr int EE = CI * 4 + I;
-      const PairOut o = pair_op(v[2 * EE], v[62 - 2 * EE], k[2 * I], k[2 * I + 1], (EE & 1) ? w1 : w0);
-      v[2 * EE] = o.a, v[62 - 2 * EE] = o.b;
-    });
-    if constexpr (CI + 1 < 4) wide_load_k<C, CI + 1>(tu, k, g);
-  });
-#else
-  StaticFor<2 * PART, 2 * PART + 2>::run([&]<int CI>() RPSF_AI {
-    cf acc = k[0];
-    StaticFor<1, 8>::run([&]<int I>() RPSF_AI { acc = acc + k[I]; });
-    v[2 * CI] = v[2 * CI] + acc;
-    if constexpr (CI + 1 < 4) wide_load_k<C, CI + 1>(tu, k, g);
-  });
-#endif
-  if constexpr (PART == 1) {
-    ABL_VALU(fft_axis<1, 2, 16, 4, true, 0>(v));
-    ABL_VALU(stage3_rows<C, true, 0, 0>(t, gids, v));
-  }
-}
-template <class C, class COUNT>
-__device__ __forceinline__ void wide_transform_pp(int t, int tu, int dup, const GroupIds<C>& gids, cf* v, const cf* tw, cf* lds, const cf* g, COUNT&& count_previous) {
-  // ONE code path for both halves, the second half one segment behind the first: a segment is a stage's arithmetic (V) or an exchange (L), they alternate
-  // strictly - S1 | X1 | S2 | X2 | F | X2' | S2' | X1' | S1' - and every segment carries two workgroup barriers (middle and end: the X2 exchanges need the one
-  // in the middle, the others keep step), so that while one half is in an L segment the other is in the V segment next to it, and LDS holds one half at a time.
-  cf k[8];
-  if (dup == 1) { ABL_BAR(); ABL_BAR(); }
-  ABL_VALU(stage1h<C, 0, false>(t, v, tw));
-  ABL_BAR(); ABL_BAR();
-  ABL_LDS(x1_write2<C, 0>(t, v, lds));
-  ABL_BAR();
-  ABL_LDS(x1_read2<C, 0>(t, v, lds));
-  ABL_BAR();
-  ABL_VALU(stage2h<C, 0, false>(t, v, tw));
-  wide_load_k<C, 0>(tu, k, g);
-  ABL_BAR();
-  count_previous();
-  ABL_BAR();
-  ABL_LDS(x2_mid_write2<C, 0>(t, v, lds));
-  ABL_BAR();
-  ABL_LDS(x2_last_read2<C, 0>(gids, v, lds));
-  ABL_BAR();
-  wide_freq<C, 0>(t, tu, gids, v, k, tw, g);
-  ABL_BAR();
-  wide_freq<C, 1>(t, tu, gids, v, k, tw, g);
-  ABL_BAR();
-  ABL_LDS(x2_last_write2<C, 0>(gids, v, lds));
-  ABL_BAR();
-  ABL_LDS(x2_mid_read2<C, 0>(t, v, lds));
-  ABL_BAR();
-  ABL_VALU(stage2h<C, 0, true>(t, v, tw));
-  ABL_BAR(); ABL_BAR();
-  ABL_LDS(x1_write2<C, 0>(t, v, lds));
-  ABL_BAR();
-  ABL_LDS(x1_read2<C, 0>(t, v, lds));
-  ABL_BAR();
-  ABL_VALU(stage1h<C, 0, true>(t, v, tw));
-  // (the first half owes two barriers: it pays them behind its stores, which so run beside the second half's last stage - patch_body2)
-}
-#endif  // RPSF_DEV_WIDE
 
 template <class C, class REENTER, bool HOT = false, bool KNT = true, bool PLANE_NT = false>
 __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reenter) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int T = C::T, N = C::N;
   constexpr bool PERSIST = std::remove_reference_t<REENTER>::enabled;
-  // (tu: the thread's id in the workgroup - protocol duties; t: the thread of the plan it computes as - the same except in the 1024-thread skeleton)
-  const int tu = threadIdx.x;
-  const int t = C::WIDE ? (tu & (T - 1)) : tu;
-  [[maybe_unused]] const int dup = C::WIDE ? (int)__builtin_amdgcn_readfirstlane((unsigned)(tu / T)) : 0;  // (wave-uniform: a scalar branch condition)
+  const int tu = threadIdx.x, t = tu;
   // Fused plane sum: a few workgroups at the head of the grid sum finished tiles beside the patches for the whole
   // launch (the patches leave half of the HBM bandwidth unused), the ones at its tail take the CUs the partial last
   // round of patches leaves idle.  All of them draw tiles from one queue.
   // (persistent form: bit 30 of the block index says that this is a re-entry - the tables are in LDS already and the park
   // words hold the tiles of the previous patch, still to be counted)
-#if defined(RPSF_STAMPS)  // diagnostic builds: when did this pass reach the kernel's first instructions (stamp 14, through an LDS word)
-  if (threadIdx.x == 0) *reinterpret_cast<unsigned long long*>(reinterpret_cast<cf*>(smem + Launch2<C>::TABLE_FLOATS) + C::BUF_UNITS + 4) = __builtin_amdgcn_s_memrealtime();
-#endif
+  if constexpr (dev::STAMPS)  // diagnostic builds: when did this pass reach the kernel's first instructions (stamp 14, through an LDS word)
+    if (threadIdx.x == 0) *reinterpret_cast<unsigned long long*>(reinterpret_cast<cf*>(smem + Launch2<C>::TABLE_FLOATS) + C::BUF_UNITS + 4) = __builtin_amdgcn_s_memrealtime();
   // (the tile sums of the persistent kernels are compiled for "fused" - no run-time choice between two kinds of load in front of each of the 32 of a pass:
   // config 2 -2 %; in the 256-pixel kernel -1.2 % at 4096^2 and nothing at 8192^2 once the sums index by shift and mask, profiles/r04t, r04aa)
-#if defined(RPSF_DEV_SUM_RUNTIME)  // development: A/B of the tile sums with the run-time choice of plane loads left in
-  constexpr bool SUM_KNOWN_FUSED = false;
-#else
   constexpr bool SUM_KNOWN_FUSED = HOT;
-#endif
   const bool again = PERSIST && ((blockIdx.x >> 30) & 1u);
-#if defined(RPSF_STAMPS)  // ... and which workgroup this is (its block index at dispatch, kept in LDS across re-entries: stamp 15)
-  // (an unused word of the bin-pair table: bit 31 clear, so the walk of the self-paired bins ignores it; written again behind the table staging below)
-  if (threadIdx.x == 0 && !again) reinterpret_cast<uint32_t*>(smem + 3 * C::N)[Launch2<C>::OT_WORDS - 1] = blockIdx.x;
-#endif
+  if constexpr (dev::STAMPS)  // ... and which workgroup this is (its block index at dispatch, kept in LDS across re-entries: stamp 15)
+    // (an unused word of the bin-pair table: bit 31 clear, so the walk of the self-paired bins ignores it; written again behind the table staging below)
+    if (threadIdx.x == 0 && !again) reinterpret_cast<uint32_t*>(smem + 3 * C::N)[Launch2<C>::OT_WORDS - 1] = blockIdx.x;
   // (persistent form: a summing workgroup at the head of the grid has nothing to sum while the first patches are still being
   // computed - no tile is complete before a full patch period - so it computes ONE patch of its XCD's chunk first)
   const int blk = (int)(blockIdx.x & 0x3fffffffu);
@@ -435,7 +208,6 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   const int pb = head_patch ? (blk & 7) : blk - p.sum_first;                             // workgroup-uniform
   bool patchy = pb >= 0 && pb < p.patch_blocks;
   int frame = 0, xrow = 0, seq = 0;
-  [[maybe_unused]] int half = 0;  // (RPSF_DEV_SPLIT skeleton, C::HALF: a queue position is half a patch - rows [half ROWS, (half + 1) ROWS))
   if (patchy) {
     xrow = p.slot0 + (pb >> 3);
     if constexpr (PERSIST) {
@@ -454,7 +226,6 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
         xrow += p.head_patches ? p.sum_first >> 3 : 0;
       }
     }
-    if constexpr (C::HALF) half = xrow & 1, xrow >>= 1;
     if (p.n_frames > 1) {
       if (p.frame_major) {  // persistent batches of large frames: one frame after the other (its planes stay in the Infinity Cache)
         const int left = p.n_patches - (pb & 7) * p.chunk, mine = left < p.chunk ? (left > 0 ? left : 1) : p.chunk;  // slots of this XCD
@@ -473,32 +244,9 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   }
   cf* const lds = reinterpret_cast<cf*>(smem + Launch2<C>::TABLE_FLOATS);
   cf* const park = lds + C::BUF_UNITS;
-  // Split barriers (development, -DRPSF_SPLIT_BARRIERS; 256-pixel persistent kernel): where arithmetic that does not depend on the exchange sits between a
-  // wave's LDS writes and its next LDS reads, the wave ARRIVES (one LDS atomic, in order behind its writes) before that arithmetic and WAITS (polls the
-  // counter) behind it, instead of an s_barrier behind it - a wave that is slow in the arithmetic no longer holds up the others, who only need its writes.
-  // Counter k counts arrivals for ever; a generation is WAVES arrivals, and no wave can arrive for the next one before it has seen this one complete.
-#if defined(RPSF_SPLIT_BARRIERS)
-  constexpr bool SPLITB = PERSIST && C::SPLIT_ROWS && !C::WIDE && !C::HALF;
-#else
-  constexpr bool SPLITB = false;
-#endif
-  [[maybe_unused]] unsigned* const sync = reinterpret_cast<unsigned*>(park + C::PARK_UNITS);
-  [[maybe_unused]] auto arrive = [&](int k) RPSF_AI -> unsigned {
-    unsigned old = 0;
-    asm volatile("" ::: "memory");
-    if ((tu & 63) == 0) old = __hip_atomic_fetch_add(sync + k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    asm volatile("" ::: "memory");
-    return old;
-  };
-  [[maybe_unused]] auto await = [&](int k, unsigned old) RPSF_AI {
-    const unsigned target = (__builtin_amdgcn_readfirstlane(old) & ~(unsigned)(C::WAVES - 1)) + (unsigned)C::WAVES;
-    while ((int)(__builtin_amdgcn_readfirstlane(__hip_atomic_load(sync + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) - target) < 0)
-      __builtin_amdgcn_s_sleep(1);
-    asm volatile("" ::: "memory");
-  };
   // persistent form: the previous patch of this workgroup is counted on its tiles once its plane stores have drained
   [[maybe_unused]] auto count_previous = [&]() RPSF_AI {
-    if (tu < (C::HALF ? 2 : 4)) __hip_atomic_fetch_add(p.tile_done + reinterpret_cast<const unsigned*>(park)[1 + t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tu < 4) __hip_atomic_fetch_add(p.tile_done + reinterpret_cast<const unsigned*>(park)[1 + t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   if (!patchy) {
     if constexpr (PERSIST) {
@@ -508,18 +256,14 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
         count_previous();
       }
     }
-#if !defined(RPSF_DEV_NO_SIDE_JOB)  // (development: A/B of the summing loop with and without the hook)
     if constexpr (PERSIST && C::T == 512) {
       if (!again && blk < p.sum_first) {  // a head summing workgroup: the image prefetch is its side job
         ImagePrefetch<C> prefetch(p, blk, p.prefetch && p.n_frames <= 1);
-        sum_tiles_worker<ImagePrefetch<C>&, C::WIDE ? 4 : 8, SUM_KNOWN_FUSED>(p.ts, 0, 1, prefetch);
+        sum_tiles_worker<ImagePrefetch<C>&, 8, SUM_KNOWN_FUSED>(p.ts, 0, 1, prefetch);
         prefetch.finish();
         return;
       }
     }
-#endif
-    if constexpr (C::WIDE) sum_tiles_worker<NoSideJob, 4>(p.ts, 0, 1);
-    else
     sum_tiles_worker<NoSideJob, 8, SUM_KNOWN_FUSED>(p.ts, 0, 1);
     return;
   }
@@ -530,29 +274,10 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   // The slot descriptor through the scalar cache (a constant-address-space load of a uniform address): as a vector load it
   // would queue behind the plane stores of the workgroup's previous patch - VMEM returns in order - and the gather, which
   // needs the corner, would not even be issued before those stores are acknowledged.
-  // (256-pixel plan, re-entries: the previous pass of this workgroup has fetched the descriptor already and left it in LDS - words 12 ... 16 of the park
-  // area: corner, patch, plane, and the slot it belongs to + 1 -, which saves the scalar load's round trip at the head of the pass: DESC_AHEAD)
+  // (fetching it a pass ahead, into LDS, measured nothing: profiles/r04p)
   typedef const int __attribute__((address_space(4))) cint_as4;
-#if defined(RPSF_DEV_DESC_AHEAD)  // (development: measured round 4, profiles/r04p - 0.1916 vs 0.1916 ms, nothing - so it stays out of the product)
-  constexpr bool DESC_AHEAD = PERSIST && HOT && C::SPLIT_ROWS && !C::WIDE;
-#else
-  constexpr bool DESC_AHEAD = false;
-#endif
-  int4 dsc;
-  {
-    const cint_as4* dptr = (const cint_as4*)(const void*)(p.desc + (p.seq_base + seq));
-    bool have = false;
-    if constexpr (DESC_AHEAD) {
-      if (again) {
-        const int4 q = *reinterpret_cast<const int4*>(reinterpret_cast<const int*>(park) + 12);
-        const int tag = reinterpret_cast<const int*>(park)[16];
-        dsc = make_int4(__builtin_amdgcn_readfirstlane(q.x), __builtin_amdgcn_readfirstlane(q.y), __builtin_amdgcn_readfirstlane(q.z),
-                        __builtin_amdgcn_readfirstlane(q.w));
-        have = (int)__builtin_amdgcn_readfirstlane(tag) == seq + 1;  // (workgroup-uniform)
-      }
-    }
-    if (!have) dsc = make_int4(dptr[0], dptr[1], dptr[2], dptr[3]);
-  }
+  const cint_as4* dptr = (const cint_as4*)(const void*)(p.desc + (p.seq_base + seq));
+  const int4 dsc = make_int4(dptr[0], dptr[1], dptr[2], dptr[3]);
   const int patch = dsc.z;
   // Start-up stagger.  The workgroups of one round move in lock step otherwise - all CUs stream K at one moment, store at
   // another, and the memory system alternates between idle and saturated.  The first resident workgroup of each CU is
@@ -560,22 +285,18 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   if (p.stagger_ticks > 0 && pb < p.stagger_blocks && !again && !head_patch) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     // evenly spaced delays in bit-reversed order of the chunk row (profiles/r02av: -1 % against hashed delays at 12 us)
-#if defined(RPSF_DEV_STAGGER_LINEAR)  // development: delays in chunk-row order (neighbours in the queue start next to each other in time)
-    const unsigned long long wait = (unsigned long long)((unsigned)(pb >> 3) & 31u) * p.stagger_ticks >> 5;
-#else
     // (a second, longer range of delays for the workgroups that will run one patch fewer - they have a period of slack - measured worse:
     // profiles/r04h, 0.195 ... 0.203 against 0.190 ... 0.194 ms)
     const unsigned long long wait = (unsigned long long)(__brev((unsigned)pb >> 3) >> 22) * p.stagger_ticks >> 10;
-#endif
     while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
   }
   STAMP(0);
-#if defined(RPSF_STAMPS)
-  if (threadIdx.x == 0) p.stamps[(size_t)patch * 16 + 14] = *reinterpret_cast<const unsigned long long*>(reinterpret_cast<cf*>(smem + Launch2<C>::TABLE_FLOATS) + C::BUF_UNITS + 4);
-  if (threadIdx.x == 0) p.stamps[(size_t)patch * 16 + 15] = 1 + (again ? reinterpret_cast<const uint32_t*>(smem + 3 * C::N)[Launch2<C>::OT_WORDS - 1] : blockIdx.x);
-#endif
-  const int pr = dsc.x + p.origin_row + (C::HALF ? half * C::ROWS : 0), pc = dsc.y + p.origin_col;
-  const int kpatch = C::HALF ? 2 * patch + half : patch;  // (skeleton: the two halves share the patch's K bytes between them)
+  if constexpr (dev::STAMPS) {
+    if (threadIdx.x == 0) p.stamps[(size_t)patch * 16 + 14] = *reinterpret_cast<const unsigned long long*>(reinterpret_cast<cf*>(smem + Launch2<C>::TABLE_FLOATS) + C::BUF_UNITS + 4);
+    if (threadIdx.x == 0) p.stamps[(size_t)patch * 16 + 15] = 1 + (again ? reinterpret_cast<const uint32_t*>(smem + 3 * C::N)[Launch2<C>::OT_WORDS - 1] : blockIdx.x);
+  }
+  const int pr = dsc.x + p.origin_row, pc = dsc.y + p.origin_col;
+  const int kpatch = patch;
   const cf* g = p.g + (size_t)kpatch * C::G_PER_PATCH;
   cf* tw = reinterpret_cast<cf*>(smem);
   float* win = smem + 2 * N;
@@ -597,40 +318,25 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   const bool fast = patch_inside2<C>(pr, pc, im.H, im.W, im.row0, im.rows) && quads_aligned(im.img, im.ld, pc);
   int* maps = reinterpret_cast<int*>(lds);
   if (!fast) {
-#if defined(RPSF_DEV_NO_END_BARRIER)  // (the maps overlay wave 0's X1 region, which a pass that ended without a barrier may still be reading)
-    if (PERSIST && again) lds_barrier();
-#endif
     build_pad_maps<C>(t, maps, im, pr, pc);
     lds_barrier();
   }
-#if defined(RPSF2_ABL_NOGATHER)
+  if constexpr (dev::NOGATHER) {
 #pragma unroll
-  for (int j = 0; j < 64; ++j) v[j] = cf{(float)(t + j), (float)(t - j)};
-#else
-#if defined(RPSF_DEV_WIDE)
-  if constexpr (C::WIDE) wide_gather<C>(t, dup, v, im, pr, pc);
-  else
-#endif
-  load_raw2<C, HOT>(t, v, im, pr, pc, fast, maps);
-#endif
+    for (int j = 0; j < 64; ++j) v[j] = cf{(float)(t + j), (float)(t - j)};
+  } else {
+    load_raw2<C, HOT>(t, v, im, pr, pc, fast, maps);
+  }
   if (!again) {
-    if constexpr (SPLITB) {
-      if (tu < 8) sync[tu] = 0;
-    }
     if (t < N) tw[t] = tw0, win[t] = wn0;
     if (t + T < N) tw[t + T] = tw1, win[t + T] = wn1;
     if (t < Launch2<C>::OT_WORDS) ot[t] = ot0;
   }
   // tables staged; the maps (which share LDS with the exchange buffer) are no longer needed.  (A re-entered pass over an interior patch has
   // neither to wait for: its first LDS operations are wave-local, and the previous pass ended with a barrier.)
-#if defined(RPSF_DEV_X1_BARRIERS)  // development: A/B against the ten-barrier pass of rounds 2-4
-  lds_barrier();
-#else
   if (!(PERSIST && again && fast)) lds_barrier();  // (workgroup-uniform)
-#endif
-#if defined(RPSF_DEV_CARRY) || defined(RPSF_STAMPS)  // the workgroup's block index at dispatch, kept in an unused word of the bin-pair table
-  if (PERSIST && !again && t == 0) ot[Launch2<C>::OT_WORDS - 1] = blockIdx.x & 0x3fffffffu;
-#endif
+  if constexpr (dev::STAMPS)  // the workgroup's block index at dispatch, kept in an unused word of the bin-pair table
+    if (PERSIST && !again && t == 0) ot[Launch2<C>::OT_WORDS - 1] = blockIdx.x & 0x3fffffffu;
   // Persistent launches: the next slot of this XCD's chunk (xq counters are never reset: this launch owns the positions from xq_base[xcd]
   // on, position 0 = slot 0) and the tile this lane will count the patch on.
   // 256-pixel plan (EARLY_DRAW): REQUESTED right after the frequency step and PUT INTO LDS IN FRONT OF THE PLANE STORES, a whole inverse
@@ -638,28 +344,11 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   // as until round 4, the values cost a drain: the stores sit in divergent branches (interior / rim paths), the compiler cannot count them,
   // so the wait in front of the use was `s_waitcnt vmcnt(0)` - wave 0 waited for the acknowledgement of its 32 write-through stores, and
   // the seven other waves for wave 0 at the barrier behind it (the "No drain here" below was not true of the code object).
-#if defined(RPSF_DEV_LATE_DRAW)  // development: A/B
-  constexpr bool EARLY_DRAW = false;
-#else
-  constexpr bool EARLY_DRAW = PERSIST && C::SPLIT_ROWS && !C::WIDE;
-#endif
+  constexpr bool EARLY_DRAW = PERSIST && C::SPLIT_ROWS;
   // (the 128-pixel plan, MID_DRAW: requested behind the last barrier of the inverse exchange - across its slot-by-slot frequency step the two values cost 44
   // spilled registers - and put into LDS in front of the stores all the same: configs 2 / 5 -0.7 % / -0.5 %, profiles/r04r)
-#if defined(RPSF_DEV_LATE_DRAW)
-  constexpr bool MID_DRAW = false;
-#else
-  constexpr bool MID_DRAW = PERSIST && !EARLY_DRAW && !C::WIDE && !C::HALF;
-#endif
-  // (development, -DRPSF_DEV_NO_END_BARRIER: the pass ends without a barrier - the park words are in LDS before the last barrier of the inverse exchange -
-  // so that from there to the first exchange barrier of the next pass every wave runs on its own)
-#if defined(RPSF_DEV_NO_END_BARRIER)
-  constexpr bool END_BARRIER = !EARLY_DRAW;
-#else
-  constexpr bool END_BARRIER = true;
-#endif
+  constexpr bool MID_DRAW = PERSIST && !EARLY_DRAW;
   unsigned drawn = 0, qword = 0;  // (one register each: lane tu < 4 holds the word of its own tile)
-  [[maybe_unused]] int4 ndsc = make_int4(0, 0, 0, 0);  // DESC_AHEAD: the next slot's descriptor (wave 0, scalar) and the slot it belongs to + 1
-  [[maybe_unused]] int ntag = 0;
   // (Tried on top of it, round 4, profiles/r04o: every wave reads the drawn position behind the last barrier of the inverse exchange, fetches the next
   // slot's descriptor and touches one dword of each of the next patch's 2048 lines, a transform stage ahead of its gather - new frames 0.2095 -> 0.204 ms,
   // but the repeated frame of the headline loop 0.1916 -> 0.200: the descriptor's scalar load sits on the chain right behind a barrier.  The opt-in
@@ -667,37 +356,14 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   [[maybe_unused]] auto draw_next = [&]() RPSF_AI {
     if constexpr (PERSIST) {
       if (HOT || p.tile_done) {
-        if (tu < (C::HALF ? 2 : 4)) qword = reinterpret_cast<const uint32_t*>(p.quads + (p.seq_base + seq))[C::HALF ? 2 * half + tu : tu];
+        if (tu < 4) qword = reinterpret_cast<const uint32_t*>(p.quads + (p.seq_base + seq))[tu];
         if (tu == 0 && !head_patch)
           drawn = __hip_atomic_fetch_add(p.xq + (pb & 7) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.xq_base[pb & 7] +
                   (p.head_patches ? (unsigned)(p.sum_first >> 3) : 0u);
       }
     }
   };
-#if defined(RPSF_DEV_WIDE)
-  if constexpr (C::WIDE) {
-    ABL_VALU(wide_swap<C>(v));
-    wide_window<C>(t, dup, v, win);
-    STAMP(1);
-#if RPSF_DEV_WIDE >= 2
-    wide_transform_pp<C>(t, tu, dup, gids, v, tw, lds, g, [&]() RPSF_AI {
-#else
-    wide_transform<C>(t, tu, dup, gids, v, tw, lds, g, [&]() RPSF_AI {
-#endif
-      if constexpr (PERSIST) {
-        if (again) count_previous();
-      }
-    });
-    ABL_VALU(wide_swap<C>(v));
-    STAMP(9);
-  }
-#endif
-  if constexpr (!C::WIDE) {
   window_patch2<C>(t, v, win);
-#if defined(RPSF_DEV_SKEW)  // development: the second wave of every SIMD (waves w and w + WAVES/2 share one) starts the barrier-free stage-1 / X1 region late,
-                            // so that its butterflies fall under its partner's LDS bursts instead of competing with its butterflies
-  if (C::WAVES >= 2 && t >= C::T / 2) __builtin_amdgcn_s_sleep(RPSF_DEV_SKEW);
-#endif
   STAMP(1);
   // ---- forward: the halves leapfrog through stage 1, X1 (wave-local) and stage 2 ----
   ABL_VALU(stage1h<C, 0, false>(t, v, tw));
@@ -705,6 +371,7 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   ABL_VALU(stage1h<C, 1, false>(t, v, tw));
   wave_lds_sync();
   ABL_LDS(x1_read2<C, 0>(t, v, lds));
+  asm volatile("" ::: "memory");  // (compiler-only: the hardware keeps a wave's DS operations in order, the optimiser must too - other lanes of the wave read what this lane writes)
   ABL_LDS(x1_write2<C, 1>(t, v, lds));  // (a wave's DS operations complete in order: these writes cannot overtake the reads)
   STAMP(2);
   ABL_VALU(stage2h<C, 0, false>(t, v, tw));
@@ -712,12 +379,12 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   ABL_LDS(x1_read2<C, 1>(t, v, lds));
   STAMP(3);
   cf k[2 * C::KCH];
-#if defined(RPSF2_ABL_NOK)
+  if constexpr (dev::NOK) {
 #pragma unroll
-  for (int j = 0; j < 2 * C::KCH; ++j) k[j] = cf{1.0f + j, 0.5f * t};
-#else
-  load_k_chunk2<C, 0, KNT>(t, k, g);  // in flight across the exchange below (raw barriers do not drain VMEM)
-#endif
+    for (int j = 0; j < 2 * C::KCH; ++j) k[j] = cf{1.0f + j, 0.5f * t};
+  } else {
+    load_k_chunk2<C, 0, KNT>(t, k, g);  // in flight across the exchange below (raw barriers do not drain VMEM)
+  }
   cf ko[2 * C::ORBIT_ROUNDS];
   if (t < 64) {
     const cf* gs = p.gs + (size_t)kpatch * C::GS_PER_PATCH;
@@ -725,15 +392,9 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   }
   // No barrier between X1 and X2: a wave's X1 region IS its own two planes of the X2 image (Cfg2::X1_OWN_ROWS), which only its own
   // x2_mid_write2 touches - its DS operations complete in order.
-#if defined(RPSF_DEV_X1_BARRIERS)
-  ABL_BAR();
-#endif
+  asm volatile("" ::: "memory");  // (compiler-only: the hardware keeps a wave's DS operations in order, the optimiser must too - other lanes of the wave read what this lane writes)
   ABL_LDS(x2_mid_write2<C, 0>(t, v, lds));
-  [[maybe_unused]] unsigned arrived = 0;
-  if constexpr (SPLITB) arrived = arrive(2);
   ABL_VALU(stage2h<C, 1, false>(t, v, tw));
-  if constexpr (SPLITB) await(2, arrived);
-  else
   ABL_BARI(2);
   if constexpr (PERSIST) {
     // every wave has its pixels, so - VMEM returns in order - the plane stores of the workgroup's previous patch, issued
@@ -743,23 +404,10 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   ABL_LDS(x2_last_read2<C, 0>(gids, v, lds));
   ABL_BARI(3);
   ABL_LDS(x2_mid_write2<C, 1>(t, v, lds));
-  if constexpr (SPLITB) arrived = arrive(4);
   if constexpr (C::SPLIT_ROWS) ABL_VALU(stage3_rows<C, false, 0, 0>(t, gids, v));  // the row DFTs of the half that has arrived, under the exchange of the other
-  if constexpr (SPLITB) await(4, arrived);
-  else
   ABL_BARI(4);
   ABL_LDS(x2_last_read2<C, 1>(gids, v, lds));
   // no barrier: every X2 unit is read by exactly one thread, the same one that rewrites it below
-#if defined(RPSF_KSTAGE2)
-  ABL_BAR();  // ... unless the buffer takes the pair words of chunks 1 and 2 meanwhile (freq_b_staged): every read of the exchange is done
-  {
-    const int wave0 = t & ~63;
-    StaticFor<0, 2 * C::KCH>::run([&]<int I>() RPSF_AI {
-      __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(g + ((size_t)(C::KCH + I) * C::T + t) * 2),
-                                       (__attribute__((address_space(3))) float*)(lds + ((size_t)I * C::T + wave0) * 2), 16, 0, /*nt*/ 2);
-    });
-  }
-#endif
   STAMP(4);
   // ---- frequency step ----
   if constexpr (C::SPLIT_ROWS) ABL_VALU(stage3_rows<C, false, 1, 0>(t, gids, v));
@@ -770,55 +418,27 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
     wave_lds_sync();
   }
   STAMP(5);
-#if defined(RPSF2_ABL_NOVALU)
-  StaticFor<1, C::NCHUNK>::run([&]<int CI>() RPSF_AI {  // keep the K stream: every chunk is requested and consumed
-    cf acc = k[0];
-    StaticFor<1, 2 * C::KCH>::run([&]<int I>() RPSF_AI { acc = acc + k[I]; });
-    v[CI] = v[CI] + acc;
-    load_k_chunk2<C, CI>(t, k, g);
-  });
-  v[0] = v[0] + k[0] + k[15];
-#else
-#if defined(RPSF_KSTAGE2)
-  freq_b_staged<C>(t, gids, v, k, g, tw, park, lds);
-  ABL_BAR();  // every staged word has been used: the inverse exchange may overwrite the buffer
-#elif defined(RPSF_KDEPTH2)  // development: two chunks of pair words in flight from here on (requested any earlier, the allocator spills 56 registers)
-  cf k1[2 * C::KCH];
-  load_k_chunk2<C, 1>(t, k1, g);
-  freq_b_depth2<C>(t, gids, v, k, k1, g, tw, park);
-#else
-  freq_b<C, KNT>(t, gids, v, k, g, tw, park);
-#endif
-#endif
+  if constexpr (dev::NOVALU) {
+    StaticFor<1, C::NCHUNK>::run([&]<int CI>() RPSF_AI {  // keep the K stream: every chunk is requested and consumed
+      cf acc = k[0];
+      StaticFor<1, 2 * C::KCH>::run([&]<int I>() RPSF_AI { acc = acc + k[I]; });
+      v[CI] = v[CI] + acc;
+      load_k_chunk2<C, CI>(t, k, g);
+    });
+    v[0] = v[0] + k[0] + k[15];
+  } else {
+    freq_b<C, KNT>(t, gids, v, k, g, tw, park);
+  }
   if constexpr (C::SPLIT_ROWS) ABL_VALU(stage3_rows<C, true, 0, 0>(t, gids, v));
   STAMP(6);
-#if defined(RPSF_DEV_SLEEP_ALL)  // development, sensitivity of the apply to the length of a patch's chain: every wave / only wave 0 / all but wave 0 naps here (units of 64 cycles)
-  __builtin_amdgcn_s_sleep(RPSF_DEV_SLEEP_ALL);
-#endif
-#if defined(RPSF_DEV_SLEEP_W0)
-  if (t < 64) __builtin_amdgcn_s_sleep(RPSF_DEV_SLEEP_W0);
-#endif
-#if defined(RPSF_DEV_SLEEP_REST)
-  if (t >= 64) __builtin_amdgcn_s_sleep(RPSF_DEV_SLEEP_REST);
-#endif
-#if defined(RPSF_DEV_SLEEP_W13)  // waves 1-3 only (the first wave of SIMDs 1-3)
-  if (t >= 64 && t < 256) __builtin_amdgcn_s_sleep(RPSF_DEV_SLEEP_W13);
-#endif
-#if defined(RPSF_DEV_SLEEP_W47)  // waves 4-7 only (the second wave of every SIMD)
-  if (t >= 256) __builtin_amdgcn_s_sleep(RPSF_DEV_SLEEP_W47);
-#endif
   if constexpr (EARLY_DRAW) draw_next();
   // ---- inverse ----
   ABL_LDS(x2_last_write2<C, 0>(gids, v, lds));
-  if constexpr (SPLITB) arrived = arrive(5);
   if constexpr (C::SPLIT_ROWS) ABL_VALU(stage3_rows<C, true, 1, 0>(t, gids, v));
-  if constexpr (SPLITB) await(5, arrived);
-  else
   ABL_BARI(5);
   ABL_LDS(x2_mid_read2<C, 0>(t, v, lds));
   ABL_BARI(6);
   ABL_LDS(x2_last_write2<C, 1>(gids, v, lds));
-  if constexpr (SPLITB) arrived = arrive(7);
   ABL_VALU(stage2h<C, 0, true>(t, v, tw));
   // (park: idle since the frequency step; the previous pass's words were read by count_previous long ago)
   auto park_draw = [&]() RPSF_AI {
@@ -827,39 +447,18 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
       if (tu < 4) reinterpret_cast<unsigned*>(park)[1 + tu] = (unsigned)frame * p.n_tiles + quad_tile(qword);  // (this frame's counters)
     }
   };
-  if constexpr (EARLY_DRAW && !END_BARRIER) park_draw();  // in front of the LAST barrier of the pass: every wave may read the words behind it
-  if constexpr (SPLITB) await(7, arrived);
-  else
   ABL_BARI(7);
   ABL_LDS(x2_mid_read2<C, 1>(t, v, lds));
-  if constexpr (EARLY_DRAW && END_BARRIER) park_draw();
+  if constexpr (EARLY_DRAW) park_draw();
   // (no barrier: the wave's X1 region is the planes it has just read, see above)
-#if defined(RPSF_DEV_X1_BARRIERS)
-  ABL_BAR();
-#endif
   if constexpr (MID_DRAW) draw_next();
-  // DESC_AHEAD: wave 0 knows the drawn position (its lane 0 holds it) and fetches the next slot's descriptor through the scalar cache now; the
-  // value is first touched in front of the stores, a stage and a half later (a use right here would put the load's round trip on the chain).
-  if constexpr (DESC_AHEAD && EARLY_DRAW) {
-    if (tu < 64 && p.n_frames <= 1 && !head_patch) {
-      const int nx0 = (int)__builtin_amdgcn_readfirstlane(drawn);
-      const int left0 = p.n_patches - (pb & 7) * p.chunk;
-      if (nx0 >= 0 && nx0 < (left0 < p.chunk ? left0 : p.chunk)) {
-        const int nseq = (pb & 7) * p.chunk + nx0;
-        const cint_as4* nd = (const cint_as4*)(const void*)(p.desc + (p.seq_base + nseq));
-        ndsc = make_int4(nd[0], nd[1], nd[2], nd[3]);
-        ntag = nseq + 1;
-      }
-    }
-  }
-#if defined(RPSF_DEV_SKEW)
-  if (C::WAVES >= 2 && t >= C::T / 2) __builtin_amdgcn_s_sleep(RPSF_DEV_SKEW);
-#endif
   STAMP(7);
+  asm volatile("" ::: "memory");  // (compiler-only: the hardware keeps a wave's DS operations in order, the optimiser must too - other lanes of the wave read what this lane writes)
   ABL_LDS(x1_write2<C, 0>(t, v, lds));
   ABL_VALU(stage2h<C, 1, true>(t, v, tw));
   wave_lds_sync();
   ABL_LDS(x1_read2<C, 0>(t, v, lds));
+  asm volatile("" ::: "memory");  // (compiler-only: the hardware keeps a wave's DS operations in order, the optimiser must too - other lanes of the wave read what this lane writes)
   ABL_LDS(x1_write2<C, 1>(t, v, lds));
   STAMP(8);
   ABL_VALU(stage1h<C, 0, true>(t, v, tw));
@@ -867,24 +466,19 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
   ABL_LDS(x1_read2<C, 1>(t, v, lds));
   ABL_VALU(stage1h<C, 1, true>(t, v, tw));
   STAMP(9);
-  }  // !C::WIDE
   // ---- overlap-add ----
-#if defined(RPSF2_ABL_NOSTORE)
-  if (!p.tile_done) {  // keep every value live but store (almost) nothing
-    float acc = 0.f;
+  if constexpr (dev::NOSTORE) {
+    if (!p.tile_done) {  // keep every value live but store (almost) nothing
+      float acc = 0.f;
 #pragma unroll
-    for (int j = 0; j < 64; ++j) acc += v[j].x * v[j].y;
-    if (acc == 123456.789f) ov.out[threadIdx.x] = acc;
-    return;
-  }  // (fused / persistent launches keep their protocol: the plane stores below become no-ops that keep the values live)
-#endif
+      for (int j = 0; j < 64; ++j) acc += v[j].x * v[j].y;
+      if (acc == 123456.789f) ov.out[threadIdx.x] = acc;
+      return;
+    }  // (fused / persistent launches keep their protocol: the plane stores below become no-ops that keep the values live)
+  }
   const int plane = HOT || ov.plane_stride ? dsc.w : 0;
   auto add = [](float* a, float val) { unsafeAtomicAdd(a, val); };
-#if defined(RPSF_DEV_PSTORE_PLAIN)  // development: plane stores of the non-fused path without the streaming hint
-  auto pstore4 = [](float* a, f32x4 val) RPSF_AI { *reinterpret_cast<f32x4*>(a) = val; };
-#else
   auto pstore4 = [](float* a, f32x4 val) RPSF_AI { __builtin_nontemporal_store(val, reinterpret_cast<f32x4*>(a)); };
-#endif
   auto pstore1 = [](float* a, float val) RPSF_AI { *a = val; };
   if (!HOT && p.dv.out) {  // direct overlap-add (opt-in; moves as many bytes as the planes do and waits on top - DESIGN.md)
     OutView dv = p.dv;
@@ -911,69 +505,16 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
       if (tu == 0) *reinterpret_cast<unsigned*>(park) = drawn;
       if (tu < 4) reinterpret_cast<unsigned*>(park)[1 + tu] = (unsigned)frame * p.n_tiles + quad_tile(qword);
     }
-    if constexpr (DESC_AHEAD && EARLY_DRAW) {
-      if (tu == 0) {
-        *reinterpret_cast<int4*>(reinterpret_cast<int*>(park) + 12) = ndsc;
-        reinterpret_cast<int*>(park)[16] = ntag;
-      }
-    }
-#if defined(RPSF_DEV_CARRY)
-    // timing experiment (results are wrong): the right half of every patch goes to the workgroup's private carry buffer, what the
-    // previous patch left there is added to the left half, and only that reaches a colour plane (two planes, by lattice-row parity)
-    if (PERSIST && patch_inside2<C>(pr, pc, ov.H, ov.W, ov.row0, ov.rows) && quads_aligned(ov.out, ov.ld, pc)) {
-#if RPSF_DEV_CARRY >= 2  // ring of hand-off buffers per XCD chunk: queue position q writes slot q % 64 and reads slot (q - 1) % 64 - what the
-                         // workgroup that drew the previous position (a neighbour on the same XCD, a moment ago) wrote (no flags: timing only)
-      float* const cw = p.carry + (size_t)((pb & 7) * 64 + (xrow & 63)) * (C::T * 64);
-      float* const cr = p.carry + (size_t)((pb & 7) * 64 + ((xrow + 63) & 63)) * (C::T * 64);
-#else
-      float* const cw = p.carry + (size_t)ot[Launch2<C>::OT_WORDS - 1] * (C::T * 64);
-      float* const cr = cw;
-#endif
-      const __amdgpu_buffer_rsrc_t crs = plane_rsrc(p.carry);
-      const float* const cbase = p.carry;
-      store_patch2_carry<C>(t, v, ov, plane & 2, pr, pc, win, cr, cw,
-                            [=](const f32x4* a) RPSF_AI {
-#if RPSF_DEV_CARRY_NT & 4  // L1-bypassing (agent-scope) loads: what a hand-off from another workgroup needs
-                              typedef int i32x4 __attribute__((ext_vector_type(4)));
-                              const i32x4 q = __builtin_amdgcn_raw_buffer_load_b128(crs, (int)((reinterpret_cast<const float*>(a) - cbase) * sizeof(float)), 0, /*sc1*/ 16);
-                              return f32x4{__int_as_float(q.x), __int_as_float(q.y), __int_as_float(q.z), __int_as_float(q.w)};
-#elif RPSF_DEV_CARRY_NT & 1
-                              return __builtin_nontemporal_load(a);
-#else
-                              return *a;
-#endif
-                            },
-                            [=](float* a, f32x4 val) RPSF_AI { plane_store16_wt(rsrc, (size_t)(a - pbase), val); });
-    } else
-#endif
-#if defined(RPSF_DEV_WIDE)
-    if constexpr (C::WIDE)
-      wide_store<C>(t, dup, v, ov, plane, pr, pc, win,
-#if defined(RPSF2_ABL_NOSTORE)
-                    [=](float* a, f32x4 val) RPSF_AI { asm volatile("" ::"v"(val.x), "v"(val.y), "v"(val.z), "v"(val.w), "v"(a)); });
-#else
-                    [=](float* a, f32x4 val) RPSF_AI { plane_store16_wt(rsrc, (size_t)(a - pbase), val); });
-#endif
-    else
-#endif
     store_patch2<C, HOT>(
         t, v, ov, ov, plane, pr, pc, win, nullptr, add, []<int R1, int C1>(const float* a) RPSF_AI { return *reinterpret_cast<const f32x4*>(a); },
         [](const float* a) { return *a; },
-#if defined(RPSF2_ABL_NOSTORE)
-        [=](float* a, f32x4 val) RPSF_AI { asm volatile("" ::"v"(val.x), "v"(val.y), "v"(val.z), "v"(val.w), "v"(a)); },
-#else
         [=](float* a, f32x4 val) RPSF_AI {
           // (PLANE_NT: the instantiation for batches of frames side by side, whose planes are live all at once - see rpsf.hip, plane_nt)
-          if constexpr (PLANE_NT) plane_store16_aux<16 | 2>(rsrc, (size_t)(a - pbase), val);
+          if constexpr (dev::NOSTORE) asm volatile("" ::"v"(val.x), "v"(val.y), "v"(val.z), "v"(val.w), "v"(a));
+          else if constexpr (PLANE_NT) plane_store16_aux<16 | 2>(rsrc, (size_t)(a - pbase), val);
           else plane_store16_wt(rsrc, (size_t)(a - pbase), val);
         },
-#endif
         [](float* a, float val) RPSF_AI { __hip_atomic_store(reinterpret_cast<unsigned*>(a), __float_as_uint(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); });
-#if defined(RPSF_DEV_WIDE) && RPSF_DEV_WIDE >= 2
-    if constexpr (C::WIDE) {
-      if (dup == 0) { ABL_BAR(); ABL_BAR(); }
-    }
-#endif
     STAMP(10);
     if constexpr (PERSIST) {
       // No drain here: the next patch's loads queue behind these stores anyway, and the patch is counted on its tiles from
@@ -982,12 +523,12 @@ __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reen
         if (tu == 0) *reinterpret_cast<unsigned*>(park) = drawn;  // (park: idle since the frequency step)
         if (tu < 4) reinterpret_cast<unsigned*>(park)[1 + tu] = (unsigned)frame * p.n_tiles + quad_tile(qword);  // (this frame's counters)
       }
-      if constexpr (END_BARRIER) lds_barrier();
+      lds_barrier();
       STAMP(12);
       const unsigned nx = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const unsigned*>(park));
       const int left = p.n_patches - (pb & 7) * p.chunk;  // slots of this XCD's chunk that hold a patch (x frames: queue positions)
       // ... or, once the chunk is exhausted, a block index behind the patches: the workgroup sums tiles with the others
-      const bool more = (int)nx < (left < p.chunk ? left : p.chunk) * (p.n_frames > 1 ? p.n_frames : 1) * (C::HALF ? 2 : 1);
+      const bool more = (int)nx < (left < p.chunk ? left : p.chunk) * (p.n_frames > 1 ? p.n_frames : 1);
       // (a head summing workgroup has had its patch: it re-enters under its own block index and sums from now on)
       reenter(0x40000000u | (head_patch ? (unsigned)blk : (unsigned)p.sum_first + (more ? ((nx << 3) | (unsigned)(pb & 7)) : (unsigned)p.patch_blocks)),
               (unsigned)tu);
@@ -1014,11 +555,7 @@ __global__ __launch_bounds__(Launch2<C>::WG, 2) void patch_kernel2(PatchParams p
 // the persistent form of the 256-pixel plan (instantiated in k2_256p.hip)
 // (RPSF_VGPR_CAP: development builds that leave registers for co-resident waves of another kernel; the attribute counts the
 // unified register file in halves, so 124 caps the kernel at 248)
-#if defined(RPSF_VGPR_CAP)
-#define RPSF_VGPR_ATTR __attribute__((amdgpu_num_vgpr(RPSF_VGPR_CAP)))
-#else
 #define RPSF_VGPR_ATTR
-#endif
 extern "C" __global__ __launch_bounds__(512, 2) RPSF_VGPR_ATTR void patch_kernel2_256p(PatchParams p);
 // ... and of the 128-pixel plan (k2_128p.hip): four 128-thread workgroups per CU hide the dispatch of one another, but only
 // persistent ones keep the phase offsets of the start-up stagger
@@ -1030,14 +567,6 @@ extern "C" __global__ __launch_bounds__(128, 2) void patch_kernel2_128pc(PatchPa
 // ... and with streaming plane stores on top (k2_128pcs.hip), for batches of frames side by side whose planes - live all at once - exceed the Infinity Cache:
 // 8 x 2048^2 0.3244 -> 0.3096 ms; 2 ... 4 frames, single frames of any size and the 256-pixel plan lose 2 ... 8 % with them (profiles/r04bd)
 extern "C" __global__ __launch_bounds__(128, 2) void patch_kernel2_128pcs(PatchParams p);
-#if defined(RPSF_DEV_SPLIT)
-// Development: the split-patch timing skeleton (k2_256s.hip) - half patches (128 rows x 256 columns) on 256-thread workgroups, two per CU,
-// the same phases, K bytes, LDS traffic and plane stores per pixel as patch_kernel2_256p; results are wrong by design.
-extern "C" __global__ __launch_bounds__(256, 2) void patch_kernel2_256s(PatchParams p);
-#endif
-#if defined(RPSF_DEV_WIDE)
-extern "C" __global__ __launch_bounds__(1024, 4) void patch_kernel2_256w(PatchParams p);  // the 1024-thread timing skeleton (k2_256s.hip)
-#endif
 template <class C>
 struct PersistentKernel2;
 template <>

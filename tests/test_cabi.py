@@ -96,3 +96,26 @@ def test_saturation_fill_matches_the_reference_loop():
         assert np.array_equal(np.isnan(got), np.isnan(expect)), width
         ok = ~np.isnan(expect)
         assert np.allclose(got[ok], expect[ok], rtol=1e-13, atol=0), width
+
+
+def test_development_switches_still_compile(tmp_path):
+    """The timing ablations and phase stamps that stay in the kernel sources (RPSF2_ABL_*, RPSF_STAMPS / RPSF_WAVE_STAMPS; `if constexpr
+    (dev::...)` branches in rpsf_kernels2.hpp) are never set by the product build: compile the persistent kernels with all of them, so
+    that an edit of the hot path cannot silently rot them.  (No GPU needed: hipcc cross-compiles.)"""
+    import shutil
+    import subprocess
+
+    from regularizepsf_amd import build as hip_build
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    sets = {
+        "k2_256p.hip": ["-DRPSF_STAMPS", "-DRPSF_WAVE_STAMPS", "-DRPSF2_ABL_NOGATHER", "-DRPSF2_ABL_NOK", "-DRPSF2_ABL_NOSTORE",
+                        "-DRPSF2_ABL_NOVALU", "-DRPSF2_ABL_NOLDS", "-DRPSF2_ABL_NOBAR"],
+        "k2_128p.hip": ["-DRPSF_STAMPS", "-DRPSF2_ABL_NOBAR_MASK=20"],
+    }
+    for source, defines in sets.items():
+        out = tmp_path / (source + ".o")
+        done = subprocess.run([hipcc, *hip_build.FLAGS, *defines, "-c", str(hip_build.CSRC / source), "-o", str(out)],
+                              capture_output=True, text=True)
+        assert done.returncode == 0, done.stderr[-2000:]
+        assert out.stat().st_size > 0

@@ -1072,3 +1072,36 @@ def test_every_form_of_the_128_pixel_persistent_kernel():
     finally:
         del os.environ["RPSF_PLANE_NT"]
     assert np.array_equal(streamed, outs["1"][1])
+
+
+@pytest.mark.timeout(900, method="thread")
+def test_two_persistent_128_pixel_batches_on_two_streams():
+    """Forward progress with the 128-pixel plan's largest head: from 4096 patch-frames on a persistent launch carries 160 head summing
+    workgroups (sum_first_for, rpsf.hip) that hold CU slots without progress of their own.  Two such launches (two plans, two streams:
+    4 x 2048^2 frames each, 4356 patch-frames) in flight at once, 40 rounds: every round the same bits, frame 0 against the oracle."""
+    from regularizepsf_amd import _native
+
+    h = w = 2048
+    n, frames = 128, 4
+    coords, k = orc.synthetic_transfer(h, w, n, alpha=3.0, epsilon=0.1)
+    geom = _native.Geometry.whole(h, w, _native.PAD_MODES["symmetric"])
+    stacks = [np.stack([orc.starfield(h, w, 40 + 10 * j + f) for f in range(frames)]) for j in range(2)]
+    plans, bufs = [], []
+    for j in range(2):
+        plan = _native.Plan(n, coords)
+        plan.set_transfer(k)
+        plans.append(plan)
+        bufs.append((_native.DeviceBuffer(stacks[j].nbytes).upload(stacks[j]), _native.DeviceBuffer(stacks[j].nbytes)))
+    first = [None, None]
+    for _ in range(4):
+        for _ in range(10):
+            for j in range(2):
+                plans[j].apply_batch_device(bufs[j][0].ptr, bufs[j][1].ptr, frames, h * w, h * w, geom)
+        plans[0].synchronize()
+        for j in range(2):
+            got = bufs[j][1].download((frames, h, w))
+            if first[j] is None:
+                first[j] = got
+            assert np.array_equal(got, first[j]), j
+    ref = orc.apply_transfer(stacks[1][0], coords, k, workers=-1)
+    assert np.abs(first[1][0] - ref).max() <= TOL * np.abs(ref).max()
