@@ -381,12 +381,97 @@ def run_batch(args, rank, world, device, comm):
     emit_json(line)
 
 
+def run_construct(args, device):
+    """`--config construct`: the transfer-array build at the headline sizes (1089 patches of 256 x 256; ArrayPSF(device=) x 2 ->
+    ArrayPSFTransform.construct, regularizepsf/psf.py:216-219 and transform.py:78-82), every stage timed by itself (best of `--steps`
+    runs, wall clock between device synchronisations; every stage is hundreds of microseconds or more) and priced on its algorithmic
+    bytes.  The rocprofv3 kernel rows of the same command are under profiles/."""
+    from oracle import regpsf_oracle as orc
+    from regularizepsf_amd import _native
+
+    h, w, n, _ = CONFIGS[3]
+    coords = [tuple(int(v) for v in t) for t in orc.calculate_covering((h, w), n)]
+    count, per = len(coords), n * n
+    rng = np.random.default_rng(3)
+    src = np.stack([orc.coma_psf(n, r, c, h, w) for r, c in coords]).astype(np.float32)
+    tgt = np.broadcast_to(orc.gaussian_psf(n, 1.8).astype(np.float32), src.shape).copy()
+    lib = _native.lib()
+    reps = max(3, min(args.steps, 10))
+
+    def best(fn):
+        times = []
+        for _ in range(reps):
+            _native.check(lib.rpsf_device_synchronize(device))
+            t0 = time.perf_counter()
+            fn()
+            _native.check(lib.rpsf_device_synchronize(device))
+            times.append(1e3 * (time.perf_counter() - t0))
+        return min(times)
+
+    s_dev = _native.psf_fft_device(src, device)
+    t_dev = _native.psf_fft_device(tgt, device)
+    k_dev = _native.DeviceBuffer(count * per * 8, device)
+    plan = _native.Plan(n, coords, device)
+    full_b, packed_b = count * per * 8, None
+    ms_fft_host = best(lambda: _native.psf_fft_device(src, device).free())
+    ms_k2 = best(lambda: _native.check(lib.rpsf_build_transfer_device(device, count * per, s_dev.ptr, t_dev.ptr, 0, 3.0, 0.1, k_dev.ptr, None)))
+    ms_pack = best(lambda: plan.set_transfer_device(k_dev.ptr))
+    packed_b = plan.transfer_bytes
+    ms_fused = best(lambda: plan.set_transfer_spectra_device(s_dev.ptr, t_dev.ptr, 3.0, 0.1))
+    params = np.zeros((count, _native.MODEL_PARAMS))
+    params[:, 0], params[:, 1], params[:, 2], params[:, 3], params[:, 4] = 1.0, n / 2, n / 2, 1.5, 1.9
+    ms_model = best(lambda: [b.free() for b in _native.psf_model_fft_device("elliptical_gaussian", n, params, True, device) if b is not None])
+    # parity of K2 (SURVEY 8a-4 / 8d): the GPU's K against the oracle's construct on the SAME complex64 spectra (NumPy evaluates complex64 input in
+    # float32, as the reference does for float32 PSFs), first 64 patches: identical non-finite bins (float32 spectra of smooth PSFs are exactly 0 in the
+    # (N/2, N/2) bin, 0 / 0 = NaN there on both sides), max|K_gpu - K_ref| <= 1e-5 max|K_ref| on the rest
+    _native.check(lib.rpsf_build_transfer_device(device, count * per, s_dev.ptr, t_dev.ptr, 0, 3.0, 0.1, k_dev.ptr, None))
+    k_gpu = k_dev.download((count, n, n), np.complex64)[:64]
+    s64 = s_dev.download((count, n, n), np.complex64)[:64]
+    t64 = t_dev.download((count, n, n), np.complex64)[:64]
+    with np.errstate(all="ignore"):
+        k_ref = orc.construct_transfer(s64, t64, 3.0, 0.1)
+    finite = np.isfinite(k_ref)
+    same_pattern = bool(np.array_equal(np.isfinite(k_gpu), finite))
+    k_err = float(np.abs(k_gpu[finite] - k_ref[finite]).max() / np.abs(k_ref[finite]).max())
+    def gbs(nbytes, ms):
+        return round(nbytes / (ms * 1e-3) / 1e9, 1)
+
+    fused_bytes = 2 * full_b + packed_b
+    cus, name = _native.device_info(device)
+    line = {
+        "metric": "transfer-array build (ArrayPSFTransform.construct on device-resident spectra): milliseconds + fraction of HBM roofline, 1089 patches of 256x256",
+        "value": round(ms_fused, 4), "unit": "ms", "n_gpus": 1, "steps": reps, "warmup": 0, "ms_per_step": round(ms_fused, 4),
+        "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{count} patches of {n}x{n}: coma PSF grid -> Gaussian target, alpha=3 eps=0.1; spectra resident in HBM (complex64), packed folded K out",
+                   "patch": n, "patches": count, "device": name, "compute_units": cus},
+        "roofline": {"bound": "hbm", "achieved": gbs(fused_bytes, ms_fused), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(gbs(fused_bytes, ms_fused) / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "pack_spectra_kernel2",
+                     "algorithmic_bytes": int(fused_bytes),
+                     "bytes_model": "source and target spectra read once (2 x n N^2 x 8 B) + packed folded K written once (n N (N/2+1) x 8 B)"},
+        "stages": {
+            "construct_one_pass_ms": round(ms_fused, 4),
+            "construct_two_pass_ms": round(ms_k2 + ms_pack, 4),
+            "k2_build_transfer": {"ms": round(ms_k2, 4), "bytes": 3 * full_b, "gb_per_s": gbs(3 * full_b, ms_k2), "frac": round(gbs(3 * full_b, ms_k2) / HBM_PEAK_GBS, 4)},
+            "pack_kernel2": {"ms": round(ms_pack, 4), "bytes": full_b + packed_b, "gb_per_s": gbs(full_b + packed_b, ms_pack),
+                             "frac": round(gbs(full_b + packed_b, ms_pack) / HBM_PEAK_GBS, 4)},
+            "k3_psf_fft_from_host_samples": {"ms": round(ms_fft_host, 4), "what": "ArrayPSF(device=): float32 samples over PCIe (pageable) + spectrum kernel, spectra stay on the device",
+                                             "h2d_bytes": int(src.nbytes), "spectra_bytes": full_b},
+            "k6_k3_model_to_spectra": {"ms": round(ms_model, 4), "what": "rasterise an elliptical Gaussian per patch on the device (float64 evaluation) + spectrum kernel; parameters only cross PCIe",
+                                       "bytes": count * per * 4 + full_b},
+        },
+        "parity": {"k_max_rel": float(f"{k_err:.3e}"), "bound": 1e-5, "non_finite_bins": int((~finite).sum()), "non_finite_pattern_identical": same_pattern,
+                   "against": "the oracle's construct (NumPy, float32 arithmetic for complex64 input like the reference) on the same complex64 spectra, first 64 patches "
+                              "(SURVEY 8d: max|K_gpu - K_ref| <= 1e-5 max|K_ref| over the finite bins)"},
+    }
+    emit_json(line)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", type=int, default=None, choices=sorted(CONFIGS),
+    ap.add_argument("--config", default=None, choices=[str(c) for c in sorted(CONFIGS)] + ["construct"],
                     help="default: 3 (BASELINE headline) on one GPU, 4 (one 8192^2 frame, row bands, strong scaling) on several")
     ap.add_argument("--weak", action="store_true", help="N > 1: grow the image with the ranks instead of cutting one frame")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -441,6 +526,12 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         args.gpus = world
+    if args.config == "construct":
+        from regularizepsf_amd import _native as _n
+
+        return run_construct(args, local_rank % max(1, _n.device_count()))
+    if args.config is not None:
+        args.config = int(args.config)
     if args.config is None:
         args.config = 3 if world == 1 or args.weak else 4
     if args.verify is None:

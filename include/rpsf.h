@@ -67,6 +67,11 @@ void rpsf_plan_destroy(rpsf_plan* plan);
 int rpsf_plan_set_transfer(rpsf_plan* plan, const float* k_c64_host);
 /* Same, from a device-resident full K (e.g. produced by rpsf_build_transfer_device). */
 int rpsf_plan_set_transfer_device(rpsf_plan* plan, const void* k_c64_device);
+/* The same from the two PSF spectra K is built from (ArrayPSFTransform.construct, transform.py:78-82; complex64 (n_patches, N, N) each, on
+ * the plan's device, e.g. left there by rpsf_psf_fft_device): the formula is evaluated where the packer reads K, so the full K is never
+ * written or read back - 2 x n N^2 x 8 B in, the packed n N (N/2 + 1) x 8 B out, bit-identical to rpsf_build_transfer_device followed by
+ * rpsf_plan_set_transfer_device. */
+int rpsf_plan_set_transfer_spectra_device(rpsf_plan* plan, const void* s_c64_dev, const void* t_c64_dev, double alpha, double epsilon);
 /* Overlap-add strategy (transform.py:167-169).  0 = automatic: on a regular half-overlap lattice of
  * corners (calculate_covering output) patches of equal lattice parity never overlap, so each patch
  * stores into one of four colour planes with plain coalesced stores and the planes are summed in a

@@ -55,6 +55,7 @@ _PROTOTYPES = {
     "rpsf_plan_destroy": (None, [c_void_p]),
     "rpsf_plan_set_transfer": (c_int, [c_void_p, c_void_p]),
     "rpsf_plan_set_transfer_device": (c_int, [c_void_p, c_void_p]),
+    "rpsf_plan_set_transfer_spectra_device": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_double]),
     "rpsf_plan_transfer_bytes": (c_int, [c_void_p, POINTER(c_size_t)]),
     "rpsf_plan_set_overlap_mode": (c_int, [c_void_p, c_int]),
     "rpsf_plan_set_stagger": (c_int, [c_void_p, c_int]),
@@ -213,6 +214,10 @@ class Plan:
 
     def set_transfer_device(self, ptr: c_void_p) -> None:
         check(lib().rpsf_plan_set_transfer_device(self._handle, ptr))
+
+    def set_transfer_spectra_device(self, s_ptr: c_void_p, t_ptr: c_void_p, alpha: float, epsilon: float) -> None:
+        """Packed K straight from the two device-resident PSF spectra (construct and pack in one pass; the full K is never materialised)."""
+        check(lib().rpsf_plan_set_transfer_spectra_device(self._handle, s_ptr, t_ptr, float(alpha), float(epsilon)))
 
     def set_overlap_mode(self, mode: str) -> None:
         """'auto' (on lattices: 'direct' for 128/256-pixel patches, 'planes' for smaller ones; 'atomic' otherwise),

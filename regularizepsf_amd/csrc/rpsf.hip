@@ -816,6 +816,40 @@ extern "C" int rpsf_plan_set_transfer_device(rpsf_plan* p, const void* k_dev) {
   return RPSF_OK;
 }
 
+// construct -> pack in one pass (transform.py:78-82 evaluated where the packer reads K): complex64 spectra of the plan's patches on its device
+extern "C" int rpsf_plan_set_transfer_spectra_device(rpsf_plan* p, const void* s_c64_dev, const void* t_c64_dev, double alpha, double epsilon) {
+  if (!p || !s_c64_dev || !t_c64_dev) return fail(RPSF_E_BADARG, "null argument");
+  if (p->parent) return fail(RPSF_E_STATE, "a view shares its parent's transfer kernel");
+  HIP_TRY(hipSetDevice(p->device));
+  const cf* s = reinterpret_cast<const cf*>(s_c64_dev);
+  const cf* t = reinterpret_cast<const cf*>(t_c64_dev);
+  int rc = RPSF_OK;
+  if (p->generic) {  // the fallback multiplies by the caller's unfolded K: K2 straight into the plan's copy
+    rc = rpsf_build_transfer_device(p->device, (size_t)p->N * p->N * p->n_patches, s, t, 0, alpha, epsilon, p->d_kfull, p->stream);
+  } else if (p->v2) {
+    rc = dispatch_v2(p->N, [&]<class C>() -> int {
+      const size_t total = ((size_t)C::G_PER_PATCH + C::GS_PER_PATCH) * p->n_patches;
+      pack_spectra_kernel2<C><<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, p->stream>>>(s, t, (float)alpha, (float)epsilon, p->n_patches,
+                                                                                                 p->d_tab, p->d_pairtab, p->d_g, p->d_gs);
+      HIP_TRY(hipGetLastError());
+      return RPSF_OK;
+    });
+  } else {
+    rc = dispatch_n(p->N, [&]<class C>() -> int {
+      const size_t total = (size_t)C::G_PER_PATCH * p->n_patches;
+      pack_spectra_kernel<C><<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, p->stream>>>(s, t, (float)alpha, (float)epsilon, p->n_patches,
+                                                                                                p->d_tab, p->d_pairtab, p->d_g, p->d_gs);
+      HIP_TRY(hipGetLastError());
+      return RPSF_OK;
+    });
+  }
+  if (rc != RPSF_OK) return rc;
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  p->have_k = true;
+  for (rpsf_plan* band : p->bands) band->have_k = true;
+  return RPSF_OK;
+}
+
 extern "C" int rpsf_plan_transfer_bytes(const rpsf_plan* p, size_t* bytes) {
   if (!p || !bytes) return fail(RPSF_E_BADARG, "null argument");
   *bytes = (p->g_elems + p->gs_elems) * sizeof(cf);

@@ -817,18 +817,23 @@ RPSF_HD void freq_step(int t, const GroupIds<C>& gids, cf* v, KRing<C>& r, const
 
 // Value of the packed K arrays at (thread t, register rho).  kfull = one patch of the caller's
 // transfer kernel, N x N complex64 (IndexedCube values, transform.py:164).  which = 0: g, 1: gs.
-template <class C>
-RPSF_HD cf kh_at(const cf* __restrict__ kfull, int kr, int kc) {
-  cf a = kfull[kr * C::N + kc];
-  cf b = kfull[((C::N - kr) & (C::N - 1)) * C::N + ((C::N - kc) & (C::N - 1))];
+// (KF: where K comes from - the caller's full array, or a functor that evaluates transform.py:78-82 from the two PSF spectra on the fly, so that
+// construct -> pack never writes or reads the full K: rpsf_kernels.hpp, KFromSpectra)
+RPSF_HD cf k_at(const cf* k, int i) { return k[i]; }
+template <class F>
+RPSF_HD cf k_at(const F& f, int i) { return f(i); }
+template <class C, class KF>
+RPSF_HD cf kh_at(const KF& kfull, int kr, int kc) {
+  cf a = k_at(kfull, kr * C::N + kc);
+  cf b = k_at(kfull, ((C::N - kr) & (C::N - 1)) * C::N + ((C::N - kc) & (C::N - 1)));
   return cf{(a.x + b.x) * (0.5f * C::SCALE), (a.y - b.y) * (0.5f * C::SCALE)};
 }
 template <class C>
 RPSF_HD bool slot_is_special(int s, int t) {
   return (t & ~(C::WAVE - 1)) < C::spec_t(s);
 }
-template <class C>
-RPSF_HD cf pack_value(const cf* __restrict__ kfull, const uint16_t* __restrict__ tab, const uint32_t* __restrict__ pt, int t,
+template <class C, class KF>
+RPSF_HD cf pack_value(const KF& kfull, const uint16_t* __restrict__ tab, const uint32_t* __restrict__ pt, int t,
                       int rho, int which) {
   // rho = 2*w + b, w = word index in the thread's stream;  which = 0: g, 1: gs (special-format slots of
   // three-stage plans only).  See the layout comment above load_k_chunk.

@@ -664,8 +664,8 @@ RPSF_HD void freq_b(int t, const GroupIds<C>& gids, cf* v, cf* k, const cf* __re
 }
 
 // Value of the packed K stream at (thread t, word w, side b)
-template <class C>
-RPSF_HD cf pack_value2(const cf* __restrict__ kfull, const uint16_t* __restrict__ tab, int t, int w, int b) {
+template <class C, class KF>
+RPSF_HD cf pack_value2(const KF& kfull, const uint16_t* __restrict__ tab, int t, int w, int b) {
   const int s = w / C::E, e = w % C::E;
   int q, m;
   gid_to_qm2<C>(tab[(t * C::NSLOT + s) * 2], q, m);
@@ -673,8 +673,8 @@ RPSF_HD cf pack_value2(const cf* __restrict__ kfull, const uint16_t* __restrict_
   return kh_at<C>(kfull, kr, b ? kc + C::NC : kc);
 }
 // ... and of the side array of the self-paired bin pairs (entry i of the orbit table)
-template <class C>
-RPSF_HD cf pack_orbit2(const cf* __restrict__ kfull, const uint16_t* __restrict__ tab, const uint32_t* __restrict__ ot, int i, int b) {
+template <class C, class KF>
+RPSF_HD cf pack_orbit2(const KF& kfull, const uint16_t* __restrict__ tab, const uint32_t* __restrict__ ot, int i, int b) {
   const uint32_t ent = ot[i];
   if (!(ent >> 31)) return cf{0.f, 0.f};
   const int x1 = ent & 0xff, t = x1 / (2 * C::E), member = (x1 / C::E) & 1, e = x1 % C::E;

@@ -21,14 +21,18 @@ using namespace rpsf;
 #define RPSF_DECL_V1(C)                                                                                        \
   extern template __global__ void patch_kernel<C>(PatchParams);                                                \
   extern template __global__ void pack_kernel<C>(const cf*, int, const uint16_t*, const uint32_t*, cf*, cf*);  \
+  extern template __global__ void pack_spectra_kernel<C>(const cf*, const cf*, float, float, int, const uint16_t*, const uint32_t*, cf*, cf*); \
   extern template __global__ void psf_fft_kernel<C>(const float*, int, const uint16_t*, const cf*, cf*);
 #define RPSF_DECL_V2(C)                                           \
   extern template __global__ void patch_kernel2<C>(PatchParams); \
-  extern template __global__ void pack_kernel2<C>(const cf*, int, const uint16_t*, const uint32_t*, cf*, cf*);
+  extern template __global__ void pack_kernel2<C>(const cf*, int, const uint16_t*, const uint32_t*, cf*, cf*); \
+  extern template __global__ void pack_spectra_kernel2<C>(const cf*, const cf*, float, float, int, const uint16_t*, const uint32_t*, cf*, cf*);
 #define RPSF_INST_V1(C)                                                                                \
   template __global__ void patch_kernel<C>(PatchParams);                                               \
   template __global__ void pack_kernel<C>(const cf*, int, const uint16_t*, const uint32_t*, cf*, cf*); \
+  template __global__ void pack_spectra_kernel<C>(const cf*, const cf*, float, float, int, const uint16_t*, const uint32_t*, cf*, cf*); \
   template __global__ void psf_fft_kernel<C>(const float*, int, const uint16_t*, const cf*, cf*);
 #define RPSF_INST_V2(C)                                    \
   template __global__ void patch_kernel2<C>(PatchParams); \
-  template __global__ void pack_kernel2<C>(const cf*, int, const uint16_t*, const uint32_t*, cf*, cf*);
+  template __global__ void pack_kernel2<C>(const cf*, int, const uint16_t*, const uint32_t*, cf*, cf*); \
+  template __global__ void pack_spectra_kernel2<C>(const cf*, const cf*, float, float, int, const uint16_t*, const uint32_t*, cf*, cf*);

@@ -539,6 +539,68 @@ __global__ __launch_bounds__(Launch<C>::WG, Launch<C>::WAVES_PER_SIMD) void patc
 }
 
 // ------------------------------------------------------------------------------------------------
+// K2: transform.py:78-82.  Mirrors NumPy's evaluation order: |.| by hypot, scalar powers with
+// NumPy's fast paths (0, 1, 2, 0.5, -1), complex * real as a full complex product with (r, 0),
+// complex / real as NumPy's scaled division, then a plain complex product with T.
+// ------------------------------------------------------------------------------------------------
+template <class R>
+__device__ __forceinline__ R np_pow(R x, R e) {
+  if (e == R(0)) return R(1);
+  if (e == R(1)) return x;
+  if (e == R(2)) return x * x;
+  if (e == R(0.5)) return sqrt(x);
+  if (e == R(-1)) return R(1) / x;
+  return pow(x, e);
+}
+
+template <class R>
+__device__ __forceinline__ void transfer_value(R sr, R si, R tr, R ti, R alpha, R eps, R& kr, R& ki) {
+#pragma clang fp contract(off)  // (NumPy rounds every product; and the value must not depend on which kernel this is inlined into: K2 and the one-pass packers)
+  R sabs = hypot(sr, si), tabs = hypot(tr, ti);
+  R pw = np_pow(sabs, alpha - R(1));
+  // conj(S) * (pw + 0i)
+  R cr = sr, ci = -si;
+  R nr = cr * pw - ci * R(0), ni = cr * R(0) + ci * pw;
+  R den = np_pow(sabs, alpha + R(1)) + np_pow(eps * tabs, alpha + R(1));
+  // (nr + i ni) / (den + 0i), NumPy's algorithm for |re| >= |im|
+  R qr, qi;
+  if (fabs(den) == R(0)) {
+    qr = nr / fabs(den);
+    qi = ni / fabs(den);
+  } else {
+    R rat = R(0) / den;
+    R scl = R(1) / (den + R(0) * rat);
+    qr = (nr + ni * rat) * scl;
+    qi = (ni - nr * rat) * scl;
+  }
+  kr = qr * tr - qi * ti;
+  ki = qr * ti + qi * tr;
+}
+
+template <class R>
+__global__ void build_transfer_kernel(const R* __restrict__ s, const R* __restrict__ t, R* __restrict__ k,
+                                      size_t count, R alpha, R eps) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  transfer_value<R>(s[2 * i], s[2 * i + 1], t[2 * i], t[2 * i + 1], alpha, eps, k[2 * i], k[2 * i + 1]);
+}
+
+// One patch of K evaluated from the two PSF spectra where the packers ask for it (complex64 spectra, float32 arithmetic: the very operations of
+// build_transfer_kernel<float>, so the packed K is bit-identical to K2 followed by the pack kernel): `construct` on device-resident spectra goes
+// spectra -> packed K in ONE pass - 2 x n N^2 x 8 B read, n N (N/2 + 1) x 8 B written - instead of writing the full K (n N^2 x 8 B) and reading it back.
+struct KFromSpectra {
+  const cf* s;
+  const cf* t;
+  float alpha, eps;
+  __device__ __forceinline__ cf operator()(int i) const {
+    const cf a = s[i], b = t[i];
+    cf k;
+    transfer_value<float>(a.x, a.y, b.x, b.y, alpha, eps, k.x, k.y);
+    return k;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
 // K-pack
 // ------------------------------------------------------------------------------------------------
 template <class C>
@@ -552,6 +614,27 @@ __global__ void pack_kernel(const cf* __restrict__ kfull, int n_patches, const u
   int b = rem & 1, t = (rem >> 1) % C::T, i = (rem >> 1) / C::T;
   int rho = 2 * i + b;
   const cf* kf = kfull + (size_t)patch * C::N * C::N;
+  g[idx] = pack_value<C>(kf, tab, pt, t, rho, 0);
+  if constexpr (!C::INLINE_GS) {
+    const int w = rho >> 1, s = w / C::E, e = w % C::E;
+    if (slot_is_special<C>(s, t))
+      gs[(size_t)patch * C::GS_PER_PATCH + (size_t)C::spec_prefix(s) * 2 * C::E + ((size_t)e * C::spec_t(s) + t) * 2 + b] =
+          pack_value<C>(kf, tab, pt, t, rho, 1);
+  }
+}
+
+// The same packer fed from the two PSF spectra (see KFromSpectra)
+template <class C>
+__global__ void pack_spectra_kernel(const cf* __restrict__ s_fft, const cf* __restrict__ t_fft, float alpha, float eps, int n_patches,
+                                    const uint16_t* __restrict__ tab, const uint32_t* __restrict__ pt, cf* __restrict__ g, cf* __restrict__ gs) {
+  const size_t per = (size_t)C::G_PER_PATCH;
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= per * n_patches) return;
+  int patch = (int)(idx / per);
+  int rem = (int)(idx % per);
+  int b = rem & 1, t = (rem >> 1) % C::T, i = (rem >> 1) / C::T;
+  int rho = 2 * i + b;
+  const KFromSpectra kf{s_fft + (size_t)patch * C::N * C::N, t_fft + (size_t)patch * C::N * C::N, alpha, eps};
   g[idx] = pack_value<C>(kf, tab, pt, t, rho, 0);
   if constexpr (!C::INLINE_GS) {
     const int w = rho >> 1, s = w / C::E, e = w % C::E;
@@ -794,48 +877,6 @@ __global__ __launch_bounds__(256) void fixup_kernel(FixParams p) {
       *o = acc;
     }
   }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K2: transform.py:78-82.  Mirrors NumPy's evaluation order: |.| by hypot, scalar powers with
-// NumPy's fast paths (0, 1, 2, 0.5, -1), complex * real as a full complex product with (r, 0),
-// complex / real as NumPy's scaled division, then a plain complex product with T.
-// ------------------------------------------------------------------------------------------------
-template <class R>
-__device__ __forceinline__ R np_pow(R x, R e) {
-  if (e == R(0)) return R(1);
-  if (e == R(1)) return x;
-  if (e == R(2)) return x * x;
-  if (e == R(0.5)) return sqrt(x);
-  if (e == R(-1)) return R(1) / x;
-  return pow(x, e);
-}
-
-template <class R>
-__global__ void build_transfer_kernel(const R* __restrict__ s, const R* __restrict__ t, R* __restrict__ k,
-                                      size_t count, R alpha, R eps) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  R sr = s[2 * i], si = s[2 * i + 1], tr = t[2 * i], ti = t[2 * i + 1];
-  R sabs = hypot(sr, si), tabs = hypot(tr, ti);
-  R pw = np_pow(sabs, alpha - R(1));
-  // conj(S) * (pw + 0i)
-  R cr = sr, ci = -si;
-  R nr = cr * pw - ci * R(0), ni = cr * R(0) + ci * pw;
-  R den = np_pow(sabs, alpha + R(1)) + np_pow(eps * tabs, alpha + R(1));
-  // (nr + i ni) / (den + 0i), NumPy's algorithm for |re| >= |im|
-  R qr, qi;
-  if (fabs(den) == R(0)) {
-    qr = nr / fabs(den);
-    qi = ni / fabs(den);
-  } else {
-    R rat = R(0) / den;
-    R scl = R(1) / (den + R(0) * rat);
-    qr = (nr + ni * rat) * scl;
-    qi = (ni - nr * rat) * scl;
-  }
-  k[2 * i] = qr * tr - qi * ti;
-  k[2 * i + 1] = qr * ti + qi * tr;
 }
 
 // ------------------------------------------------------------------------------------------------

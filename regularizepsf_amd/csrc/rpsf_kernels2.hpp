@@ -181,6 +181,11 @@ struct ImagePrefetch {
 // kernel 29 spilled SGPRs and half of its 200 KB).  Everything else runs the one-patch-per-workgroup kernel patch_kernel2.
 
 
+// The second-generation packer fed from the two PSF spectra (KFromSpectra, rpsf_kernels.hpp)
+template <class C>
+__global__ void pack_spectra_kernel2(const cf* __restrict__ s_fft, const cf* __restrict__ t_fft, float alpha, float eps, int n_patches,
+                                     const uint16_t* __restrict__ tab, const uint32_t* __restrict__ ot, cf* __restrict__ g, cf* __restrict__ gs);
+
 template <class C, class REENTER, bool HOT = false, bool KNT = true, bool PLANE_NT = false>
 __device__ __forceinline__ void patch_body2(const PatchParams& p, REENTER&& reenter) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -593,6 +598,24 @@ __global__ void pack_kernel2(const cf* __restrict__ kfull, int n_patches, const 
   const int patch = (int)(idx / per);
   const int rem = (int)(idx % per);
   const cf* kf = kfull + (size_t)patch * C::N * C::N;
+  if (rem < C::G_PER_PATCH) {
+    const int b = rem & 1, t = (rem >> 1) % C::T, w = (rem >> 1) / C::T;
+    g[(size_t)patch * C::G_PER_PATCH + rem] = pack_value2<C>(kf, tab, t, w, b);
+  } else {
+    const int r2 = rem - C::G_PER_PATCH;
+    gs[(size_t)patch * C::GS_PER_PATCH + r2] = pack_orbit2<C>(kf, tab, ot, r2 >> 1, r2 & 1);
+  }
+}
+
+template <class C>
+__global__ void pack_spectra_kernel2(const cf* __restrict__ s_fft, const cf* __restrict__ t_fft, float alpha, float eps, int n_patches,
+                                     const uint16_t* __restrict__ tab, const uint32_t* __restrict__ ot, cf* __restrict__ g, cf* __restrict__ gs) {
+  const size_t per = (size_t)C::G_PER_PATCH + C::GS_PER_PATCH;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= per * n_patches) return;
+  const int patch = (int)(idx / per);
+  const int rem = (int)(idx % per);
+  const KFromSpectra kf{s_fft + (size_t)patch * C::N * C::N, t_fft + (size_t)patch * C::N * C::N, alpha, eps};
   if (rem < C::G_PER_PATCH) {
     const int b = rem & 1, t = (rem >> 1) % C::T, w = (rem >> 1) / C::T;
     g[(size_t)patch * C::G_PER_PATCH + rem] = pack_value2<C>(kf, tab, t, w, b);

@@ -103,18 +103,20 @@ class ArrayPSFTransform:
                 and all(isinstance(v, numbers.Integral) for c in source.coordinates for v in c)):
             # Both spectra were computed on this GPU (ArrayPSF(device=...)) and are still there: K2 -> pack -> plan without
             # anything crossing PCIe; the IndexedCube downloads K the first time somebody looks at its values.
+            # spectra -> packed K in ONE pass (the formula is evaluated where the packer reads K): the full K - 571 MB at 1089 patches of 256
+            # pixels - is neither written nor read back; it is built, from the same resident spectra, only if somebody looks at the values.
             count = len(source) * n_patch * n_patch
-            kbuf = _native.DeviceBuffer(count * 8, device)
-            _native.build_transfer_device(dev_s[0].ptr, dev_t[0].ptr, kbuf.ptr, count, False, alpha, epsilon, device)
             plan = _native.Plan(n_patch, source.coordinates, device=device)
-            plan.set_transfer_device(kbuf.ptr)
-            plan.synchronize()
+            plan.set_transfer_spectra_device(dev_s[0].ptr, dev_t[0].ptr, alpha, epsilon)
             shape = (len(source), n_patch, n_patch)
 
-            def fetch(buf=kbuf, shape=shape):
-                values = buf.download(shape, np.complex64)
-                buf.free()
-                return values
+            def fetch(bufs=(dev_s[0], dev_t[0]), shape=shape, count=count):  # (holds the two spectra alive)
+                kbuf = _native.DeviceBuffer(count * 8, device)
+                try:
+                    _native.build_transfer_device(bufs[0].ptr, bufs[1].ptr, kbuf.ptr, count, False, alpha, epsilon, device)
+                    return kbuf.download(shape, np.complex64)
+                finally:
+                    kbuf.free()
 
             cube = IndexedCube._deferred(source.coordinates, shape, fetch)
             out = cls(cube, device=device)

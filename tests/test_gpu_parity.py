@@ -1105,3 +1105,49 @@ def test_two_persistent_128_pixel_batches_on_two_streams():
             assert np.array_equal(got, first[j]), j
     ref = orc.apply_transfer(stacks[1][0], coords, k, workers=-1)
     assert np.abs(first[1][0] - ref).max() <= TOL * np.abs(ref).max()
+
+
+@pytest.mark.parametrize(("n", "shape"), [(16, (64, 80)), (32, (96, 128)), (64, (192, 256)), (128, (384, 256)), (256, (512, 768)), (20, (60, 50))])
+def test_construct_packs_k_straight_from_the_spectra(n, shape):
+    """`construct` on device-resident spectra evaluates transform.py:78-82 where the packer reads K (one pass, the full K is never
+    materialised): bit-identical to K2 followed by the pack kernel - in the packed stream (same apply, bit for bit) and in the values
+    a caller sees when it looks at the transform's kernel."""
+    from regularizepsf_amd import _native
+
+    h, w = shape
+    coords = [tuple(int(v) for v in c) for c in rp.calculate_covering(shape, n)]
+    src, tgt = make_psfs("coma", coords, n, h, w)
+    # (float32 spectra of smooth PSFs are exactly zero in the (N/2, N/2) bin - the alternating sum cancels - and 0 / 0 is NaN there, in the
+    # reference's float32 arithmetic as well: test_construct_degenerate_bins_follow_reference covers that; here a small spike keeps K finite)
+    src[:, 0, 0] += 2e-3
+    tgt[:, 0, 0] += 1e-3
+    image = orc.starfield(h, w, seed=n)
+    pad = _native.PAD_MODES["symmetric"]
+    per = len(coords) * n * n
+    if n in _native.SUPPORTED_PATCH_SIZES:
+        s_dev = _native.psf_fft_device(src.astype(np.float32))
+        t_dev = _native.psf_fft_device(tgt.astype(np.float32))
+    else:  # (no spectrum kernel for this size: the spectra come from the host)
+        s_dev = _native.DeviceBuffer(per * 8).upload(orc.psf_fft(src).astype(np.complex64))
+        t_dev = _native.DeviceBuffer(per * 8).upload(orc.psf_fft(tgt).astype(np.complex64))
+    fused = _native.Plan(n, coords)
+    fused.set_transfer_spectra_device(s_dev.ptr, t_dev.ptr, 3.0, 0.1)
+    k_dev = _native.DeviceBuffer(per * 8)
+    _native.build_transfer_device(s_dev.ptr, t_dev.ptr, k_dev.ptr, per, False, 3.0, 0.1)
+    two_pass = _native.Plan(n, coords)
+    two_pass.set_transfer_device(k_dev.ptr)
+    a, b = fused.apply(image, pad), two_pass.apply(image, pad)
+    if n in _native.SUPPORTED_PATCH_SIZES:
+        assert np.array_equal(a, b)
+    else:  # float atomics in the fallback's overlap-add
+        assert np.abs(a - b).max() <= 2e-6 * np.abs(b).max()
+    k = k_dev.download((len(coords), n, n), np.complex64)
+    assert np.isfinite(k).all()
+    check(a.astype(np.float64), orc.apply_transfer(image, coords, k))
+    if n in _native.SUPPORTED_PATCH_SIZES:  # the class API takes the same route and hands out the same K when asked
+        ps = rp.ArrayPSF(rp.IndexedCube(coords, src.astype(np.float32)), device=0)
+        pt = rp.ArrayPSF(rp.IndexedCube(coords, tgt.astype(np.float32)), device=0)
+        t = rp.ArrayPSFTransform.construct(ps, pt, 3.0, 0.1)
+        assert np.array_equal(t.apply(image), a.astype(np.float64))
+        assert np.array_equal(t._transfer_kernel.values, k)
+        assert np.array_equal(t.apply(image), a.astype(np.float64))  # looking at K did not change (or re-upload) anything
