@@ -139,6 +139,14 @@ int rpsf_apply(rpsf_plan* plan, const float* image_host, int height, int width, 
  * copies.  rpsf_apply above is this call with float32 on both sides. */
 int rpsf_apply_host(rpsf_plan* plan, const void* image_host, int image_is_f64, int height, int width, int pad_mode,
                     float pad_value, void* out_host, int out_is_f64);
+/* ArrayPSFTransform.apply with a finite saturation_threshold, whole (transform.py:117-138,171-177): float64 copy, np.pad by
+ * 2N (pad_mode's index map on the host), mask = padded > threshold, binary dilation with scipy's default cross element
+ * (dilation >= 1 iterations), NaN, the sequential row-major nanmean fill over [i - w/2, i + w/2) (neighborhood_width >= 0),
+ * the correction of the padded frame on the GPU, the raw values restored on the mask, the crop.  The host steps are the
+ * reference's, in its order, on the plan's own scratch; only the rows the patches read and the rows the caller gets cross
+ * PCIe.  (dilation < 1, negative widths and np.pad modes the kernel does not know stay with the Python layer's NumPy route.) */
+int rpsf_apply_host_saturated(rpsf_plan* plan, const void* image_host, int image_is_f64, int height, int width, int pad_mode,
+                              double threshold, int dilation, int neighborhood_width, void* out_host, int out_is_f64);
 /* Same with image and output already resident on the plan's device; asynchronous on `stream`
  * (a hipStream_t, or NULL for the plan's own stream).  Every pixel of the resident output rows is written
  * (uncovered ones with 0).  image_dev / out_dev must be ordinary device memory of the plan's device

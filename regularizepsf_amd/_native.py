@@ -67,6 +67,7 @@ _PROTOTYPES = {
     "rpsf_plan_debug_stamps": (c_int, [c_void_p, c_void_p, c_size_t]),
     "rpsf_apply": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "rpsf_apply_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int]),
+    "rpsf_apply_host_saturated": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_double, c_int, c_int, c_void_p, c_int]),
     "rpsf_apply_device": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(Geometry), c_void_p]),
     "rpsf_apply_device_timed": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(Geometry), c_int, c_void_p, c_void_p]),
     "rpsf_apply_batch": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
@@ -283,6 +284,20 @@ class Plan:
             out = np.empty(img.shape, out_dtype)
         check(lib().rpsf_apply_host(self._handle, _ptr(img), int(img.dtype == np.float64), img.shape[0], img.shape[1],
                                     pad_mode, pad_value, _ptr(out), int(out_dtype == np.float64)))
+        return out
+
+    def apply_host_saturated(self, image: np.ndarray, pad_mode: int, threshold: float, dilation: int, neighborhood_width: int,
+                             out_dtype=np.float64) -> np.ndarray:
+        """``ArrayPSFTransform.apply`` with a finite saturation threshold in one library call (mask, dilation, sequential fill and
+        restore on the host as the reference does them, the correction of the padded frame on the GPU)."""
+        img = np.asarray(image)
+        if img.dtype not in (np.float32, np.float64) or img.dtype.byteorder == ">":
+            img = img.astype(np.float64)  # (the reference's astype(float): integer frames compare against the threshold as float64)
+        img = np.ascontiguousarray(img)
+        out = np.empty(img.shape, out_dtype)
+        check(lib().rpsf_apply_host_saturated(self._handle, _ptr(img), int(img.dtype == np.float64), img.shape[0], img.shape[1], pad_mode,
+                                              float(threshold), int(dilation), int(neighborhood_width), _ptr(out),
+                                              int(np.dtype(out_dtype) == np.float64)))
         return out
 
     def apply_device(self, image_ptr: c_void_p, out_ptr: c_void_p, geometry: Geometry, stream: c_void_p | None = None) -> None:

@@ -55,6 +55,14 @@ static int fail(int code, const std::string& msg) {
 
 extern "C" const char* rpsf_last_error(void) { return g_err.c_str(); }
 
+// Python's slice arithmetic for [start, stop) over a length-n axis (a negative bound wraps once): the window rule of the saturation fill
+static void py_slice(long start, long stop, long n, long* lo, long* hi) {
+  if (start < 0) start = std::max(start + n, 0L);
+  if (stop < 0) stop = std::max(stop + n, 0L);
+  *lo = std::min(start, n);
+  *hi = std::min(stop, n);
+}
+
 // Device allocation that is freed on every exit path of the entry points that make temporaries
 struct DevBuf {
   void* p = nullptr;
@@ -86,6 +94,8 @@ struct rpsf_plan {
   // Views: a plan over a subset of another plan's patches that shares its tables, its packed K (desc.z = the patch's index in the
   // parent) and its stream - the row bands a single large host frame is cut into so that its upload, its patches and its download
   // overlap (host_one_frame).  Owned by the parent, built for one frame shape.
+  std::vector<double> sat_padded;   // rpsf_apply_host_saturated: the 2N-padded float64 frame and its mask (host scratch, kept between calls)
+  std::vector<uint8_t> sat_mask;
   rpsf_plan* parent = nullptr;
   std::vector<int32_t> k_index;           // view: patch i of this plan is patch k_index[i] of the parent
   std::vector<rpsf_plan*> bands;          // parent: its row-band views
@@ -1878,6 +1888,148 @@ extern "C" int rpsf_device_numa_node(int device, int* node) {
   return RPSF_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// ArrayPSFTransform.apply with a finite saturation threshold, whole (regularizepsf/transform.py:117-138,171-177): float64 copy, np.pad by 2N
+// (the mode's index map, evaluated here on the host), mask = padded > threshold, binary dilation with the cross element (`dilation` >= 1
+// iterations = a diamond of that radius; scipy treats the outside as background), NaN, the sequential row-major nanmean fill, the correction of
+// the PADDED frame on the GPU (corners shifted by 2N, constant padding: exactly what the reference's slices see), raw values restored on the mask,
+// crop.  Everything the reference does on the host stays on the host and in its order; what changed against the NumPy / SciPy route of rounds 1-4
+// is the cost: no np.pad / astype / copy temporaries (three passes over a (H + 4N)^2 float64 frame), no scipy.ndimage pass over the whole mask for
+// a handful of pixels, no device allocation per call, only the rows the patches read and the rows the caller gets cross PCIe.
+// ------------------------------------------------------------------------------------------------
+extern "C" int rpsf_apply_host_saturated(rpsf_plan* p, const void* image_host, int image_is_f64, int height, int width, int pad_mode,
+                                         double threshold, int dilation, int neighborhood_width, void* out_host, int out_is_f64) {
+  if (!p || !image_host || !out_host) return fail(RPSF_E_BADARG, "null argument");
+  if (height <= 0 || width <= 0) return fail(RPSF_E_BADARG, "image shape must be positive");
+  if (pad_mode < 0 || pad_mode > RPSF_PAD_WRAP) return fail(RPSF_E_BADARG, "unknown pad mode");
+  if (dilation < 1 || neighborhood_width < 0) return fail(RPSF_E_BADARG, "dilation must be >= 1 and the neighbourhood width >= 0 (other values: the NumPy route)");
+  if (!p->have_k) return fail(RPSF_E_STATE, "no transfer kernel installed (call rpsf_plan_set_transfer first)");
+  const int N = p->N, H = height, W = width;
+  const long PH = (long)H + 4L * N, PW = (long)W + 4L * N;
+  if (PH * PW >= ((long)1 << 31)) return fail(RPSF_E_UNSUPPORTED, "padded frame too large for this entry point");
+  // rows of the padded frame the patches read, and the geometry of the correction on it
+  const int r_lo = (int)std::max<long>(0, 2L * N + std::min(0, p->corner_min[0])), r_hi = (int)std::min<long>(PH, 2L * N + p->corner_max[0] + N);
+  rpsf_geometry g{(int)PH, (int)PW, RPSF_PAD_CONSTANT, 0.f, 2 * N, 2 * N, r_lo, r_hi - r_lo, (int)PW, 2 * N, H, (int)PW};
+  int rc = check_geometry(p, &g);
+  if (rc != RPSF_OK) return rc;
+  HIP_TRY(hipSetDevice(p->device));
+  rc = pipe_ensure(p, (size_t)PH * PW, 1);
+  if (rc != RPSF_OK) return rc;
+  HostPipe& q = *p->pipe;
+  HostPool& pool = HostPool::get(p->device);
+  p->sat_padded.resize((size_t)PH * PW);
+  p->sat_mask.assign((size_t)PH * PW, 0);
+  double* const padded = p->sat_padded.data();
+  uint8_t* const mask = p->sat_mask.data();
+  std::vector<int> colmap(PW);
+  for (long c = 0; c < PW; ++c) colmap[c] = pad_index((int)(c - 2L * N), W, pad_mode);
+  const int parts = (int)std::min<long>(PH, (long)pool.width() * 4);
+  std::vector<std::vector<int64_t>> hot(parts);  // per part: flat indices of the pixels above the threshold
+  // ---- pad (:119-123) + threshold (:129), row blocks in parallel
+  pool.run(parts, [&](int part) {
+    const long ra = PH * part / parts, rb = PH * (part + 1) / parts;
+    for (long r = ra; r < rb; ++r) {
+      const int sr = pad_index((int)(r - 2L * N), H, pad_mode);
+      double* dst = padded + r * PW;
+      if (sr < 0) {
+        for (long c = 0; c < PW; ++c) dst[c] = 0.0;  // np.pad(mode="constant") pads with 0
+      } else if (image_is_f64) {
+        const double* src = static_cast<const double*>(image_host) + (size_t)sr * W;
+        for (long c = 0; c < PW; ++c) dst[c] = colmap[c] < 0 ? 0.0 : src[colmap[c]];
+      } else {
+        const float* src = static_cast<const float*>(image_host) + (size_t)sr * W;
+        for (long c = 0; c < PW; ++c) dst[c] = colmap[c] < 0 ? 0.0 : (double)src[colmap[c]];
+      }
+      for (long c = 0; c < PW; ++c)
+        if (dst[c] > threshold) hot[part].push_back(r * PW + c);
+    }
+  });
+  // ---- dilation (:133): every pixel within `dilation` city-block steps of a saturated one
+  std::vector<uint8_t> row_has(PH, 0);
+  size_t n_hot = 0;
+  for (const auto& list : hot) {
+    n_hot += list.size();
+    for (const int64_t idx : list) {
+      const long r = idx / PW, c = idx % PW;
+      for (long dr = -dilation; dr <= dilation; ++dr) {
+        const long rr = r + dr;
+        if (rr < 0 || rr >= PH) continue;
+        const long span = dilation - std::labs(dr);
+        const long c0 = std::max<long>(0, c - span), c1 = std::min<long>(PW - 1, c + span);
+        std::memset(mask + rr * PW + c0, 1, (size_t)(c1 - c0 + 1));
+        row_has[rr] = 1;
+      }
+    }
+  }
+  // ---- raw values of the masked pixels the caller will see (:126, :172), NaN (:134), sequential fill (:135-138)
+  struct Raw {
+    int64_t idx;
+    double value;
+  };
+  std::vector<Raw> raw;
+  if (n_hot) {
+    for (long r = 0; r < PH; ++r) {
+      if (!row_has[r]) continue;
+      for (long c = 0; c < PW; ++c)
+        if (mask[r * PW + c]) {
+          if (r >= 2L * N && r < 2L * N + H && c >= 2L * N && c < 2L * N + W) raw.push_back({r * PW + c, padded[r * PW + c]});
+          padded[r * PW + c] = std::nan("");
+        }
+    }
+    const long hw = neighborhood_width / 2;
+    for (long i = 0; i < PH; ++i) {
+      if (!row_has[i]) continue;
+      for (long j = 0; j < PW; ++j) {
+        if (!mask[i * PW + j]) continue;
+        long r0, r1, c0, c1;
+        py_slice(i - hw, i + hw, PH, &r0, &r1);
+        py_slice(j - hw, j + hw, PW, &c0, &c1);
+        double sum = 0.0;
+        long cnt = 0;
+        for (long r = r0; r < r1; ++r)
+          for (long c = c0; c < c1; ++c) {
+            const double v = padded[r * PW + c];
+            if (v == v) sum += v, ++cnt;
+          }
+        padded[i * PW + j] = cnt ? sum / (double)cnt : std::nan("");
+      }
+    }
+  }
+  // ---- the correction of the padded frame (rows the patches read in, the caller's rows out)
+  const size_t in_lo = (size_t)r_lo * PW, in_hi = (size_t)r_hi * PW, out_lo = (size_t)2 * N * PW, out_hi = out_lo + (size_t)H * PW;
+  const int T = host_parts_for((in_hi - in_lo) * sizeof(float));
+  pool.run(T, [&](int t) {
+    size_t a, b;
+    rpsf_host::split_range(in_lo, in_hi, t, T, a, b);
+    rpsf_host::narrow_or_copy(q.h_in[0], padded, true, a, b);
+  });
+  hipError_t err = hipMemcpyAsync(q.d_in[0], q.h_in[0] + in_lo, (in_hi - in_lo) * sizeof(float), hipMemcpyHostToDevice, p->stream);
+  if (err == hipSuccess && launch_apply(p, q.d_in[0], q.d_out[0], g, p->stream, nullptr) != RPSF_OK) err = hipErrorUnknown;
+  if (err == hipSuccess) err = hipMemcpyAsync(q.h_out[0] + out_lo, q.d_out[0], (out_hi - out_lo) * sizeof(float), hipMemcpyDeviceToHost, p->stream);
+  if (err == hipSuccess) err = hipStreamSynchronize(p->stream);
+  if (err != hipSuccess) return drain_after_error(p, err, "saturated host frame");
+  // ---- crop (:174-177) with the raw values back on the mask (:172)
+  const int rows_parts = std::min(H, pool.width() * 4);
+  pool.run(rows_parts, [&](int part) {
+    const long ra = (long)H * part / rows_parts, rb = (long)H * (part + 1) / rows_parts;
+    for (long r = ra; r < rb; ++r) {
+      const float* src = q.h_out[0] + out_lo + (size_t)r * PW + 2 * N;
+      if (out_is_f64) {
+        double* dst = static_cast<double*>(out_host) + (size_t)r * W;
+        for (long c = 0; c < W; ++c) dst[c] = (double)src[c];
+      } else {
+        std::memcpy(static_cast<float*>(out_host) + (size_t)r * W, src, (size_t)W * sizeof(float));
+      }
+    }
+  });
+  for (const Raw& x : raw) {
+    const long r = x.idx / PW - 2L * N, c = x.idx % PW - 2L * N;
+    if (out_is_f64) static_cast<double*>(out_host)[(size_t)r * W + c] = x.value;
+    else static_cast<float*>(out_host)[(size_t)r * W + c] = (float)x.value;
+  }
+  return RPSF_OK;
+}
+
 extern "C" int rpsf_host_threads(int* threads) {
   if (!threads) return fail(RPSF_E_BADARG, "null argument");
   *threads = HostPool::get().width();
@@ -2088,12 +2240,6 @@ extern "C" int rpsf_psf_model_fft_device(int device, int model, int patch_size, 
 // [i - w/2, i + w/2) x [j - w/2, j + w/2), so later pixels see earlier fills.  Window bounds follow Python
 // slice semantics (a negative start wraps once; an empty window gives NaN), as in the reference.
 // ------------------------------------------------------------------------------------------------
-static void py_slice(long start, long stop, long n, long* lo, long* hi) {
-  if (start < 0) start = std::max(start + n, 0L);
-  if (stop < 0) stop = std::max(stop + n, 0L);
-  *lo = std::min(start, n);
-  *hi = std::min(stop, n);
-}
 
 extern "C" int rpsf_saturation_fill(double* padded, int rows, int cols, const uint8_t* mask, int neighborhood_width) {
   if (!padded || !mask || rows <= 0 || cols <= 0) return fail(RPSF_E_BADARG, "bad argument");

@@ -27,16 +27,27 @@ def _kernel_stamp(cube: IndexedCube) -> tuple:
 
     The reference multiplies by ``values`` as they are at every ``apply`` (transform.py:164), and ``IndexedCube`` does not
     copy them, so a caller may edit the array in place between two applies.  ``__setitem__`` is counted exactly; edits that
-    bypass it (``cube.values[i] = ...``, ``k *= 2``) are caught by hashing an evenly strided sample of about 64 K
-    elements (every patch of a 256-pixel cube contributes ~60 of them; 0.2 ms).  An edit confined to elements between
-    two samples is not seen - call :meth:`ArrayPSFTransform.invalidate` after such surgical edits.
+    bypass it (``cube.values[i] = ...``, ``k *= 2``) are caught by hashing one 64-byte line of every patch (at most 4096
+    patches, evenly spaced beyond that; the line's position inside the patch varies from patch to patch) - 20 ... 60 us, where
+    the evenly strided 64 K-element sample of rounds 2-4 cost 0.3 ... 1.4 ms of cache misses per apply, more than a small frame's
+    whole correction.  An edit confined to a few elements of a patch is not seen - call :meth:`ArrayPSFTransform.invalidate`
+    after such surgical edits.
     """
     if getattr(cube, "_loader", None) is not None:  # still on the GPU only (construct from device-resident spectra): nobody can have edited it
         return ("deferred", id(cube), cube._edits)
     values = cube.values
-    if values.flags.c_contiguous or values.flags.f_contiguous:
+    if values.ndim == 3 and values.flags.c_contiguous and values.itemsize in (8, 16) and values.size:
+        per = values.shape[1] * values.shape[2]
+        words = values.reshape(-1).view(np.uint64)  # 1 (complex64) or 2 (complex128) words per element
+        wpp = per * (values.itemsize // 8)
+        patches = np.arange(0, values.shape[0], max(1, values.shape[0] // 4096), dtype=np.int64)
+        line = min(8, wpp)
+        offset = (patches * 104729) % max(1, wpp - line + 1)
+        index = (patches * wpp + offset)[:, None] + np.arange(line, dtype=np.int64)[None, :]
+        sample = words[index.reshape(-1)]
+    elif values.flags.c_contiguous or values.flags.f_contiguous:
         flat = values.reshape(-1, order="A")
-        sample = flat[:: max(1, flat.size // 65536)]
+        sample = flat[:: max(1, flat.size // 4096)]
     else:  # strided views are rare and small: hash everything
         sample = np.ascontiguousarray(values)
     digest = hashlib.blake2b(sample.tobytes(), digest_size=8).digest()
@@ -237,8 +248,15 @@ class ArrayPSFTransform:
         if saturation_threshold == math.inf and pad_mode in _native.PAD_MODES:  # nothing can exceed +inf
             return plan.apply_host(image, _native.PAD_MODES[pad_mode])  # float64 out; conversions inside the library
 
-        # Host-side padding: np.pad modes the kernel does not evaluate, and the saturation branch,
-        # which works on the padded image (transform.py:119-138,171-172).
+        if (pad_mode in _native.PAD_MODES and isinstance(saturation_dilation, numbers.Integral) and saturation_dilation >= 1
+                and isinstance(neighborhood_width, numbers.Integral) and neighborhood_width >= 0):
+            # the saturation branch in one library call: the reference's host steps (pad, mask, dilation, sequential fill, restore) on the
+            # plan's own scratch, the correction of the padded frame on the GPU (rpsf_apply_host_saturated)
+            return plan.apply_host_saturated(image, _native.PAD_MODES[pad_mode], saturation_threshold, saturation_dilation,
+                                             neighborhood_width)
+
+        # Host-side padding: np.pad modes the kernel does not evaluate, and the corner cases of the saturation branch (dilation < 1: scipy
+        # iterates to a fixed point; negative widths), which work on the padded image (transform.py:119-138,171-172).
         padded = np.pad(image.astype(float), ((2 * n, 2 * n), (2 * n, 2 * n)), mode=pad_mode)
         raw = padded.copy()
         mask = padded > saturation_threshold

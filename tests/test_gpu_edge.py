@@ -96,3 +96,40 @@ def test_float64_image_on_a_1e7_pedestal(n, shape):
         ref_f = ref if frame.dtype == np.float64 else orc.apply_transfer(frame, coords, k)
         d = out - ref_f
         assert np.abs(d).max() <= TOL * np.abs(ref_f).max() and np.linalg.norm(d) <= TOL * np.linalg.norm(ref_f)
+
+
+@pytest.mark.parametrize(("n", "shape", "pad_mode", "dilation", "width", "dtype"), [
+    (32, (96, 128), "symmetric", 1, 7, np.float32), (32, (96, 128), "reflect", 2, 5, np.float64), (64, (200, 192), "constant", 1, 7, np.float32),
+    (64, (200, 192), "edge", 3, 2, np.float32), (32, (70, 90), "wrap", 1, 1, np.float64), (128, (300, 260), "symmetric", 2, 7, np.float32),
+    (16, (40, 48), "symmetric", 1, 0, np.float32), (64, (192, 192), "symmetric", 1, 7, np.int32), (256, (512, 640), "symmetric", 1, 7, np.float32)])
+def test_saturation_branch_in_one_library_call(n, shape, pad_mode, dilation, width, dtype):
+    """`apply(..., saturation_threshold=...)` through rpsf_apply_host_saturated: pad, mask, dilation, sequential fill, restore as the
+    reference does them (regularizepsf/transform.py:117-138,171-172) - saturated pixels inside, on the rim (their mirror images in the
+    pad are masked and filled on their own), in the corners, in clusters, next to NaN pixels; the raw values come back exactly."""
+    h, w = shape
+    coords, k = orc.synthetic_transfer(h, w, n, alpha=1.0, epsilon=0.1)
+    rng = np.random.default_rng(n + dilation + width)
+    image = orc.starfield(h, w, seed=3 * n).astype(np.float64)
+    hot = [(0, 0), (h - 1, w - 1), (1, w // 2), (h // 2, 0), (h // 2, w // 2), (h // 2, w // 2 + 1), (h // 2 + 1, w // 2)]
+    hot += [(int(r), int(c)) for r, c in zip(rng.integers(0, h, 12), rng.integers(0, w, 12))]
+    for r, c in hot:
+        image[r, c] = 5.0e4 + r + c
+    image[h // 3 : h // 3 + 4, w // 3 : w // 3 + 5] = 7.0e4  # a saturated blob: later fills see earlier ones
+    if dtype == np.float64:
+        image[h // 4, w // 4] = np.nan  # a masked detector pixel next to nothing in particular
+    image = image.astype(dtype)
+    threshold = 2.0e4
+    ref = orc.apply_transfer(image, coords, k, pad_mode=pad_mode, saturation_threshold=threshold, saturation_dilation=dilation,
+                             neighborhood_width=width)
+    t = rp.ArrayPSFTransform(rp.IndexedCube(coords, k))
+    before = image.copy()
+    out = t.apply(image, pad_mode=pad_mode, saturation_threshold=threshold, saturation_dilation=dilation, neighborhood_width=width)
+    assert np.array_equal(image, before, equal_nan=True)  # the input is never modified
+    _compare(out, ref)
+    for r, c in hot:  # restored raw values, exactly (transform.py:172)
+        assert out[r, c] == float(image[r, c]) == ref[r, c]
+    # the same transform without saturated pixels in the frame, and a second saturated call on another frame size
+    calm = np.minimum(np.nan_to_num(before.astype(np.float64), nan=100.0), 1.0e4)
+    _compare(t.apply(calm, pad_mode=pad_mode, saturation_threshold=threshold, saturation_dilation=dilation, neighborhood_width=width),
+             orc.apply_transfer(calm, coords, k, pad_mode=pad_mode, saturation_threshold=threshold, saturation_dilation=dilation,
+                                neighborhood_width=width))
