@@ -45,6 +45,8 @@ CONFIGS = {  # name -> (height, width, patch, starfield seed)
     3: (4096, 4096, 256, 3),
     4: (8192, 8192, 256, 4),   # BASELINE.json configs[3]: one 8192^2 frame, row bands over the ranks (strong scaling)
     5: (2048, 2048, 128, 100),  # batch of frames sharing config 2's transfer kernel (BASELINE.json configs[4])
+    6: (4096, 4096, 64, 6),    # not a BASELINE config: the first-generation (two-stage) kernels at the frame size of the headline - the patch size
+                               # of the reference's own example (docs/source/example.ipynb: psf_size = 64)
 }
 
 

@@ -986,7 +986,8 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
         // patches leave idle (RPSF_FRAME_MAJOR=0/1 overrides).
         bool frame_major = std::is_same_v<C, Cfg256v2> && p->persist && b.frames > 1 && p->n_patches >= 1024 &&
                            16.0 * (double)p->planes_floats * b.frames > 256.0 * 1048576.0;  // (8 x 2048^2: 0.056 ms per frame side by side, 0.061 in turn)
-        if (const char* e = std::getenv("RPSF_FRAME_MAJOR")) frame_major = frame_major && std::atoi(e) != 0;
+        if (const char* e = std::getenv("RPSF_FRAME_MAJOR"))  // development sweeps: 0 = never, 2 = any persistent batch
+          frame_major = std::atoi(e) == 2 ? (p->persist && b.frames > 1) : (frame_major && std::atoi(e) != 0);
         pp.frame_major = ts.frame_major = frame_major ? 1 : 0;
         // Frames of a batch side by side keep the planes of ALL of them live at once (8 x 2048^2: 537 MB against a 256 MiB Infinity Cache): the 128-pixel
         // kernels then store them with the streaming hint - 0.3156 -> 0.3009 ms (-4.7 %); a single frame loses 8 % that way, and so does the 256-pixel
