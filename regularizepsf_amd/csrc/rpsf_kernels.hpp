@@ -113,19 +113,18 @@ __device__ __forceinline__ void sum_tile(const TileSum& p0, uint32_t entry_any_l
   const bool vec = ((x0 | x1 | p.ld_planes | p.ld_out) & 3) == 0 && (p.plane_stride & 3) == 0 &&
                    ((reinterpret_cast<uintptr_t>(p.planes) | reinterpret_cast<uintptr_t>(p.out)) & 15) == 0;
   const int gw = (x1 - x0) >> 2;
-  // (a tile is 2^k groups of four pixels wide except where the image clips its last column to something else - those few tiles go pixel by pixel)
-  constexpr bool POW2 = true;
-  const bool wide_path = vec && (gw & (gw - 1)) == 0;
-  if (wide_path) {
+  // Row and column group of element i: a tile is 2^k groups of four pixels wide except where the image clips its last column, and an integer
+  // division by a run-time value is a dozen instructions, three of them v_cndmask on VCC (23 cycles apiece on gfx950): the power-of-two case
+  // shifts and masks; the clipped tiles (e.g. 96 of 128 pixels at the right edge of a 4064-wide image) keep the 16-byte accesses in a compact loop with
+  // the division (until round 5 they fell to the pixel-by-pixel path: four agent-scope loads per pixel).
+  if (vec) {
     const __amdgpu_buffer_rsrc_t rsrc = plane_rsrc(p.planes);
     const int total = gw * (y1 - y0);
     // (UN = 8: 32 sixteen-byte loads per thread - a whole tile per pass for the patch kernels' workgroup sizes)
-    // Row and column group of element i: a tile is 2^k groups wide except where the image clips it, and an integer division by a run-time
-    // value is a dozen instructions, three of them v_cndmask on VCC (23 cycles apiece on gfx950): the power-of-two case shifts and masks.
-    {
+    if ((gw & (gw - 1)) == 0) {
       const int sh = 31 - __builtin_clz((unsigned)gw);
-      auto row_of = [&](int i) RPSF_AI { return POW2 ? i >> sh : i / gw; };
-      auto col_of = [&](int i) RPSF_AI { return POW2 ? i & (gw - 1) : i % gw; };
+      auto row_of = [&](int i) RPSF_AI { return i >> sh; };
+      auto col_of = [&](int i) RPSF_AI { return i & (gw - 1); };
       for (int i0 = tid; i0 < total; i0 += UN * nthreads) {
         f4 v[UN][4];
 #pragma unroll
@@ -148,6 +147,20 @@ __device__ __forceinline__ void sum_tile(const TileSum& p0, uint32_t entry_any_l
             if ((cov >> k) & 1) acc += v[u][k];
           __builtin_nontemporal_store(acc, reinterpret_cast<f4*>(p.out + (size_t)(y0 + row_of(i) - p.row0) * p.ld_out + x0 + (col_of(i) << 2)));
         }
+      }
+    } else {  // a clipped tile: the same 16-byte accesses, one group per thread and step (a compact loop: these are a few tiles per frame, and a second
+              // unrolled instantiation would cost the persistent kernels 19 KB of code and 13 more spilled SGPRs)
+      for (int i = tid; i < total; i += nthreads) {
+        const int row = i / gw, col = i - row * gw;
+        const size_t off = (size_t)(y0 + row - p.row0) * p.ld_planes + x0 + (col << 2);
+        f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if ((cov >> k) & 1) {  // (workgroup-uniform)
+            const size_t o = off + k * p.plane_stride;
+            acc += fused ? plane_load16_wt(rsrc, o) : __builtin_nontemporal_load(reinterpret_cast<const f4*>(p.planes + o));
+          }
+        __builtin_nontemporal_store(acc, reinterpret_cast<f4*>(p.out + (size_t)(y0 + row - p.row0) * p.ld_out + x0 + (col << 2)));
       }
     }
   } else {
