@@ -192,6 +192,9 @@ int rpsf_host_free(void* ptr);
  * pinned to cores of the NUMA node the (first) device hangs off, spread over its core complexes (RPSF_HOST_AFFINITY=0: not
  * pinned; RPSF_HOST_THREADS: width). */
 int rpsf_host_threads(int* threads);
+/* Self-test of that pool (no GPU involved; the CPU test suite runs it): `jobs` jobs of up to `parts` parts from each of `callers`
+ * threads at once, every part checked to have run exactly once; *failures = number of jobs that came out wrong. */
+int rpsf_host_pool_selftest(int callers, int jobs, int parts, int* failures);
 /* That node (-1: unknown): a process that feeds the GPU from host arrays should run and allocate there - staging copies
  * from the other socket run at a third of the rate (scripts/micro/host_copy.hip). */
 int rpsf_device_numa_node(int device, int* node);

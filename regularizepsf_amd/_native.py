@@ -77,6 +77,7 @@ _PROTOTYPES = {
     "rpsf_host_alloc": (c_int, [c_int, c_size_t, POINTER(c_void_p)]),
     "rpsf_host_free": (c_int, [c_void_p]),
     "rpsf_host_threads": (c_int, [POINTER(c_int)]),
+    "rpsf_host_pool_selftest": (c_int, [c_int, c_int, c_int, POINTER(c_int)]),
     "rpsf_device_numa_node": (c_int, [c_int, POINTER(c_int)]),
     "rpsf_pcie_probe": (c_int, [c_int, c_size_t, c_int, POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
     "rpsf_apply_batch_device": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_size_t, POINTER(Geometry),
@@ -334,6 +335,21 @@ class Plan:
         of one shape; float32 / float64 frames are taken as they are (no stacking, no astype on the host side of the call),
         anything else goes through float32.  Returns (or fills ``out``, C-contiguous float32 / float64) a (frames, H, W) stack.
         H2D of the next frames, the shared-K launches and D2H + widening of the previous ones overlap on three streams."""
+        if (isinstance(images, np.ndarray) and images.ndim == 3 and images.shape[0] and images.flags.c_contiguous
+                and images.dtype in (np.float32, np.float64) and images.dtype.byteorder != ">"):
+            # a contiguous stack: one call on the base pointers (no per-frame Python work - for 512^2 frames that was half of the time)
+            out_dtype = np.dtype(out.dtype if out is not None else out_dtype)
+            if out_dtype not in (np.float32, np.float64):
+                msg = "out_dtype must be float32 or float64"
+                raise ValueError(msg)
+            if out is None:
+                out = np.empty(images.shape, out_dtype)
+            elif out.shape != images.shape or not out.flags.c_contiguous or not out.flags.writeable:
+                msg = "out must be a writeable C-contiguous array of shape (frames, H, W)"
+                raise ValueError(msg)
+            check(lib().rpsf_apply_batch_host(self._handle, _ptr(images), int(images.dtype == np.float64), images.shape[0], images.shape[1],
+                                              images.shape[2], pad_mode, pad_value, _ptr(out), int(out_dtype == np.float64)))
+            return out
         frames = [np.asarray(im) for im in images]
         if not frames:
             msg = "need at least one frame"

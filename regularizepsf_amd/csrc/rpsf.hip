@@ -1709,10 +1709,10 @@ static int host_one_frame(rpsf_plan* p, const void* image, int in_f64, void* out
 }
 
 // Frames per group of the streamed pipeline: small frames go through the shared-K batch launch a few at a time (the packed K is
-// read once per group, and a launch / a copy of a few hundred KiB is all overhead); from 16 MiB per frame on (2048^2), where a
-// frame's copies take several times its kernel, one by one - a short batch then pays the shortest ramp.
+// read once per group, and a launch / a copy of a few hundred KiB is all overhead: up to 32 frames or 16 MiB per group); from 16 MiB per
+// frame on (2048^2), where a frame's copies take several times its kernel, one by one - a short batch then pays the shortest ramp.
 static int stream_group_frames(size_t frame_bytes, int n_frames) {
-  int g = (int)std::max<size_t>(1, std::min<size_t>(8, ((size_t)16 << 20) / std::max<size_t>(1, frame_bytes)));
+  int g = (int)std::max<size_t>(1, std::min<size_t>(32, ((size_t)16 << 20) / std::max<size_t>(1, frame_bytes)));
   if (const char* e = std::getenv("RPSF_STREAM_GROUP")) g = std::max(1, std::min(64, std::atoi(e)));  // development sweeps
   return std::min(g, n_frames);
 }
@@ -1735,7 +1735,7 @@ static int host_frames(rpsf_plan* p, const void* const* images, int in_f64, void
   if (rc != RPSF_OK) return rc;
   HostPipe& q = *p->pipe;
   HostPool& pool = HostPool::get(p->device);
-  const int T = host_parts_for(bytes);
+  const int T = host_parts_for(bytes * G);  // (a job stages / unstages a whole group: small frames still give every worker a part)
   auto frames_of = [&](int grp) { return std::min(G, n_frames - grp * G); };
   const bool direct_in = !in_f64 && all_pinned(images, n_frames);
   const bool direct_out = !out_f64 && all_pinned(const_cast<const void* const*>(outs), n_frames);
@@ -1767,10 +1767,21 @@ static int host_frames(rpsf_plan* p, const void* const* images, int in_f64, void
     const int ci = direct_in ? 0 : fi, co = direct_out ? 0 : fo;  // frames this job stages / unstages
     if (ci + co > 0)
       pool.run(T, [&](int t) {
+        // the group's frames laid end to end, cut into T parts: a part covers a run of pixels that may span frames
+        const size_t total_in = (size_t)ci * count, total_out = (size_t)co * count;
         size_t a, b;
-        rpsf_host::split_range(0, count, t, T, a, b);
-        for (int f = 0; f < ci; ++f) rpsf_host::narrow_or_copy(q.h_in[si] + (size_t)f * count, images[next_in * G + f], in_f64 != 0, a, b);
-        for (int f = 0; f < co; ++f) rpsf_host::widen_or_copy(outs[next_out * G + f], out_f64 != 0, q.h_out[so] + (size_t)f * count, a, b);
+        rpsf_host::split_range(0, total_in, t, T, a, b);
+        while (a < b) {
+          const size_t f = a / count, lo = a % count, hi = std::min(count, lo + (b - a));
+          rpsf_host::narrow_or_copy(q.h_in[si] + f * count, images[next_in * G + f], in_f64 != 0, lo, hi);
+          a += hi - lo;
+        }
+        rpsf_host::split_range(0, total_out, t, T, a, b);
+        while (a < b) {
+          const size_t f = a / count, lo = a % count, hi = std::min(count, lo + (b - a));
+          rpsf_host::widen_or_copy(outs[next_out * G + f], out_f64 != 0, q.h_out[so] + f * count, lo, hi);
+          a += hi - lo;
+        }
       });
     t_jobs += ms_since(t_phase), t_phase = std::chrono::steady_clock::now();
     if (can_in) {
@@ -2028,6 +2039,35 @@ extern "C" int rpsf_apply_host_saturated(rpsf_plan* p, const void* image_host, i
     if (out_is_f64) static_cast<double*>(out_host)[(size_t)r * W + c] = x.value;
     else static_cast<float*>(out_host)[(size_t)r * W + c] = (float)x.value;
   }
+  return RPSF_OK;
+}
+
+// Self-test of the host worker pool (no GPU involved: the CPU test suite calls it): `jobs` jobs of `parts` parts from each of `callers` threads at
+// once; every part adds its index into a per-job cell and the job must see the exact total when run() returns.  Returns the number of jobs
+// whose total was wrong (0 = pass) through *failures.
+extern "C" int rpsf_host_pool_selftest(int callers, int jobs, int parts, int* failures) {
+  if (!failures || callers <= 0 || jobs <= 0 || parts <= 0) return fail(RPSF_E_BADARG, "bad argument");
+  HostPool& pool = HostPool::get();
+  std::atomic<int> bad{0};
+  auto caller = [&](int id) {
+    for (int j = 0; j < jobs; ++j) {
+      const int n = 1 + (parts + id + j) % parts;  // varying job sizes, single-part jobs included
+      std::atomic<long> sum{0};
+      std::vector<int> hits(n, 0);
+      pool.run(n, [&](int i) {
+        sum.fetch_add(i + 1, std::memory_order_relaxed);
+        ++hits[i];  // every part exactly once, by exactly one thread
+      });
+      bool ok = sum.load() == (long)n * (n + 1) / 2;
+      for (int i = 0; i < n && ok; ++i) ok = hits[i] == 1;
+      if (!ok) bad.fetch_add(1);
+    }
+  };
+  std::vector<std::thread> threads;
+  for (int c = 1; c < callers; ++c) threads.emplace_back(caller, c);
+  caller(0);
+  for (auto& t : threads) t.join();
+  *failures = bad.load();
   return RPSF_OK;
 }
 

@@ -316,11 +316,13 @@ class ArrayPSFTransform:
 
     def _apply_batch_locked(self, images, workers, pad_mode, saturation_threshold, saturation_dilation, neighborhood_width,
                             dtype, out) -> np.ndarray:
+        stack = None
         if isinstance(images, np.ndarray):
             if images.ndim != 3:
                 msg = f"images must have shape (frames, H, W), got {images.shape}"
                 raise ValueError(msg)
-            frames = list(images)
+            frames = images  # (iterated only on the per-frame routes below)
+            stack = images
             shape = images.shape[1:]
         else:
             frames = [np.asarray(im) for im in images]
@@ -329,7 +331,7 @@ class ArrayPSFTransform:
                 msg = "images must be a sequence of two dimensional arrays of one shape"
                 raise ValueError(msg)
         dtype = np.dtype(out.dtype if out is not None else dtype)
-        if (saturation_threshold != math.inf or pad_mode not in _native.PAD_MODES or not frames
+        if (saturation_threshold != math.inf or pad_mode not in _native.PAD_MODES or len(frames) == 0
                 or dtype not in (np.float32, np.float64)):
             outs = [self.apply(im, workers, pad_mode, saturation_threshold, saturation_dilation, neighborhood_width)
                     for im in frames]
@@ -345,7 +347,7 @@ class ArrayPSFTransform:
         plan = self._device_plan()
         height, width = shape
         self._check_corners(n, height, width)
-        return plan.apply_frames_host(frames, _native.PAD_MODES[pad_mode], out_dtype=dtype, out=out)
+        return plan.apply_frames_host(stack if stack is not None else frames, _native.PAD_MODES[pad_mode], out_dtype=dtype, out=out)
 
     # ------------------------------------------------------------------ persistence (transform.py:220-282)
     def save(self, path: pathlib.Path, overwrite: bool = False) -> None:

@@ -119,3 +119,22 @@ def test_development_switches_still_compile(tmp_path):
                               capture_output=True, text=True)
         assert done.returncode == 0, done.stderr[-2000:]
         assert out.stat().st_size > 0
+
+
+@pytest.mark.parametrize("threads", ["1", "3", "16"])
+def test_host_worker_pool_runs_every_part_exactly_once(threads):
+    """The persistent host pool behind the host-array entry points (csrc/rpsf_hostpipe.hpp) needs no GPU: jobs of 1 ... 37 parts from four
+    calling threads at once (the pool serves one job at a time; callers take turns), thousands of times - every part runs exactly once and
+    run() returns only when all have.  The pool's width is fixed when a process first uses it, so each width runs in a process of its own."""
+    import subprocess
+    import sys
+
+    code = ("import ctypes, sys; sys.path.insert(0, %r); from regularizepsf_amd import _native; lib = _native.lib(); "
+            "bad = ctypes.c_int(-1); n = ctypes.c_int(0); "
+            "assert lib.rpsf_host_pool_selftest(4, 1500, 37, ctypes.byref(bad)) == 0, lib.rpsf_last_error(); "
+            "assert lib.rpsf_host_threads(ctypes.byref(n)) == 0; print(bad.value, n.value)" % str(ROOT))
+    env = dict(__import__("os").environ, RPSF_HOST_THREADS=threads)
+    done = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert done.returncode == 0, done.stderr[-1500:]
+    bad, width = (int(v) for v in done.stdout.split())
+    assert bad == 0 and width == max(1, int(threads))
