@@ -895,28 +895,33 @@ def main() -> None:
     if pipeline:  # the overlapped steps priced on the same bytes (not roofline.frac: SURVEY 8d's t is one device-resident apply)
         line["roofline"]["frac_steps_in_flight"] = round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     if world == 1 and not args.no_e2e:
-        # one host-array apply(), end to end: what every caller of the class API gets (float32 frame in, float64 out as the reference
-        # returns it; and float32 out); PCIe floor = the frame's float32 bytes in, then out (a single frame cannot overlap its own directions
-        # without being cut into row bands)
-        # (one process per GPU runs next to it: for this leg the thread is bound to the GPU's NUMA node, so that the arrays it allocates are
-        # first touched there; the affinity is restored afterwards - the cpu_baseline leg uses every core of the box)
         affinity = os.sched_getaffinity(0)
-        bound_node = -1 if args.no_bind else _native.bind_to_device_node(device)
-        host_image = np.array(band_image, np.float32)[None]
-        e2e = {}
-        for label, dt in (("f32_to_f64", np.float64), ("f32_to_f32", np.float32)):
-            ms, _, probe = e2e_host_frames(plan, host_image, _native.PAD_MODES[pad], dt)
-            e2e[label] = round(ms, 4)
-        e2e["f32_to_f32_pinned_arrays"] = round(e2e_host_frames(plan, host_image, _native.PAD_MODES[pad], np.float32, pinned=True)[0], 4)
-        line["e2e_ms"] = e2e["f32_to_f64"]
-        line["e2e"] = {"what": "one ArrayPSFTransform.apply-style call on host arrays (rpsf_apply_host: chunked staging on the persistent host pool, "
-                               "H2D, patch launch, D2H, widening), best of 5, result buffer reused",
-                       "ms": e2e, "pcie": {k: round(v, 4) for k, v in probe.items()},
-                       "pcie_floor_ms": round(probe["h2d_ms"] + probe["d2h_ms"], 4), "host_threads": _native.host_threads(),
-                       "over_pcie_floor": round(e2e["f32_to_f64"] / (probe["h2d_ms"] + probe["d2h_ms"]), 3),
-                       "process_bound_to_numa_node": bound_node, "device_numa_node": _native.device_numa_node(device)}
-        del host_image
-        os.sched_setaffinity(0, affinity)
+        try:  # (an auxiliary leg: whatever goes wrong in it must not cost the run its headline line)
+            # one host-array apply(), end to end: what every caller of the class API gets (float32 frame in, float64 out as the reference
+            # returns it; and float32 out); PCIe floor = the frame's float32 bytes in, then out (a single frame cannot overlap its own directions
+            # without being cut into row bands)
+            # (one process per GPU runs next to it: for this leg the thread is bound to the GPU's NUMA node, so that the arrays it allocates are
+            # first touched there; the affinity is restored afterwards - the cpu_baseline leg uses every core of the box)
+            bound_node = -1 if args.no_bind else _native.bind_to_device_node(device)
+            host_image = np.array(band_image, np.float32)[None]
+            e2e = {}
+            for label, dt in (("f32_to_f64", np.float64), ("f32_to_f32", np.float32)):
+                ms, _, probe = e2e_host_frames(plan, host_image, _native.PAD_MODES[pad], dt)
+                e2e[label] = round(ms, 4)
+            e2e["f32_to_f32_pinned_arrays"] = round(e2e_host_frames(plan, host_image, _native.PAD_MODES[pad], np.float32, pinned=True)[0], 4)
+            line["e2e_ms"] = e2e["f32_to_f64"]
+            line["e2e"] = {"what": "one ArrayPSFTransform.apply-style call on host arrays (rpsf_apply_host: the frame cut into row bands so that staging on the "
+                                   "persistent host pool, H2D, the bands' patch launches, D2H and widening overlap), best of 5, result buffer reused",
+                           "ms": e2e, "pcie": {k: round(v, 4) for k, v in probe.items()},
+                           "pcie_floor_ms": round(probe["h2d_ms"] + probe["d2h_ms"], 4), "host_threads": _native.host_threads(),
+                           "over_pcie_floor": round(e2e["f32_to_f64"] / (probe["h2d_ms"] + probe["d2h_ms"]), 3),
+                           "process_bound_to_numa_node": bound_node, "device_numa_node": _native.device_numa_node(device)}
+            del host_image
+        except Exception as e:  # noqa: BLE001
+            line["e2e_error"] = f"{type(e).__name__}: {e}"
+            print(f"[bench] end-to-end leg failed: {line['e2e_error']}", file=sys.stderr, flush=True)
+        finally:
+            os.sched_setaffinity(0, affinity)
     traffic_file = ROOT / "profiles" / "traffic_latest.json"
     if world == 1 and args.config == 3 and traffic_file.exists():  # PMC counters cannot be read from inside the process
         tr = json.loads(traffic_file.read_text())

@@ -1647,7 +1647,11 @@ static int host_one_frame(rpsf_plan* p, const void* image, int in_f64, void* out
       }
     }
   } else {
-  if (direct_in) err = hipMemcpyAsync(q.d_in[0], image, bytes, hipMemcpyHostToDevice, q.st_in);
+  // (a frame of one chunk - under 8 MiB - has nothing to overlap with itself: everything on the plan's stream, no events to tie three together;
+  // 512^2: 0.179 -> see profiles/r05v)
+  const bool one_stream = n_chunks == 1;
+  const hipStream_t s_in = one_stream ? p->stream : q.st_in, s_out = one_stream ? p->stream : q.st_out;
+  if (direct_in) err = hipMemcpyAsync(q.d_in[0], image, bytes, hipMemcpyHostToDevice, s_in);
   for (int c = 0; c < n_chunks && err == hipSuccess && !direct_in; ++c) {
     size_t lo, hi;
     chunk_range(c, lo, hi);
@@ -1658,23 +1662,28 @@ static int host_one_frame(rpsf_plan* p, const void* image, int in_f64, void* out
       rpsf_host::narrow_or_copy(q.h_in[0], image, in_f64 != 0, a, b);
     });
     t_conv_in += ms_since(t0);
-    if (hi > lo) err = hipMemcpyAsync(q.d_in[0] + lo, q.h_in[0] + lo, (hi - lo) * sizeof(float), hipMemcpyHostToDevice, q.st_in);
+    if (hi > lo) err = hipMemcpyAsync(q.d_in[0] + lo, q.h_in[0] + lo, (hi - lo) * sizeof(float), hipMemcpyHostToDevice, s_in);
   }
-  if (err == hipSuccess) err = hipEventRecord(q.ev_in[0], q.st_in);
-  if (err == hipSuccess) err = hipStreamWaitEvent(p->stream, q.ev_in[0], 0);
+  if (!one_stream) {
+    if (err == hipSuccess) err = hipEventRecord(q.ev_in[0], s_in);
+    if (err == hipSuccess) err = hipStreamWaitEvent(p->stream, q.ev_in[0], 0);
+  }
   if (err == hipSuccess && launch_apply(p, q.d_in[0], q.d_out[0], g, p->stream, nullptr) != RPSF_OK) err = hipErrorUnknown;
-  if (err == hipSuccess) err = hipEventRecord(q.ev_k[0], p->stream);
-  if (err == hipSuccess) err = hipStreamWaitEvent(q.st_out, q.ev_k[0], 0);
+  if (!one_stream || trace) {
+    if (err == hipSuccess) err = hipEventRecord(q.ev_k[0], p->stream);
+    if (err == hipSuccess && !one_stream) err = hipStreamWaitEvent(s_out, q.ev_k[0], 0);
+    if (err == hipSuccess && one_stream) err = hipEventRecord(q.ev_in[0], p->stream);  // (trace only)
+  }
   if (direct_out && err == hipSuccess) {
-    err = hipMemcpyAsync(out, q.d_out[0], bytes, hipMemcpyDeviceToHost, q.st_out);
-    if (err == hipSuccess) err = hipEventRecord(q.ev_chunk[0], q.st_out);
+    err = hipMemcpyAsync(out, q.d_out[0], bytes, hipMemcpyDeviceToHost, s_out);
+    if (err == hipSuccess) err = hipEventRecord(q.ev_chunk[0], s_out);
     out_chunks.push_back({0, count});
   }
   for (int c = 0; c < n_chunks && err == hipSuccess && !direct_out; ++c) {
     size_t lo, hi;
     chunk_range(c, lo, hi);
-    if (hi > lo) err = hipMemcpyAsync(q.h_out[0] + lo, q.d_out[0] + lo, (hi - lo) * sizeof(float), hipMemcpyDeviceToHost, q.st_out);
-    if (err == hipSuccess) err = hipEventRecord(q.ev_chunk[out_chunks.size()], q.st_out);
+    if (hi > lo) err = hipMemcpyAsync(q.h_out[0] + lo, q.d_out[0] + lo, (hi - lo) * sizeof(float), hipMemcpyDeviceToHost, s_out);
+    if (err == hipSuccess) err = hipEventRecord(q.ev_chunk[out_chunks.size()], s_out);
     out_chunks.push_back({lo, hi});
   }
   }
@@ -1920,8 +1929,11 @@ extern "C" int rpsf_apply_host_saturated(rpsf_plan* p, const void* image_host, i
   const long PH = (long)H + 4L * N, PW = (long)W + 4L * N;
   if (PH * PW >= ((long)1 << 31)) return fail(RPSF_E_UNSUPPORTED, "padded frame too large for this entry point");
   // rows of the padded frame the patches read, and the geometry of the correction on it
-  const int r_lo = (int)std::max<long>(0, 2L * N + std::min(0, p->corner_min[0])), r_hi = (int)std::min<long>(PH, 2L * N + p->corner_max[0] + N);
-  rpsf_geometry g{(int)PH, (int)PW, RPSF_PAD_CONSTANT, 0.f, 2 * N, 2 * N, r_lo, r_hi - r_lo, (int)PW, 2 * N, H, (int)PW};
+  // (the hipFFT fallback for patch sizes without a compiled plan takes whole frames only)
+  const int r_lo = p->generic ? 0 : (int)std::max<long>(0, 2L * N + std::min(0, p->corner_min[0]));
+  const int r_hi = p->generic ? (int)PH : (int)std::min<long>(PH, 2L * N + p->corner_max[0] + N);
+  const int o_lo = p->generic ? 0 : 2 * N, o_rows = p->generic ? (int)PH : H;  // output rows the device hands back
+  rpsf_geometry g{(int)PH, (int)PW, RPSF_PAD_CONSTANT, 0.f, 2 * N, 2 * N, r_lo, r_hi - r_lo, (int)PW, o_lo, o_rows, (int)PW};
   int rc = check_geometry(p, &g);
   if (rc != RPSF_OK) return rc;
   HIP_TRY(hipSetDevice(p->device));
@@ -2008,7 +2020,7 @@ extern "C" int rpsf_apply_host_saturated(rpsf_plan* p, const void* image_host, i
     }
   }
   // ---- the correction of the padded frame (rows the patches read in, the caller's rows out)
-  const size_t in_lo = (size_t)r_lo * PW, in_hi = (size_t)r_hi * PW, out_lo = (size_t)2 * N * PW, out_hi = out_lo + (size_t)H * PW;
+  const size_t in_lo = (size_t)r_lo * PW, in_hi = (size_t)r_hi * PW, out_lo = (size_t)o_lo * PW, out_hi = out_lo + (size_t)o_rows * PW;
   const int T = host_parts_for((in_hi - in_lo) * sizeof(float));
   pool.run(T, [&](int t) {
     size_t a, b;
@@ -2025,7 +2037,7 @@ extern "C" int rpsf_apply_host_saturated(rpsf_plan* p, const void* image_host, i
   pool.run(rows_parts, [&](int part) {
     const long ra = (long)H * part / rows_parts, rb = (long)H * (part + 1) / rows_parts;
     for (long r = ra; r < rb; ++r) {
-      const float* src = q.h_out[0] + out_lo + (size_t)r * PW + 2 * N;
+      const float* src = q.h_out[0] + (size_t)(2 * N + r) * PW + 2 * N;  // (h_out is indexed by rows of the padded frame)
       if (out_is_f64) {
         double* dst = static_cast<double*>(out_host) + (size_t)r * W;
         for (long c = 0; c < W; ++c) dst[c] = (double)src[c];
