@@ -1756,15 +1756,39 @@ static int host_frames(rpsf_plan* p, const void* const* images, int in_f64, void
   auto ms_since = [&](std::chrono::steady_clock::time_point t0) {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   };
+  // enqueue group `grp` (staged in slot grp % depth): H2D -> shared-K launch -> D2H on the three streams
+  auto enqueue = [&](int grp) {
+    const int sg = grp % depth, fg = frames_of(grp);
+    const size_t gb = (size_t)fg * bytes;
+    if (direct_in) {
+      for (int f = 0; f < fg && err == hipSuccess; ++f)
+        err = hipMemcpyAsync(q.d_in[sg] + (size_t)f * count, images[grp * G + f], bytes, hipMemcpyHostToDevice, q.st_in);
+    } else {
+      err = hipMemcpyAsync(q.d_in[sg], q.h_in[sg], gb, hipMemcpyHostToDevice, q.st_in);
+    }
+    if (err == hipSuccess) err = hipEventRecord(q.ev_in[sg], q.st_in);
+    if (err == hipSuccess) err = hipStreamWaitEvent(p->stream, q.ev_in[sg], 0);
+    if (err == hipSuccess && launch_batch(p, q.d_in[sg], q.d_out[sg], fg, count, count, g, p->stream) != RPSF_OK) err = hipErrorUnknown;
+    if (err == hipSuccess) err = hipEventRecord(q.ev_k[sg], p->stream);
+    if (err == hipSuccess) err = hipStreamWaitEvent(q.st_out, q.ev_k[sg], 0);
+    if (direct_out) {
+      for (int f = 0; f < fg && err == hipSuccess; ++f)
+        err = hipMemcpyAsync(outs[grp * G + f], q.d_out[sg] + (size_t)f * count, bytes, hipMemcpyDeviceToHost, q.st_out);
+    } else if (err == hipSuccess) {
+      err = hipMemcpyAsync(q.h_out[sg], q.d_out[sg], gb, hipMemcpyDeviceToHost, q.st_out);
+    }
+    if (err == hipSuccess) err = hipEventRecord(q.ev_out[sg], q.st_out);
+  };
+  int staged = -1, next_enq = 0;  // a group that is staged but not yet enqueued: its enqueue runs on this thread WHILE the workers do the next job
   while (next_out < n_groups && err == hipSuccess) {
     auto t_phase = std::chrono::steady_clock::now();
     const bool can_in = next_in < n_groups && next_in - next_out < depth;
     bool out_ready = false;
-    if (next_out < next_in) {
+    if (next_out < next_enq) {
       const hipError_t qe = hipEventQuery(q.ev_out[next_out % depth]);
       if (qe == hipSuccess) out_ready = true;
       else if (qe != hipErrorNotReady) err = qe;
-      if (err == hipSuccess && !out_ready && !can_in) {  // nothing to stage: wait for the oldest group in flight
+      if (err == hipSuccess && !out_ready && !can_in && staged < 0) {  // nothing to stage or enqueue: wait for the oldest group in flight
         err = hipEventSynchronize(q.ev_out[next_out % depth]);
         out_ready = err == hipSuccess;
       }
@@ -1774,49 +1798,38 @@ static int host_frames(rpsf_plan* p, const void* const* images, int in_f64, void
     const int si = next_in % depth, so = next_out % depth;
     const int fi = can_in ? frames_of(next_in) : 0, fo = out_ready ? frames_of(next_out) : 0;
     const int ci = direct_in ? 0 : fi, co = direct_out ? 0 : fo;  // frames this job stages / unstages
-    if (ci + co > 0)
-      pool.run(T, [&](int t) {
-        // the group's frames laid end to end, cut into T parts: a part covers a run of pixels that may span frames
-        const size_t total_in = (size_t)ci * count, total_out = (size_t)co * count;
-        size_t a, b;
-        rpsf_host::split_range(0, total_in, t, T, a, b);
-        while (a < b) {
-          const size_t f = a / count, lo = a % count, hi = std::min(count, lo + (b - a));
-          rpsf_host::narrow_or_copy(q.h_in[si] + f * count, images[next_in * G + f], in_f64 != 0, lo, hi);
-          a += hi - lo;
-        }
-        rpsf_host::split_range(0, total_out, t, T, a, b);
-        while (a < b) {
-          const size_t f = a / count, lo = a % count, hi = std::min(count, lo + (b - a));
-          rpsf_host::widen_or_copy(outs[next_out * G + f], out_f64 != 0, q.h_out[so] + f * count, lo, hi);
-          a += hi - lo;
-        }
-      });
-    t_jobs += ms_since(t_phase), t_phase = std::chrono::steady_clock::now();
-    if (can_in) {
-      const size_t gb = (size_t)fi * bytes;
-      if (direct_in) {
-        for (int f = 0; f < fi && err == hipSuccess; ++f)
-          err = hipMemcpyAsync(q.d_in[si] + (size_t)f * count, images[next_in * G + f], bytes, hipMemcpyHostToDevice, q.st_in);
-      } else {
-        err = hipMemcpyAsync(q.d_in[si], q.h_in[si], gb, hipMemcpyHostToDevice, q.st_in);
-      }
-      if (err == hipSuccess) err = hipEventRecord(q.ev_in[si], q.st_in);
-      if (err == hipSuccess) err = hipStreamWaitEvent(p->stream, q.ev_in[si], 0);
-      if (err == hipSuccess && launch_batch(p, q.d_in[si], q.d_out[si], fi, count, count, g, p->stream) != RPSF_OK) err = hipErrorUnknown;
-      if (err == hipSuccess) err = hipEventRecord(q.ev_k[si], p->stream);
-      if (err == hipSuccess) err = hipStreamWaitEvent(q.st_out, q.ev_k[si], 0);
-      if (direct_out) {
-        for (int f = 0; f < fi && err == hipSuccess; ++f)
-          err = hipMemcpyAsync(outs[next_in * G + f], q.d_out[si] + (size_t)f * count, bytes, hipMemcpyDeviceToHost, q.st_out);
-      } else if (err == hipSuccess) {
-        err = hipMemcpyAsync(q.h_out[si], q.d_out[si], gb, hipMemcpyDeviceToHost, q.st_out);
-      }
-      if (err == hipSuccess) err = hipEventRecord(q.ev_out[si], q.st_out);
-      ++next_in;
-    }
+    const int to_enqueue = staged;
+    double t_meanwhile = 0.0;
+    pool.run(ci + co > 0 ? T : 0,
+             [&](int t) {
+               // the group's frames laid end to end, cut into T parts: a part covers a run of pixels that may span frames
+               const size_t total_in = (size_t)ci * count, total_out = (size_t)co * count;
+               size_t a, b;
+               rpsf_host::split_range(0, total_in, t, T, a, b);
+               while (a < b) {
+                 const size_t f = a / count, lo = a % count, hi = std::min(count, lo + (b - a));
+                 rpsf_host::narrow_or_copy(q.h_in[si] + f * count, images[next_in * G + f], in_f64 != 0, lo, hi);
+                 a += hi - lo;
+               }
+               rpsf_host::split_range(0, total_out, t, T, a, b);
+               while (a < b) {
+                 const size_t f = a / count, lo = a % count, hi = std::min(count, lo + (b - a));
+                 rpsf_host::widen_or_copy(outs[next_out * G + f], out_f64 != 0, q.h_out[so] + f * count, lo, hi);
+                 a += hi - lo;
+               }
+             },
+             [&] {
+               if (to_enqueue >= 0) {
+                 const auto t0 = std::chrono::steady_clock::now();
+                 enqueue(to_enqueue);
+                 t_meanwhile = ms_since(t0);
+               }
+             });
+    if (to_enqueue >= 0) staged = -1, next_enq = to_enqueue + 1;
+    t_enqueue += t_meanwhile;
+    t_jobs += ms_since(t_phase) - t_meanwhile;
+    if (can_in) staged = next_in++;
     if (out_ready) ++next_out;
-    t_enqueue += ms_since(t_phase);
   }
   if (trace)
     std::fprintf(stderr, "[rpsf streamed] %d frames in %d groups of %d, depth %d, %d parts per job: staging jobs %.3f ms, enqueues %.3f ms, waits %.3f ms, total %.3f ms\n",

@@ -50,8 +50,17 @@ class HostPool {
 
   template <class F>
   void run(int parts, F&& fn) {
-    if (parts <= 0) return;
+    run(parts, fn, [] {});
+  }
+  // ... with something for the calling thread to do while the workers are at it (the streamed path enqueues the previous group's copies and launch)
+  template <class F, class M>
+  void run(int parts, F&& fn, M&& meanwhile) {
+    if (parts <= 0) {
+      meanwhile();
+      return;
+    }
     if (parts == 1 || n_workers_ == 0) {
+      meanwhile();
       for (int i = 0; i < parts; ++i) fn(i);
       return;
     }
@@ -65,6 +74,7 @@ class HostPool {
       std::lock_guard<std::mutex> lock(sleep_);
       wake_.notify_all();
     }
+    meanwhile();
     // The caller does not take parts itself: it is wherever the application's thread happens to run - on the two-socket hosts often
     // the socket away from the GPU, where one part takes several times as long as on a worker and the whole job waits for it
     // (profiles/r05e: 53 us per 4 MiB chunk with the caller working, against 20 us without).
