@@ -586,8 +586,26 @@ def test_integration_stub_call_sequence():
     rc = lib.rpsf_apply_host(handle, img.ctypes.data_as(ctypes.c_void_p), 1, img.shape[0], img.shape[1], pad,
                              ctypes.c_float(0.0), out.ctypes.data_as(ctypes.c_void_p), 1)
     assert rc == 0, lib.rpsf_last_error()
-    lib.rpsf_plan_destroy(handle)
     check(out, fx["expected"])
+    # ... the saturation branch in one call (apply_saturated of the stub) ...
+    hot = img.copy()
+    hot[10, 12] = hot[40, 3] = 1.0e6
+    sat = np.empty_like(hot)
+    rc = lib.rpsf_apply_host_saturated(handle, hot.ctypes.data_as(ctypes.c_void_p), 1, hot.shape[0], hot.shape[1], pad, ctypes.c_double(5.0e5), 1, 7,
+                                       sat.ctypes.data_as(ctypes.c_void_p), 1)
+    assert rc == 0, lib.rpsf_last_error()
+    check(sat, orc.apply_transfer(hot, coords, k, pad_mode=str(fx["pad_mode"]), saturation_threshold=5.0e5))
+    assert sat[10, 12] == 1.0e6
+    # ... and the streamed loop over frames (apply_many of the stub)
+    frames = [img, img[::-1].copy(), img * 2.0]
+    stack = np.empty((3, *img.shape))
+    ins = (ctypes.c_void_p * 3)(*[f.ctypes.data for f in frames])
+    outs = (ctypes.c_void_p * 3)(*[stack[i].ctypes.data for i in range(3)])
+    rc = lib.rpsf_apply_frames_host(handle, ins, 1, 3, img.shape[0], img.shape[1], pad, ctypes.c_float(0.0), outs, 1)
+    assert rc == 0, lib.rpsf_last_error()
+    assert np.array_equal(stack[0], out)
+    check(stack[1], orc.apply_transfer(frames[1], coords, k, pad_mode=str(fx["pad_mode"])))
+    lib.rpsf_plan_destroy(handle)
 
 
 # ------------------------------------------------------------------ round 2: configs at full size, precision, seams, files
