@@ -101,7 +101,7 @@ struct rpsf_plan {
   std::vector<rpsf_plan*> bands;          // parent: its row-band views
   std::vector<int> band_rows;             // bands.size() + 1 output row boundaries
   std::vector<int> band_in_rows;          // per band: image rows [0, band_in_rows[b]) must be resident before it runs
-  int bands_h = 0, bands_w = 0, bands_mode = -1;
+  int bands_h = 0, bands_w = 0, bands_mode = -1, bands_want = -1;
   bool have_k = false;
   hipStream_t stream = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -755,7 +755,7 @@ extern "C" void rpsf_plan_destroy(rpsf_plan* p) {
 static void drop_bands(rpsf_plan* p) {
   for (rpsf_plan* band : p->bands) rpsf_plan_destroy(band);
   p->bands.clear(), p->band_rows.clear(), p->band_in_rows.clear();
-  p->bands_h = p->bands_w = 0, p->bands_mode = -1;
+  p->bands_h = p->bands_w = 0, p->bands_mode = -1, p->bands_want = -1;
 }
 
 static int pack_range(rpsf_plan* p, const cf* d_kfull, int first_patch, int count) {
@@ -1533,9 +1533,9 @@ static int drain_after_error(rpsf_plan* p, hipError_t err, const char* where) {
 // image rows its patches read are on the device, and its rows can leave while the next band is still arriving: upload, patches and download
 // of one frame overlap.  Returns the number of bands (0: this plan / frame is not cut - the caller takes the whole-frame path).
 static int ensure_bands(rpsf_plan* p, const rpsf_geometry& g, int want) {
-  if (p->bands_h == g.height && p->bands_w == g.width && p->bands_mode == g.pad_mode) return (int)p->bands.size();
+  if (p->bands_h == g.height && p->bands_w == g.width && p->bands_mode == g.pad_mode && p->bands_want == want) return (int)p->bands.size();
   drop_bands(p);
-  p->bands_h = g.height, p->bands_w = g.width, p->bands_mode = g.pad_mode;  // (remembered also when the answer is "no bands")
+  p->bands_h = g.height, p->bands_w = g.width, p->bands_mode = g.pad_mode, p->bands_want = want;  // (remembered also when the answer is "no bands")
   if (p->generic || p->parent || !p->lattice || overlap_kind(p) != OV_PLANES || g.pad_mode == RPSF_PAD_WRAP || want < 2) return 0;
   const int N = p->N, H = g.height;
   std::vector<int> rows;
