@@ -509,10 +509,12 @@ def main() -> None:
                          "apply after the other, which is also what roofline.frac is always computed on")
     ap.add_argument("--no-overlap", action="store_true",
                     help="--seam exchange: plain apply -> send/recv -> add on one stream (same as --exchange-mode plain)")
-    ap.add_argument("--exchange-mode", choices=["pipeline", "two-plans", "plain"], default="pipeline",
-                    help="how the seam exchange is overlapped: 'pipeline' (default) - one launch per step, the send / recv / add of step k on "
-                         "the exchange stream beside the launch of step k + 1; 'two-plans' - the band's last lattice row as a plan of its own, "
-                         "its rows sent beside the rest of the same step's band; 'plain' - apply -> send/recv -> add in sequence")
+    ap.add_argument("--exchange-mode", choices=["pipeline", "two-plans", "plain"], default="plain",
+                    help="how the seam exchange is run: 'plain' (default: the fewest moving parts for the first run on a real multi-GPU node) - "
+                         "apply -> ncclSend / ncclRecv -> K4 add in sequence on the plan's stream; 'pipeline' - one launch per step, the send / recv / add "
+                         "of step k on a CU-masked exchange stream beside the launch of step k + 1 (projected 5.2x against 4.5x with a real link's "
+                         "latency, DESIGN.md 7); 'two-plans' - the band's last lattice row as a plan of its own, its rows sent beside the rest of the "
+                         "same step's band")
     ap.add_argument("--seam", choices=["recompute", "exchange"], default="recompute",
                     help="N > 1: 'recompute' (default) - every band also runs the lattice row above it that reaches into its rows and "
                          "the bands are cut so that own + recomputed patches balance (585 per rank at eight bands of the 8192-wide "
