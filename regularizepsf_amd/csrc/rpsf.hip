@@ -1735,8 +1735,24 @@ static int host_frames(rpsf_plan* p, const void* const* images, int in_f64, void
                        const rpsf_geometry& g) {
   if (n_frames == 1) return host_one_frame(p, images[0], in_f64, outs[0], out_f64, g);
   const size_t count = (size_t)g.height * g.width, bytes = count * sizeof(float);
-  const int G = stream_group_frames(bytes, n_frames);
-  const int n_groups = (n_frames + G - 1) / G;
+  // Groups: `first[i]` ... `first[i + 1]` are the frames of group i.  Small frames: equal groups.  Frames that go one by one (16 MiB and more) go two
+  // by two in the MIDDLE of a long sequence - a staging job and an enqueue per two frames instead of per frame: 32 x 2048^2 float32 0.473 -> 0.415 ms
+  // per frame - while the first and the last groups stay single frames, so that the ramps (the first upload, the last download) stay short
+  // (groups of two throughout cost an 8-frame batch 0.48 -> 0.57 ms per frame; profiles/r05y).  RPSF_STREAM_GROUP fixes one size for all.
+  const int G0 = stream_group_frames(bytes, n_frames);
+  std::vector<int> first{0};
+  {
+    const bool pinned_size = std::getenv("RPSF_STREAM_GROUP") != nullptr;
+    const bool pairs = !pinned_size && G0 == 1 && n_frames >= 12 && bytes * 2 <= ((size_t)128 << 20);
+    while (first.back() < n_frames) {
+      const int at = first.back(), left = n_frames - at;
+      const int size = pairs ? ((at >= 2 && left >= 4) ? 2 : 1) : G0;
+      first.push_back(at + std::min(size, left));
+    }
+  }
+  const int n_groups = (int)first.size() - 1;
+  int G = 1;
+  for (int i = 0; i < n_groups; ++i) G = std::max(G, first[i + 1] - first[i]);
   int depth = bytes * G >= ((size_t)128 << 20) ? 3 : HostPipe::MAX_DEPTH;
   if (const char* e = std::getenv("RPSF_STREAM_DEPTH")) depth = std::max(1, std::min((int)HostPipe::MAX_DEPTH, std::atoi(e)));
   depth = std::min(depth, n_groups);
@@ -1745,7 +1761,7 @@ static int host_frames(rpsf_plan* p, const void* const* images, int in_f64, void
   HostPipe& q = *p->pipe;
   HostPool& pool = HostPool::get(p->device);
   const int T = host_parts_for(bytes * G);  // (a job stages / unstages a whole group: small frames still give every worker a part)
-  auto frames_of = [&](int grp) { return std::min(G, n_frames - grp * G); };
+  auto frames_of = [&](int grp) { return first[grp + 1] - first[grp]; };
   const bool direct_in = !in_f64 && all_pinned(images, n_frames);
   const bool direct_out = !out_f64 && all_pinned(const_cast<const void* const*>(outs), n_frames);
   hipError_t err = hipSuccess;
@@ -1762,7 +1778,7 @@ static int host_frames(rpsf_plan* p, const void* const* images, int in_f64, void
     const size_t gb = (size_t)fg * bytes;
     if (direct_in) {
       for (int f = 0; f < fg && err == hipSuccess; ++f)
-        err = hipMemcpyAsync(q.d_in[sg] + (size_t)f * count, images[grp * G + f], bytes, hipMemcpyHostToDevice, q.st_in);
+        err = hipMemcpyAsync(q.d_in[sg] + (size_t)f * count, images[first[grp] + f], bytes, hipMemcpyHostToDevice, q.st_in);
     } else {
       err = hipMemcpyAsync(q.d_in[sg], q.h_in[sg], gb, hipMemcpyHostToDevice, q.st_in);
     }
@@ -1773,7 +1789,7 @@ static int host_frames(rpsf_plan* p, const void* const* images, int in_f64, void
     if (err == hipSuccess) err = hipStreamWaitEvent(q.st_out, q.ev_k[sg], 0);
     if (direct_out) {
       for (int f = 0; f < fg && err == hipSuccess; ++f)
-        err = hipMemcpyAsync(outs[grp * G + f], q.d_out[sg] + (size_t)f * count, bytes, hipMemcpyDeviceToHost, q.st_out);
+        err = hipMemcpyAsync(outs[first[grp] + f], q.d_out[sg] + (size_t)f * count, bytes, hipMemcpyDeviceToHost, q.st_out);
     } else if (err == hipSuccess) {
       err = hipMemcpyAsync(q.h_out[sg], q.d_out[sg], gb, hipMemcpyDeviceToHost, q.st_out);
     }
@@ -1808,13 +1824,13 @@ static int host_frames(rpsf_plan* p, const void* const* images, int in_f64, void
                rpsf_host::split_range(0, total_in, t, T, a, b);
                while (a < b) {
                  const size_t f = a / count, lo = a % count, hi = std::min(count, lo + (b - a));
-                 rpsf_host::narrow_or_copy(q.h_in[si] + f * count, images[next_in * G + f], in_f64 != 0, lo, hi);
+                 rpsf_host::narrow_or_copy(q.h_in[si] + f * count, images[first[next_in] + f], in_f64 != 0, lo, hi);
                  a += hi - lo;
                }
                rpsf_host::split_range(0, total_out, t, T, a, b);
                while (a < b) {
                  const size_t f = a / count, lo = a % count, hi = std::min(count, lo + (b - a));
-                 rpsf_host::widen_or_copy(outs[next_out * G + f], out_f64 != 0, q.h_out[so] + f * count, lo, hi);
+                 rpsf_host::widen_or_copy(outs[first[next_out] + f], out_f64 != 0, q.h_out[so] + f * count, lo, hi);
                  a += hi - lo;
                }
              },
@@ -1832,7 +1848,7 @@ static int host_frames(rpsf_plan* p, const void* const* images, int in_f64, void
     if (out_ready) ++next_out;
   }
   if (trace)
-    std::fprintf(stderr, "[rpsf streamed] %d frames in %d groups of %d, depth %d, %d parts per job: staging jobs %.3f ms, enqueues %.3f ms, waits %.3f ms, total %.3f ms\n",
+    std::fprintf(stderr, "[rpsf streamed] %d frames in %d groups of up to %d, depth %d, %d parts per job: staging jobs %.3f ms, enqueues %.3f ms, waits %.3f ms, total %.3f ms\n",
                  n_frames, n_groups, G, depth, T, t_jobs, t_enqueue, t_wait, ms_since(t_start));
   if (err != hipSuccess) return drain_after_error(p, err, "streamed frames");
   return RPSF_OK;

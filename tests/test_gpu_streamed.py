@@ -194,3 +194,15 @@ def test_a_large_frame_cut_into_row_bands_is_bit_identical_to_the_whole_frame(n,
     small = np.ascontiguousarray(image[: shape[0] - n // 2, : shape[1] - n // 2])
     check(t.apply(small, pad_mode=pad_mode), orc.apply_transfer(small, coords, k, pad_mode=pad_mode, workers=-1))
     assert np.array_equal(t.apply(image, pad_mode=pad_mode), whole)
+
+
+def test_long_sequences_of_large_frames_go_two_by_two_in_the_middle():
+    """From twelve frames of more than 8 MiB on, the groups in the middle of the sequence hold two frames (a staging job and an enqueue per two
+    frames), the first and last ones a single frame: 13 frames of 1536^2 (groups 1 1 2 2 2 2 1 1 1), float32 and float64 out - the loop's pixels,
+    bit for bit, every frame in its place."""
+    coords, k, images = _case(128, (1536, 1536), 13, 77)
+    t = rp.ArrayPSFTransform(rp.IndexedCube(coords, k))
+    loop = np.stack([t.apply(im) for im in images])
+    assert np.array_equal(t.apply_batch(images), loop)
+    assert np.array_equal(t.apply_batch(list(images), dtype=np.float32), loop.astype(np.float32))
+    check(loop[12], orc.apply_transfer(images[12], coords, k, workers=-1))
