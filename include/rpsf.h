@@ -147,6 +147,12 @@ int rpsf_apply_host(rpsf_plan* plan, const void* image_host, int image_is_f64, i
  * PCIe.  (dilation < 1, negative widths and np.pad modes the kernel does not know stay with the Python layer's NumPy route.) */
 int rpsf_apply_host_saturated(rpsf_plan* plan, const void* image_host, int image_is_f64, int height, int width, int pad_mode,
                               double threshold, int dilation, int neighborhood_width, void* out_host, int out_is_f64);
+/* The same for a sequence of frames of one shape, one pointer per frame - the reference's example corrects a list of frames this way
+ * (`[transform.apply(image, saturation_threshold=...) for image in images]`, docs/source/example.ipynb cell 25): the host steps of
+ * frame i + 1 run while the GPU corrects frame i (two staging slots in turn). */
+int rpsf_apply_frames_host_saturated(rpsf_plan* plan, const void* const* images_host, int image_is_f64, int n_frames, int height,
+                                     int width, int pad_mode, double threshold, int dilation, int neighborhood_width,
+                                     void* const* outs_host, int out_is_f64);
 /* Same with image and output already resident on the plan's device; asynchronous on `stream`
  * (a hipStream_t, or NULL for the plan's own stream).  Every pixel of the resident output rows is written
  * (uncovered ones with 0).  image_dev / out_dev must be ordinary device memory of the plan's device

@@ -68,6 +68,7 @@ _PROTOTYPES = {
     "rpsf_apply": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "rpsf_apply_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int]),
     "rpsf_apply_host_saturated": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_double, c_int, c_int, c_void_p, c_int]),
+    "rpsf_apply_frames_host_saturated": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_double, c_int, c_int, c_void_p, c_int]),
     "rpsf_apply_device": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(Geometry), c_void_p]),
     "rpsf_apply_device_timed": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(Geometry), c_int, c_void_p, c_void_p]),
     "rpsf_apply_batch": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
@@ -299,6 +300,24 @@ class Plan:
         check(lib().rpsf_apply_host_saturated(self._handle, _ptr(img), int(img.dtype == np.float64), img.shape[0], img.shape[1], pad_mode,
                                               float(threshold), int(dilation), int(neighborhood_width), _ptr(out),
                                               int(np.dtype(out_dtype) == np.float64)))
+        return out
+
+    def apply_frames_host_saturated(self, images, pad_mode: int, threshold: float, dilation: int, neighborhood_width: int,
+                                    out_dtype=np.float64) -> np.ndarray:
+        """A sequence of equally shaped frames through the saturation branch: the host steps of frame i + 1 overlap the GPU's work on frame i."""
+        frames = [np.asarray(im) for im in images]
+        if not frames or any(f.ndim != 2 or f.shape != frames[0].shape for f in frames):
+            msg = "frames must be two dimensional and of one shape"
+            raise ValueError(msg)
+        is_f32 = all(f.dtype == np.float32 for f in frames)
+        want = np.float32 if is_f32 else np.float64
+        frames = [np.ascontiguousarray(f if f.dtype == want and f.dtype.byteorder != ">" else f.astype(want)) for f in frames]
+        n, shape = len(frames), frames[0].shape
+        out = np.empty((n, *shape), out_dtype)
+        in_ptrs = (c_void_p * n)(*[f.ctypes.data for f in frames])
+        out_ptrs = (c_void_p * n)(*[out[i].ctypes.data for i in range(n)])
+        check(lib().rpsf_apply_frames_host_saturated(self._handle, in_ptrs, int(not is_f32), n, shape[0], shape[1], pad_mode, float(threshold),
+                                                     int(dilation), int(neighborhood_width), out_ptrs, int(np.dtype(out_dtype) == np.float64)))
         return out
 
     def apply_device(self, image_ptr: c_void_p, out_ptr: c_void_p, geometry: Geometry, stream: c_void_p | None = None) -> None:

@@ -78,6 +78,17 @@ struct DevBuf {
 };
 
 
+// Host scratch of the saturation branch (rpsf_apply_host_saturated), per staging slot, kept between calls
+struct SatScratch {
+  std::vector<double> padded;
+  std::vector<uint8_t> mask;
+  struct Raw {
+    int64_t idx;
+    double value;
+  };
+  std::vector<Raw> raw;
+};
+
 // ------------------------------------------------------------------------------------------------
 // plan
 // ------------------------------------------------------------------------------------------------
@@ -94,8 +105,7 @@ struct rpsf_plan {
   // Views: a plan over a subset of another plan's patches that shares its tables, its packed K (desc.z = the patch's index in the
   // parent) and its stream - the row bands a single large host frame is cut into so that its upload, its patches and its download
   // overlap (host_one_frame).  Owned by the parent, built for one frame shape.
-  std::vector<double> sat_padded;   // rpsf_apply_host_saturated: the 2N-padded float64 frame and its mask (host scratch, kept between calls)
-  std::vector<uint8_t> sat_mask;
+  std::vector<SatScratch> sat;  // rpsf_apply_host_saturated: per staging slot, the 2N-padded float64 frame, its mask and the raw values (host scratch, kept between calls)
   rpsf_plan* parent = nullptr;
   std::vector<int32_t> k_index;           // view: patch i of this plan is patch k_index[i] of the parent
   std::vector<rpsf_plan*> bands;          // parent: its row-band views
@@ -1743,7 +1753,9 @@ static int host_frames(rpsf_plan* p, const void* const* images, int in_f64, void
   std::vector<int> first{0};
   {
     const bool pinned_size = std::getenv("RPSF_STREAM_GROUP") != nullptr;
-    const bool pairs = !pinned_size && G0 == 1 && n_frames >= 12 && bytes * 2 <= ((size_t)128 << 20);
+    int pairs_from = 12;
+    if (const char* e = std::getenv("RPSF_STREAM_PAIRS_FROM")) pairs_from = std::max(4, std::atoi(e));  // development sweeps
+    const bool pairs = !pinned_size && G0 == 1 && n_frames >= pairs_from && bytes * 2 <= ((size_t)128 << 20);
     while (first.back() < n_frames) {
       const int at = first.back(), left = n_frames - at;
       const int size = pairs ? ((at >= 2 && left >= 4) ? 2 : 1) : G0;
@@ -1946,140 +1958,205 @@ extern "C" int rpsf_device_numa_node(int device, int* node) {
 // crop.  Everything the reference does on the host stays on the host and in its order; what changed against the NumPy / SciPy route of rounds 1-4
 // is the cost: no np.pad / astype / copy temporaries (three passes over a (H + 4N)^2 float64 frame), no scipy.ndimage pass over the whole mask for
 // a handful of pixels, no device allocation per call, only the rows the patches read and the rows the caller gets cross PCIe.
+// A sequence of frames (rpsf_apply_frames_host_saturated - the reference's example corrects a list of frames this way, docs/source/example.ipynb
+// cell 25) alternates between two staging slots: the host steps of frame i + 1 run while the GPU corrects frame i.
 // ------------------------------------------------------------------------------------------------
-extern "C" int rpsf_apply_host_saturated(rpsf_plan* p, const void* image_host, int image_is_f64, int height, int width, int pad_mode,
-                                         double threshold, int dilation, int neighborhood_width, void* out_host, int out_is_f64) {
-  if (!p || !image_host || !out_host) return fail(RPSF_E_BADARG, "null argument");
+struct SatRun {
+  rpsf_plan* p;
+  int H, W, N, pad_mode, dilation, width, in_f64, out_f64;
+  double threshold;
+  long PH, PW;
+  int r_lo, r_hi, o_lo, o_rows;
+  rpsf_geometry g;
+  std::vector<int> colmap;
+
+  int init(rpsf_plan* plan, int height, int w, int mode, double thr, int dil, int nbw, int image_is_f64, int out_is_f64, int slots) {
+    p = plan, H = height, W = w, N = plan->N, pad_mode = mode, dilation = dil, width = nbw, in_f64 = image_is_f64, out_f64 = out_is_f64, threshold = thr;
+    PH = (long)H + 4L * N, PW = (long)W + 4L * N;
+    if (PH * PW >= ((long)1 << 31)) return fail(RPSF_E_UNSUPPORTED, "padded frame too large for this entry point");
+    // rows of the padded frame the patches read, and the geometry of the correction on it (the hipFFT fallback takes whole frames only)
+    r_lo = p->generic ? 0 : (int)std::max<long>(0, 2L * N + std::min(0, p->corner_min[0]));
+    r_hi = p->generic ? (int)PH : (int)std::min<long>(PH, 2L * N + p->corner_max[0] + N);
+    o_lo = p->generic ? 0 : 2 * N, o_rows = p->generic ? (int)PH : H;  // output rows the device hands back
+    g = rpsf_geometry{(int)PH, (int)PW, RPSF_PAD_CONSTANT, 0.f, 2 * N, 2 * N, r_lo, r_hi - r_lo, (int)PW, o_lo, o_rows, (int)PW};
+    int rc = check_geometry(p, &g);
+    if (rc != RPSF_OK) return rc;
+    HIP_TRY(hipSetDevice(p->device));
+    rc = pipe_ensure(p, (size_t)PH * PW, slots);
+    if (rc != RPSF_OK) return rc;
+    if ((int)p->sat.size() < slots) p->sat.resize(slots);
+    colmap.resize(PW);
+    for (long c = 0; c < PW; ++c) colmap[c] = pad_index((int)(c - 2L * N), W, pad_mode);
+    return RPSF_OK;
+  }
+
+  // host steps of one frame into slot s (pad, threshold, dilation, raw values, NaN, sequential fill, narrowing into the pinned staging)
+  void prepare(int s, const void* image_host) {
+    HostPipe& q = *p->pipe;
+    HostPool& pool = HostPool::get(p->device);
+    SatScratch& sc = p->sat[s];
+    sc.padded.resize((size_t)PH * PW);
+    sc.mask.assign((size_t)PH * PW, 0);
+    sc.raw.clear();
+    double* const padded = sc.padded.data();
+    uint8_t* const mask = sc.mask.data();
+    const int parts = (int)std::min<long>(PH, (long)pool.width() * 4);
+    std::vector<std::vector<int64_t>> hot(parts);  // per part: flat indices of the pixels above the threshold
+    // ---- pad (:119-123) + threshold (:129), row blocks in parallel
+    pool.run(parts, [&](int part) {
+      const long ra = PH * part / parts, rb = PH * (part + 1) / parts;
+      for (long r = ra; r < rb; ++r) {
+        const int sr = pad_index((int)(r - 2L * N), H, pad_mode);
+        double* dst = padded + r * PW;
+        if (sr < 0) {
+          for (long c = 0; c < PW; ++c) dst[c] = 0.0;  // np.pad(mode="constant") pads with 0
+        } else if (in_f64) {
+          const double* src = static_cast<const double*>(image_host) + (size_t)sr * W;
+          for (long c = 0; c < PW; ++c) dst[c] = colmap[c] < 0 ? 0.0 : src[colmap[c]];
+        } else {
+          const float* src = static_cast<const float*>(image_host) + (size_t)sr * W;
+          for (long c = 0; c < PW; ++c) dst[c] = colmap[c] < 0 ? 0.0 : (double)src[colmap[c]];
+        }
+        for (long c = 0; c < PW; ++c)
+          if (dst[c] > threshold) hot[part].push_back(r * PW + c);
+      }
+    });
+    // ---- dilation (:133): every pixel within `dilation` city-block steps of a saturated one
+    std::vector<uint8_t> row_has(PH, 0);
+    size_t n_hot = 0;
+    for (const auto& list : hot) {
+      n_hot += list.size();
+      for (const int64_t idx : list) {
+        const long r = idx / PW, c = idx % PW;
+        for (long dr = -dilation; dr <= dilation; ++dr) {
+          const long rr = r + dr;
+          if (rr < 0 || rr >= PH) continue;
+          const long span = dilation - std::labs(dr);
+          const long c0 = std::max<long>(0, c - span), c1 = std::min<long>(PW - 1, c + span);
+          std::memset(mask + rr * PW + c0, 1, (size_t)(c1 - c0 + 1));
+          row_has[rr] = 1;
+        }
+      }
+    }
+    // ---- raw values of the masked pixels the caller will see (:126, :172), NaN (:134), sequential fill (:135-138)
+    if (n_hot) {
+      for (long r = 0; r < PH; ++r) {
+        if (!row_has[r]) continue;
+        for (long c = 0; c < PW; ++c)
+          if (mask[r * PW + c]) {
+            if (r >= 2L * N && r < 2L * N + H && c >= 2L * N && c < 2L * N + W) sc.raw.push_back({r * PW + c, padded[r * PW + c]});
+            padded[r * PW + c] = std::nan("");
+          }
+      }
+      const long hw = width / 2;
+      for (long i = 0; i < PH; ++i) {
+        if (!row_has[i]) continue;
+        for (long j = 0; j < PW; ++j) {
+          if (!mask[i * PW + j]) continue;
+          long r0, r1, c0, c1;
+          py_slice(i - hw, i + hw, PH, &r0, &r1);
+          py_slice(j - hw, j + hw, PW, &c0, &c1);
+          double sum = 0.0;
+          long cnt = 0;
+          for (long r = r0; r < r1; ++r)
+            for (long c = c0; c < c1; ++c) {
+              const double v = padded[r * PW + c];
+              if (v == v) sum += v, ++cnt;
+            }
+          padded[i * PW + j] = cnt ? sum / (double)cnt : std::nan("");
+        }
+      }
+    }
+    const size_t in_lo = (size_t)r_lo * PW, in_hi = (size_t)r_hi * PW;
+    const int T = host_parts_for((in_hi - in_lo) * sizeof(float));
+    pool.run(T, [&](int t) {
+      size_t a, b;
+      rpsf_host::split_range(in_lo, in_hi, t, T, a, b);
+      rpsf_host::narrow_or_copy(q.h_in[s], padded, true, a, b);
+    });
+  }
+
+  // the correction of the padded frame of slot s: rows the patches read in, the caller's rows out; asynchronous on the plan's stream
+  hipError_t enqueue(int s) {
+    HostPipe& q = *p->pipe;
+    const size_t in_lo = (size_t)r_lo * PW, in_hi = (size_t)r_hi * PW, out_lo = (size_t)o_lo * PW, out_hi = out_lo + (size_t)o_rows * PW;
+    hipError_t err = hipMemcpyAsync(q.d_in[s], q.h_in[s] + in_lo, (in_hi - in_lo) * sizeof(float), hipMemcpyHostToDevice, p->stream);
+    if (err == hipSuccess && launch_apply(p, q.d_in[s], q.d_out[s], g, p->stream, nullptr) != RPSF_OK) err = hipErrorUnknown;
+    if (err == hipSuccess) err = hipMemcpyAsync(q.h_out[s] + out_lo, q.d_out[s], (out_hi - out_lo) * sizeof(float), hipMemcpyDeviceToHost, p->stream);
+    if (err == hipSuccess) err = hipEventRecord(q.ev_out[s], p->stream);
+    return err;
+  }
+
+  // wait for slot s, then the crop (:174-177) with the raw values back on the mask (:172)
+  hipError_t finish(int s, void* out_host) {
+    HostPipe& q = *p->pipe;
+    HostPool& pool = HostPool::get(p->device);
+    hipError_t err = hipEventSynchronize(q.ev_out[s]);
+    if (err != hipSuccess) return err;
+    const int rows_parts = std::min(H, pool.width() * 4);
+    pool.run(rows_parts, [&](int part) {
+      const long ra = (long)H * part / rows_parts, rb = (long)H * (part + 1) / rows_parts;
+      for (long r = ra; r < rb; ++r) {
+        const float* src = q.h_out[s] + (size_t)(2 * N + r) * PW + 2 * N;  // (h_out is indexed by rows of the padded frame)
+        if (out_f64) {
+          double* dst = static_cast<double*>(out_host) + (size_t)r * W;
+          for (long c = 0; c < W; ++c) dst[c] = (double)src[c];
+        } else {
+          std::memcpy(static_cast<float*>(out_host) + (size_t)r * W, src, (size_t)W * sizeof(float));
+        }
+      }
+    });
+    for (const SatScratch::Raw& x : p->sat[s].raw) {
+      const long r = x.idx / PW - 2L * N, c = x.idx % PW - 2L * N;
+      if (out_f64) static_cast<double*>(out_host)[(size_t)r * W + c] = x.value;
+      else static_cast<float*>(out_host)[(size_t)r * W + c] = (float)x.value;
+    }
+    return hipSuccess;
+  }
+};
+
+static int check_saturated_call(rpsf_plan* p, const void* a, const void* b, int height, int width, int pad_mode, int dilation, int neighborhood_width) {
+  if (!p || !a || !b) return fail(RPSF_E_BADARG, "null argument");
   if (height <= 0 || width <= 0) return fail(RPSF_E_BADARG, "image shape must be positive");
   if (pad_mode < 0 || pad_mode > RPSF_PAD_WRAP) return fail(RPSF_E_BADARG, "unknown pad mode");
   if (dilation < 1 || neighborhood_width < 0) return fail(RPSF_E_BADARG, "dilation must be >= 1 and the neighbourhood width >= 0 (other values: the NumPy route)");
   if (!p->have_k) return fail(RPSF_E_STATE, "no transfer kernel installed (call rpsf_plan_set_transfer first)");
-  const int N = p->N, H = height, W = width;
-  const long PH = (long)H + 4L * N, PW = (long)W + 4L * N;
-  if (PH * PW >= ((long)1 << 31)) return fail(RPSF_E_UNSUPPORTED, "padded frame too large for this entry point");
-  // rows of the padded frame the patches read, and the geometry of the correction on it
-  // (the hipFFT fallback for patch sizes without a compiled plan takes whole frames only)
-  const int r_lo = p->generic ? 0 : (int)std::max<long>(0, 2L * N + std::min(0, p->corner_min[0]));
-  const int r_hi = p->generic ? (int)PH : (int)std::min<long>(PH, 2L * N + p->corner_max[0] + N);
-  const int o_lo = p->generic ? 0 : 2 * N, o_rows = p->generic ? (int)PH : H;  // output rows the device hands back
-  rpsf_geometry g{(int)PH, (int)PW, RPSF_PAD_CONSTANT, 0.f, 2 * N, 2 * N, r_lo, r_hi - r_lo, (int)PW, o_lo, o_rows, (int)PW};
-  int rc = check_geometry(p, &g);
+  return RPSF_OK;
+}
+
+extern "C" int rpsf_apply_host_saturated(rpsf_plan* p, const void* image_host, int image_is_f64, int height, int width, int pad_mode,
+                                         double threshold, int dilation, int neighborhood_width, void* out_host, int out_is_f64) {
+  int rc = check_saturated_call(p, image_host, out_host, height, width, pad_mode, dilation, neighborhood_width);
   if (rc != RPSF_OK) return rc;
-  HIP_TRY(hipSetDevice(p->device));
-  rc = pipe_ensure(p, (size_t)PH * PW, 1);
+  SatRun run;
+  rc = run.init(p, height, width, pad_mode, threshold, dilation, neighborhood_width, image_is_f64, out_is_f64, 1);
   if (rc != RPSF_OK) return rc;
-  HostPipe& q = *p->pipe;
-  HostPool& pool = HostPool::get(p->device);
-  p->sat_padded.resize((size_t)PH * PW);
-  p->sat_mask.assign((size_t)PH * PW, 0);
-  double* const padded = p->sat_padded.data();
-  uint8_t* const mask = p->sat_mask.data();
-  std::vector<int> colmap(PW);
-  for (long c = 0; c < PW; ++c) colmap[c] = pad_index((int)(c - 2L * N), W, pad_mode);
-  const int parts = (int)std::min<long>(PH, (long)pool.width() * 4);
-  std::vector<std::vector<int64_t>> hot(parts);  // per part: flat indices of the pixels above the threshold
-  // ---- pad (:119-123) + threshold (:129), row blocks in parallel
-  pool.run(parts, [&](int part) {
-    const long ra = PH * part / parts, rb = PH * (part + 1) / parts;
-    for (long r = ra; r < rb; ++r) {
-      const int sr = pad_index((int)(r - 2L * N), H, pad_mode);
-      double* dst = padded + r * PW;
-      if (sr < 0) {
-        for (long c = 0; c < PW; ++c) dst[c] = 0.0;  // np.pad(mode="constant") pads with 0
-      } else if (image_is_f64) {
-        const double* src = static_cast<const double*>(image_host) + (size_t)sr * W;
-        for (long c = 0; c < PW; ++c) dst[c] = colmap[c] < 0 ? 0.0 : src[colmap[c]];
-      } else {
-        const float* src = static_cast<const float*>(image_host) + (size_t)sr * W;
-        for (long c = 0; c < PW; ++c) dst[c] = colmap[c] < 0 ? 0.0 : (double)src[colmap[c]];
-      }
-      for (long c = 0; c < PW; ++c)
-        if (dst[c] > threshold) hot[part].push_back(r * PW + c);
-    }
-  });
-  // ---- dilation (:133): every pixel within `dilation` city-block steps of a saturated one
-  std::vector<uint8_t> row_has(PH, 0);
-  size_t n_hot = 0;
-  for (const auto& list : hot) {
-    n_hot += list.size();
-    for (const int64_t idx : list) {
-      const long r = idx / PW, c = idx % PW;
-      for (long dr = -dilation; dr <= dilation; ++dr) {
-        const long rr = r + dr;
-        if (rr < 0 || rr >= PH) continue;
-        const long span = dilation - std::labs(dr);
-        const long c0 = std::max<long>(0, c - span), c1 = std::min<long>(PW - 1, c + span);
-        std::memset(mask + rr * PW + c0, 1, (size_t)(c1 - c0 + 1));
-        row_has[rr] = 1;
-      }
-    }
-  }
-  // ---- raw values of the masked pixels the caller will see (:126, :172), NaN (:134), sequential fill (:135-138)
-  struct Raw {
-    int64_t idx;
-    double value;
-  };
-  std::vector<Raw> raw;
-  if (n_hot) {
-    for (long r = 0; r < PH; ++r) {
-      if (!row_has[r]) continue;
-      for (long c = 0; c < PW; ++c)
-        if (mask[r * PW + c]) {
-          if (r >= 2L * N && r < 2L * N + H && c >= 2L * N && c < 2L * N + W) raw.push_back({r * PW + c, padded[r * PW + c]});
-          padded[r * PW + c] = std::nan("");
-        }
-    }
-    const long hw = neighborhood_width / 2;
-    for (long i = 0; i < PH; ++i) {
-      if (!row_has[i]) continue;
-      for (long j = 0; j < PW; ++j) {
-        if (!mask[i * PW + j]) continue;
-        long r0, r1, c0, c1;
-        py_slice(i - hw, i + hw, PH, &r0, &r1);
-        py_slice(j - hw, j + hw, PW, &c0, &c1);
-        double sum = 0.0;
-        long cnt = 0;
-        for (long r = r0; r < r1; ++r)
-          for (long c = c0; c < c1; ++c) {
-            const double v = padded[r * PW + c];
-            if (v == v) sum += v, ++cnt;
-          }
-        padded[i * PW + j] = cnt ? sum / (double)cnt : std::nan("");
-      }
-    }
-  }
-  // ---- the correction of the padded frame (rows the patches read in, the caller's rows out)
-  const size_t in_lo = (size_t)r_lo * PW, in_hi = (size_t)r_hi * PW, out_lo = (size_t)o_lo * PW, out_hi = out_lo + (size_t)o_rows * PW;
-  const int T = host_parts_for((in_hi - in_lo) * sizeof(float));
-  pool.run(T, [&](int t) {
-    size_t a, b;
-    rpsf_host::split_range(in_lo, in_hi, t, T, a, b);
-    rpsf_host::narrow_or_copy(q.h_in[0], padded, true, a, b);
-  });
-  hipError_t err = hipMemcpyAsync(q.d_in[0], q.h_in[0] + in_lo, (in_hi - in_lo) * sizeof(float), hipMemcpyHostToDevice, p->stream);
-  if (err == hipSuccess && launch_apply(p, q.d_in[0], q.d_out[0], g, p->stream, nullptr) != RPSF_OK) err = hipErrorUnknown;
-  if (err == hipSuccess) err = hipMemcpyAsync(q.h_out[0] + out_lo, q.d_out[0], (out_hi - out_lo) * sizeof(float), hipMemcpyDeviceToHost, p->stream);
-  if (err == hipSuccess) err = hipStreamSynchronize(p->stream);
+  run.prepare(0, image_host);
+  hipError_t err = run.enqueue(0);
+  if (err == hipSuccess) err = run.finish(0, out_host);
   if (err != hipSuccess) return drain_after_error(p, err, "saturated host frame");
-  // ---- crop (:174-177) with the raw values back on the mask (:172)
-  const int rows_parts = std::min(H, pool.width() * 4);
-  pool.run(rows_parts, [&](int part) {
-    const long ra = (long)H * part / rows_parts, rb = (long)H * (part + 1) / rows_parts;
-    for (long r = ra; r < rb; ++r) {
-      const float* src = q.h_out[0] + (size_t)(2 * N + r) * PW + 2 * N;  // (h_out is indexed by rows of the padded frame)
-      if (out_is_f64) {
-        double* dst = static_cast<double*>(out_host) + (size_t)r * W;
-        for (long c = 0; c < W; ++c) dst[c] = (double)src[c];
-      } else {
-        std::memcpy(static_cast<float*>(out_host) + (size_t)r * W, src, (size_t)W * sizeof(float));
-      }
-    }
-  });
-  for (const Raw& x : raw) {
-    const long r = x.idx / PW - 2L * N, c = x.idx % PW - 2L * N;
-    if (out_is_f64) static_cast<double*>(out_host)[(size_t)r * W + c] = x.value;
-    else static_cast<float*>(out_host)[(size_t)r * W + c] = (float)x.value;
+  return RPSF_OK;
+}
+
+extern "C" int rpsf_apply_frames_host_saturated(rpsf_plan* p, const void* const* images_host, int image_is_f64, int n_frames, int height, int width,
+                                                int pad_mode, double threshold, int dilation, int neighborhood_width, void* const* outs_host,
+                                                int out_is_f64) {
+  int rc = check_saturated_call(p, images_host, outs_host, height, width, pad_mode, dilation, neighborhood_width);
+  if (rc != RPSF_OK) return rc;
+  if (n_frames <= 0) return fail(RPSF_E_BADARG, "n_frames must be positive");
+  for (int f = 0; f < n_frames; ++f)
+    if (!images_host[f] || !outs_host[f]) return fail(RPSF_E_BADARG, "null frame pointer");
+  SatRun run;
+  rc = run.init(p, height, width, pad_mode, threshold, dilation, neighborhood_width, image_is_f64, out_is_f64, std::min(2, n_frames));
+  if (rc != RPSF_OK) return rc;
+  hipError_t err = hipSuccess;
+  for (int f = 0; f < n_frames && err == hipSuccess; ++f) {
+    run.prepare(f & 1, images_host[f]);  // (the slot's previous frame, f - 2, was finished in the iteration before)
+    err = run.enqueue(f & 1);
+    if (err == hipSuccess && f > 0) err = run.finish((f - 1) & 1, outs_host[f - 1]);  // the GPU has had the host steps of frame f to correct frame f - 1
   }
+  if (err == hipSuccess) err = run.finish((n_frames - 1) & 1, outs_host[n_frames - 1]);
+  if (err != hipSuccess) return drain_after_error(p, err, "saturated host frames");
   return RPSF_OK;
 }
 

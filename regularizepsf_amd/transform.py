@@ -331,6 +331,20 @@ class ArrayPSFTransform:
                 msg = "images must be a sequence of two dimensional arrays of one shape"
                 raise ValueError(msg)
         dtype = np.dtype(out.dtype if out is not None else dtype)
+        if (saturation_threshold != math.inf and pad_mode in _native.PAD_MODES and len(frames) > 0 and len(self) > 0
+                and dtype in (np.float32, np.float64) and isinstance(saturation_dilation, numbers.Integral) and saturation_dilation >= 1
+                and isinstance(neighborhood_width, numbers.Integral) and neighborhood_width >= 0):
+            # the saturation branch for a sequence of frames: the host steps of frame i + 1 (pad, mask, dilation, sequential fill) run while the
+            # GPU corrects frame i (rpsf_apply_frames_host_saturated)
+            n = self._checked_patch_size()
+            plan = self._device_plan()
+            self._check_corners(n, *shape)
+            res = plan.apply_frames_host_saturated(frames, _native.PAD_MODES[pad_mode], saturation_threshold, saturation_dilation,
+                                                   neighborhood_width, out_dtype=dtype)
+            if out is not None:
+                out[...] = res
+                return out
+            return res
         if (saturation_threshold != math.inf or pad_mode not in _native.PAD_MODES or len(frames) == 0
                 or dtype not in (np.float32, np.float64)):
             outs = [self.apply(im, workers, pad_mode, saturation_threshold, saturation_dilation, neighborhood_width)

@@ -133,3 +133,28 @@ def test_saturation_branch_in_one_library_call(n, shape, pad_mode, dilation, wid
     _compare(t.apply(calm, pad_mode=pad_mode, saturation_threshold=threshold, saturation_dilation=dilation, neighborhood_width=width),
              orc.apply_transfer(calm, coords, k, pad_mode=pad_mode, saturation_threshold=threshold, saturation_dilation=dilation,
                                 neighborhood_width=width))
+
+
+@pytest.mark.parametrize(("n", "shape", "frames"), [(64, (200, 192), 7), (32, (96, 128), 1), (128, (384, 320), 4)])
+def test_saturated_frames_in_sequence_equal_the_loop(n, shape, frames):
+    """`apply_batch(..., saturation_threshold=...)` - what the reference's example does frame by frame - prepares frame i + 1 on the host while the
+    GPU corrects frame i (two staging slots in turn): every frame is the single call's, bit for bit, saturated or not, and matches the oracle."""
+    h, w = shape
+    coords, k = orc.synthetic_transfer(h, w, n, alpha=1.0, epsilon=0.1)
+    rng = np.random.default_rng(7 * n)
+    stack = []
+    for f in range(frames):
+        im = orc.starfield(h, w, seed=50 + f).astype(np.float64)
+        if f % 3 != 2:  # every third frame has nothing above the threshold
+            for r, c in zip(rng.integers(0, h, 6), rng.integers(0, w, 6)):
+                im[int(r), int(c)] = 6.0e4 + f
+        else:
+            im = np.minimum(im, 1.0e4)
+        stack.append(im.astype(np.float32))
+    t = rp.ArrayPSFTransform(rp.IndexedCube(coords, k))
+    kwargs = dict(saturation_threshold=2.0e4, saturation_dilation=2, neighborhood_width=5)
+    loop = np.stack([t.apply(im, **kwargs) for im in stack])
+    assert np.array_equal(t.apply_batch(stack, **kwargs), loop, equal_nan=True)
+    assert np.array_equal(t.apply_batch(np.stack(stack), dtype=np.float32, **kwargs), loop.astype(np.float32), equal_nan=True)
+    _compare(loop[0], orc.apply_transfer(stack[0], coords, k, **kwargs))
+    _compare(loop[-1], orc.apply_transfer(stack[-1], coords, k, **kwargs))
