@@ -1,0 +1,4 @@
+// k3_16.hip - explicit instantiation of the third-generation (sweep) kernels of the 16-pixel plan (see rpsf_device.hpp)
+#include "rpsf_device.hpp"
+
+RPSF_INST_V3(Cfg3_16)

@@ -1,0 +1,334 @@
+// rpsf_core3.hpp - per-lane building blocks of the third kernel generation (N = 16, 32, 64): the "sweep" kernel of
+// rpsf_kernels3.hpp, in which a workgroup owns a region of OUTPUT pixels, walks every patch that touches it and meets the four
+// contributions to a pixel on chip (an N-row ring of the region in LDS) - no colour planes, no plane sum, every output pixel
+// written once.  Like rpsf_core.hpp these functions compile for the GPU and, as plain C++, for the CPU emulator (tests/emu/emu3.cpp).
+//
+// Stands in for regularizepsf/transform.py:151-169 (window -> fft2 -> x K -> ifft2 -> real -> window -> overlap-add).
+//
+// Work unit: a SLAB = N rows x 128 columns of the (padded) image = PPW = 128 / N patches of one lattice row and one column
+// parity, side by side, handled by ONE wave with no workgroup barrier.  A lane is one 1-D transform:
+//   R-layout  lane (q, p), q = lane / H patch of the slab, p = lane % H:  v[c] = x[p][c] + i x[p + H][c]   (H = N / 2, rows p and p + H
+//             of the patch packed into one complex row; c = column)
+//   C-layout  lane (q, k): v[r] = column k of the half spectrum, r = row / row frequency; column 0 carries the two real columns
+//             k = 0 and k = N/2 packed as one complex column
+// with three transposes through a wave-private LDS buffer (real parts, then imaginary parts: half the buffer), all by 16-byte
+// stores and 4-byte strided loads whose offsets are compile-time constants.
+//
+// Algebra (w = window, K_h = Hermitian fold of the caller's K, s = 1 / (2 N^2)):
+//   u_p[c] = (w x)[p][c] + i (w x)[p+H][c];   U_p = DFT_c(u_p)
+//   A_p[k] = U_p[k] + conj U_p[N-k] = 2 F_p[k],  B_p[k] = -i (U_p[k] - conj U_p[N-k]) = 2 F_{p+H}[k]      (F_r = spectrum of row r)
+//   column k (0 < k < H): C_k[r] = 2 F_r[k];  column 0: D[r] = 2 F_r[0] + i 2 F_r[H]  (both real)
+//   G_k = DFT_r(C_k) = 2 X[.][k];  G_k' = G_k * s K_h[.][k];   G_0'[q] = a[q] G_0[q] + b[q] conj G_0[-q],
+//   a = s (K_h[q][0] + K_h[q][H]) / 2,  b = s (K_h[q][0] - K_h[q][H]) / 2
+//   inverse column DFT, back to rows, U'[k] = V_p[k] + i V_{p+H}[k], U'[N-k] = conj V_p[k] + i conj V_{p+H}[k], inverse row DFT:
+//   u'[c] = y[p][c] + i y[p+H][c], the patch's contribution before the second window.
+#pragma once
+#include "rpsf_core.hpp"
+
+namespace rpsf {
+
+constexpr int pad_mod32(int x, int want) {  // smallest y >= x with y % 32 == want % 32
+  int y = x;
+  while ((y & 31) != (want & 31)) ++y;
+  return y;
+}
+
+constexpr double sin_poly3(double x) {  // |x| <= pi / 2
+  double x2 = x * x, term = x, sum = x;
+  for (int n = 1; n <= 12; ++n) {
+    term *= -x2 / ((2.0 * n) * (2.0 * n + 1.0));
+    sum += term;
+  }
+  return sum;
+}
+template <int N>
+constexpr float win3(int i) {  // sin((i + 1/2) pi / N), transform.py:151-155
+  constexpr double pi = 3.14159265358979323846;
+  double x = (i + 0.5) * pi / N;
+  if (x > pi / 2) x = pi - x;
+  return (float)sin_poly3(x);
+}
+
+template <int LOGN_, int KSMAX_ = 2, int WAVES_ = 8>
+struct Cfg3 {
+  static constexpr int LOGN = LOGN_, N = 1 << LOGN_, H = N / 2;
+  static constexpr int SLABW = 128, PPW = SLABW / N;  // patches per slab
+  static constexpr int PPP = N <= 32 ? PPW : 1;       // patches per exchange pass (N = 64: one, the buffer holds half a slab)
+  static constexpr int NSUB = PPW / PPP;
+  static constexpr int WAVES = WAVES_, WG = 64 * WAVES_;
+  // exchange sub-layouts (floats): X0[q][row < H][c < N] (gather -> rows, and columns -> rows on the way back as X2[q][k][r]),
+  // X1[q][r < N][j < H] (rows -> columns).  Row pitches = 4 mod 32 (16-byte stores of 8 consecutive lanes hit 32 different banks),
+  // patch strides = H mod 32 (the 4-byte loads of the 32 lanes of a half wave - two or four patches - hit 32 different banks).
+  static constexpr int P0 = N + 4, Q0 = pad_mod32(H * P0, H);
+  static constexpr int P1 = H + 4, Q1 = pad_mod32(N * P1, H);
+  static constexpr int XF = PPP * (Q0 > Q1 ? Q0 : Q1);  // floats per wave
+  // ring of the region's output rows in LDS: N rows x RP floats; RP / 2 odd (the 4-byte adds of 16 or 32 consecutive rows hit different
+  // banks; 8-byte reads of the flush stay aligned)
+  static constexpr int KSMAX = KSMAX_;                 // slabs per parity and lattice row of a region
+  static constexpr int RINGW = SLABW * KSMAX + H;
+  static constexpr int RP = RINGW + 2;
+  static_assert((RP / 2) % 2 == 1, "ring pitch");
+  static constexpr int RINGF = N * RP;
+  static constexpr int NFLAGS = 256;
+  static constexpr size_t LDS_BYTES = sizeof(float) * ((size_t)RINGF + (size_t)WAVES * XF) + sizeof(uint32_t) * (NFLAGS + 4);
+  // packed K, per patch (floats): A[j < H][k < H][4] = (K'[r][k], K'[r'][k]) for the row pair (r, r') = (0, H) if j = 0, else (j, N - j); K' = s K_h, column 0 holding a; then B[j < H][4] = (b[r], b[r'])
+  static constexpr int KA_FLOATS = H * H * 4, KB_FLOATS = H * 4, K_FLOATS = KA_FLOATS + KB_FLOATS;
+  static constexpr float SCALE = 1.0f / (2.0f * (float)N * (float)N);
+};
+
+// ---- LDS accessors (plain memory on the host) -------------------------------------------------------------------------------
+RPSF_HD f32x4 lds_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+RPSF_HD void lds_st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+RPSF_HD f32x2 lds_ld2(const float* p) { return *reinterpret_cast<const f32x2*>(p); }
+RPSF_HD void lds_add1(float* p, float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // ds_add_f32, no return: the jobs of a region are ordered by their flags (rpsf_kernels3.hpp), so nobody else touches these words meanwhile;
+  // the atomic form is used for its one-instruction read-modify-write
+  __builtin_amdgcn_ds_faddf((__attribute__((address_space(3))) float*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP, false);
+#else
+  *p += v;
+#endif
+}
+
+// ---- gather (transform.py:117-123,141-149,157-162) ----------------------------------------------------------------------------
+// G-layout: load i < H covers slab rows 2i and 2i + 1; lane = (row parity, 16-byte unit u = lane & 31 of the 128 columns)
+template <class C>
+RPSF_HD void g3_load_fast(int lane, f32x4* g, const float* slab, int ld) {
+  const float* base = slab + (size_t)(lane >> 5) * ld + 4 * (lane & 31);
+  StaticFor<0, C::H>::run([&]<int I>() RPSF_AI { g[I] = *reinterpret_cast<const f32x4*>(base + (size_t)(2 * I) * ld); });
+}
+// any slab: np.pad's index maps, pixel by pixel (slabs on the rim of the image, unaligned geometry)
+template <class C>
+RPSF_HD void g3_load_generic(int lane, f32x4* g, const ImageView& im, int row0, int col0) {
+  int cx[4];
+  for (int d = 0; d < 4; ++d) cx[d] = pad_index(col0 + 4 * (lane & 31) + d, im.W, im.pad_mode);
+  StaticFor<0, C::H>::run([&]<int I>() RPSF_AI {
+    int y = pad_index(row0 + 2 * I + (lane >> 5), im.H, im.pad_mode);
+    if (y >= 0) {
+      y -= im.row0;
+      if (y < 0 || y >= im.rows) y = -1;  // not resident: treated as fill (the launcher keeps every row a band needs resident)
+    }
+    const float* row = im.img + (size_t)(y < 0 ? 0 : y) * im.ld;
+    float px[4];
+    for (int d = 0; d < 4; ++d) {
+      const float t = row[cx[d] < 0 ? 0 : cx[d]];  // always in bounds; select afterwards
+      px[d] = (y < 0 || cx[d] < 0) ? im.pad_value : t;
+    }
+    g[I] = f32x4{px[0], px[1], px[2], px[3]};
+  });
+}
+
+// ---- T0: G-layout -> R-layout.  PART 0: slab rows [0, H) -> real parts, PART 1: rows [H, N) -> imaginary parts ------------------------
+template <class C, int PART, int SUB>
+RPSF_HD void t0_write(int lane, const f32x4* g, float* xb) {
+  const int u = lane & 31, hf = lane >> 5;
+  const int q = (4 * u) / C::N, c = (4 * u) % C::N;
+  if (q / C::PPP != SUB) return;
+  float* base = xb + (q % C::PPP) * C::Q0 + hf * C::P0 + c;
+  StaticFor<0, C::H / 2>::run([&]<int I>() RPSF_AI { lds_st4(base + (2 * I) * C::P0, g[PART * (C::H / 2) + I]); });
+}
+template <class C, int PART, int SUB>
+RPSF_HD void t0_read(int lane, cf* v, const float* xb) {
+  const int q = lane / C::H, p = lane % C::H;
+  if (q / C::PPP != SUB) return;
+  const float* base = xb + (q % C::PPP) * C::Q0 + p * C::P0;
+  StaticFor<0, C::N / 4>::run([&]<int J>() RPSF_AI {
+    const f32x4 t = lds_ld4(base + 4 * J);
+    if constexpr (PART == 0) v[4 * J].x = t.x, v[4 * J + 1].x = t.y, v[4 * J + 2].x = t.z, v[4 * J + 3].x = t.w;
+    else v[4 * J].y = t.x, v[4 * J + 1].y = t.y, v[4 * J + 2].y = t.z, v[4 * J + 3].y = t.w;
+  });
+}
+
+// first window (transform.py:151-155,163): rows by the lane's two row weights, columns by compile-time constants
+template <class C>
+RPSF_HD void window_in(cf* v, float w_re, float w_im) {
+  StaticFor<0, C::N>::run([&]<int I>() RPSF_AI {
+    constexpr float wc = win3<C::N>(I);
+    v[I].x = (v[I].x * w_re) * wc;
+    v[I].y = (v[I].y * w_im) * wc;
+  });
+}
+
+// row spectra of the two packed rows, in place: v[k] (k < H) = column k of row p (k = 0: D[p]); v[H + j] = column (j ? H - j : 0) of row p + H
+template <class C>
+RPSF_HD void unpack_rows(cf* v) {
+  constexpr int N = C::N, H = C::H;
+  const cf u0 = v[0], uh = v[H];
+  v[0] = cf{2.0f * u0.x, 2.0f * uh.x};
+  v[H] = cf{2.0f * u0.y, 2.0f * uh.y};
+  StaticFor<1, H>::run([&]<int K>() RPSF_AI {
+    const cf a = v[K], b = v[N - K];                 // U[k] = a, U[N-k] = b
+    v[K] = cf{a.x + b.x, a.y - b.y};                 // A[k] = U[k] + conj U[N-k]
+    v[N - K] = cf{a.y + b.y, b.x - a.x};             // B[k] = -i (U[k] - conj U[N-k])
+  });
+}
+// and back: from V_p[k] (v[k]) and V_{p+H}[k] (v[N-k]) to the spectrum of u' = y_p + i y_{p+H}
+template <class C>
+RPSF_HD void repack_rows(cf* v) {
+  constexpr int N = C::N, H = C::H;
+  const cf d0 = v[0], d1 = v[H];  // D'[p], D'[p+H]
+  v[0] = cf{d0.x, d1.x};
+  v[H] = cf{d0.y, d1.y};
+  StaticFor<1, H>::run([&]<int K>() RPSF_AI {
+    const cf a = v[K], b = v[N - K];                 // Va, Vb
+    v[K] = cf{a.x - b.y, a.y + b.x};                 // Va + i Vb
+    v[N - K] = cf{a.x + b.y, b.x - a.y};             // conj Va + i conj Vb
+  });
+}
+
+// ---- T1: R-layout -> C-layout through X1[q][r][j] (row p: j = k; row p + H: j = 0 for k = 0, else H - k: the registers v[H + j] in order) ----
+template <class C, int PART, int SUB>
+RPSF_HD void t1_write(int lane, const cf* v, float* xb) {
+  const int q = lane / C::H, p = lane % C::H;
+  if (q / C::PPP != SUB) return;
+  float* base = xb + (q % C::PPP) * C::Q1 + p * C::P1;
+  StaticFor<0, C::N / 4>::run([&]<int J>() RPSF_AI {
+    constexpr int R = (4 * J) / C::H, J0 = (4 * J) % C::H;  // R = 0: row p, R = 1: row p + H
+    f32x4 t;
+    if constexpr (PART == 0) t = f32x4{v[4 * J].x, v[4 * J + 1].x, v[4 * J + 2].x, v[4 * J + 3].x};
+    else t = f32x4{v[4 * J].y, v[4 * J + 1].y, v[4 * J + 2].y, v[4 * J + 3].y};
+    lds_st4(base + R * C::H * C::P1 + J0, t);
+  });
+}
+template <class C, int PART, int SUB>
+RPSF_HD void t1_read(int lane, cf* v, const float* xb) {
+  const int q = lane / C::H, k = lane % C::H;
+  if (q / C::PPP != SUB) return;
+  const float* lo = xb + (q % C::PPP) * C::Q1 + k;
+  const float* hi = xb + (q % C::PPP) * C::Q1 + C::H * C::P1 + (k == 0 ? 0 : C::H - k);
+  StaticFor<0, C::H>::run([&]<int R>() RPSF_AI {
+    const float a = lo[R * C::P1], b = hi[R * C::P1];
+    if constexpr (PART == 0) v[R].x = a, v[C::H + R].x = b;
+    else v[R].y = a, v[C::H + R].y = b;
+  });
+}
+
+// ---- frequency step (transform.py:164): x s K_h, lane = column k ----------------------------------------------------------------
+// Rows pair as (r, N - r): word 0 of a lane's stream holds the two self-paired rows (0, H), word j >= 1 the rows (j, N - j).
+// ka: the lane's first 16-byte word of A (H words apart from one j to the next); kb: the lane's B words (column 0, kb_stride = 4 floats) or 16
+// bytes of zeros (every other column, kb_stride = 0: b = 0, so that the rule of column 0 costs no branch).
+template <int N, int H>
+constexpr int k3_row(int j, int m) { return j == 0 ? (m ? H : 0) : (m ? N - j : j); }
+template <class C, bool NT>
+RPSF_HD void kmul3(cf* v, const float* ka, const float* kb, int kb_stride) {
+  constexpr int N = C::N, H = C::H;
+  StaticFor<0, H>::run([&]<int J>() RPSF_AI {
+    cf ae, ao, be, bo;
+    load_k16<NT>(ka + (size_t)J * (H * 4), ae, ao);
+    load_k16<false>(kb + (size_t)J * kb_stride, be, bo);
+    constexpr int RE = k3_row<N, H>(J, 0), RO = k3_row<N, H>(J, 1);
+    const cf x = v[RE], y = v[RO];
+    if constexpr (J == 0) {  // v'[r] = a[r] v[r] + b[r] conj v[-r], -r = r for both rows
+      v[RE] = cmul(ae, x) + cmul(be, cconj(x));
+      v[RO] = cmul(ao, y) + cmul(bo, cconj(y));
+    } else {
+      v[RE] = cmul(ae, x) + cmul(be, cconj(y));
+      v[RO] = cmul(ao, y) + cmul(bo, cconj(x));
+    }
+  });
+}
+
+// ---- T2: C-layout -> R-layout through X2[q][k][r] (same pitches as X0) ---------------------------------------------------------------
+template <class C, int PART, int SUB>
+RPSF_HD void t2_write(int lane, const cf* v, float* xb) {
+  const int q = lane / C::H, k = lane % C::H;
+  if (q / C::PPP != SUB) return;
+  float* base = xb + (q % C::PPP) * C::Q0 + k * C::P0;
+  StaticFor<0, C::N / 4>::run([&]<int J>() RPSF_AI {
+    f32x4 t;
+    if constexpr (PART == 0) t = f32x4{v[4 * J].x, v[4 * J + 1].x, v[4 * J + 2].x, v[4 * J + 3].x};
+    else t = f32x4{v[4 * J].y, v[4 * J + 1].y, v[4 * J + 2].y, v[4 * J + 3].y};
+    lds_st4(base + 4 * J, t);
+  });
+}
+template <class C, int PART, int SUB>
+RPSF_HD void t2_read(int lane, cf* v, const float* xb) {
+  const int q = lane / C::H, p = lane % C::H;
+  if (q / C::PPP != SUB) return;
+  const float* base = xb + (q % C::PPP) * C::Q0 + p;
+  StaticFor<0, C::H>::run([&]<int J>() RPSF_AI {
+    constexpr int KHI = J == 0 ? 0 : C::H - J;  // the column that register v[H + J] holds
+    const float a = base[J * C::P0], b = base[KHI * C::P0 + C::H];
+    if constexpr (PART == 0) v[J].x = a, v[C::H + J].x = b;
+    else v[J].y = a, v[C::H + J].y = b;
+  });
+}
+
+// ---- second window and overlap-add into the ring (transform.py:165-169) ---------------------------------------------------------
+enum Acc3 : int { ACC_SKIP = 0, ACC_STORE = 1, ACC_ADD = 2 };
+// upper: the lane's row p of the slab (real parts), lower: row p + H (imaginary parts); ru / rl: their ring rows at the patch's first column
+template <class C>
+RPSF_HD void accumulate3(const cf* v, float w_re, float w_im, bool valid, float* ru, float* rl, int mode_u, int mode_l) {
+  const float su = valid ? w_re : 0.0f, sl = valid ? w_im : 0.0f;
+  auto val = [&](float x, float s, float wc) RPSF_AI { return valid ? (x * s) * wc : 0.0f; };  // (an invalid patch contributes exact zeros, whatever its pixels were)
+  if (mode_u == ACC_STORE) {
+    StaticFor<0, C::N>::run([&]<int I>() RPSF_AI { ru[I] = val(v[I].x, su, win3<C::N>(I)); });
+  } else if (mode_u == ACC_ADD) {
+    StaticFor<0, C::N>::run([&]<int I>() RPSF_AI { lds_add1(ru + I, val(v[I].x, su, win3<C::N>(I))); });
+  }
+  if (mode_l == ACC_STORE) {
+    StaticFor<0, C::N>::run([&]<int I>() RPSF_AI { rl[I] = val(v[I].y, sl, win3<C::N>(I)); });
+  } else if (mode_l == ACC_ADD) {
+    StaticFor<0, C::N>::run([&]<int I>() RPSF_AI { lds_add1(rl + I, val(v[I].y, sl, win3<C::N>(I))); });
+  }
+}
+
+// ---- flush: H finished ring rows x the slab's 128 columns -> the output image (transform.py:174-177, float32 here) ------------------
+// band_row: image row of the band's first row; col0: image column of the slab's first column; [oc0, oc1): image columns this region owns
+struct Flush3 {
+  float* out;  // rows [row0, row0 + rows) of the output, row stride ld
+  int ld, row0, rows, Himg, Wimg;
+  int aligned;  // 16-byte stores allowed (ld, column origin and pointer multiples of four floats)
+};
+template <class C, class Store4, class Store1>
+RPSF_HD void flush3(int lane, const float* ring_band /*ring row of the band's first row, at the slab's first column*/, const Flush3& f, int band_row, int col0,
+                    int oc0, int oc1, Store4&& st4, Store1&& st1) {
+  const int u = lane & 31, hf = lane >> 5;
+  const int c = col0 + 4 * u;
+  const int lo = oc0 > 0 ? oc0 : 0, hi = oc1 < f.Wimg ? oc1 : f.Wimg;
+  StaticFor<0, C::H / 2>::run([&]<int I>() RPSF_AI {
+    const int r = band_row + 2 * I + hf;
+    const float* src = ring_band + (2 * I + hf) * C::RP + 4 * u;
+    const f32x2 a = lds_ld2(src), b = lds_ld2(src + 2);
+    if (r >= f.row0 && r < f.row0 + f.rows && r >= 0 && r < f.Himg) {
+      float* dst = f.out + (size_t)(r - f.row0) * f.ld + c;
+      if (f.aligned && c >= lo && c + 4 <= hi) {
+        st4(dst, f32x4{a.x, a.y, b.x, b.y});
+      } else {
+        if (c >= lo && c < hi) st1(dst, a.x);
+        if (c + 1 >= lo && c + 1 < hi) st1(dst + 1, a.y);
+        if (c + 2 >= lo && c + 2 < hi) st1(dst + 2, b.x);
+        if (c + 3 >= lo && c + 3 < hi) st1(dst + 3, b.y);
+      }
+    }
+  });
+}
+
+// ---- K pack (one-time, at set_transfer): value `idx` of a patch's K_FLOATS / 2 complex values ---------------------------------------------
+template <class C, class KF>
+RPSF_HD cf kh3_at(const KF& kfull, int kr, int kc) {  // Hermitian fold (legal for any K: only Re(ifft2) is kept, transform.py:164), not scaled
+  const cf a = k_at(kfull, kr * C::N + kc);
+  const cf b = k_at(kfull, ((C::N - kr) & (C::N - 1)) * C::N + ((C::N - kc) & (C::N - 1)));
+  return cf{(a.x + b.x) * 0.5f, (a.y - b.y) * 0.5f};
+}
+template <class C, class KF>
+RPSF_HD cf pack_value3(const KF& kfull, int idx) {
+  constexpr int H = C::H, N = C::N;
+  const bool side = idx >= H * H * 2;  // B[j][2] behind A[j][k][2]
+  const int i2 = side ? idx - H * H * 2 : idx;
+  const int m = i2 & 1, k = side ? 0 : (i2 >> 1) % H, j = side ? i2 >> 1 : (i2 >> 1) / H;
+  const int r = j == 0 ? (m ? H : 0) : (m ? N - j : j);
+  if (k != 0) {
+    const cf x = kh3_at<C>(kfull, r, k);
+    return cf{x.x * C::SCALE, x.y * C::SCALE};
+  }
+  const cf x0 = kh3_at<C>(kfull, r, 0), xh = kh3_at<C>(kfull, r, H);
+  if (!side) return cf{(x0.x + xh.x) * (0.5f * C::SCALE), (x0.y + xh.y) * (0.5f * C::SCALE)};
+  return cf{(x0.x - xh.x) * (0.5f * C::SCALE), (x0.y - xh.y) * (0.5f * C::SCALE)};
+}
+
+using Cfg3_16 = Cfg3<4, 4>;
+using Cfg3_32 = Cfg3<5, 2>;
+using Cfg3_64 = Cfg3<6, 2>;
+
+}  // namespace rpsf

@@ -1,0 +1,201 @@
+// rpsf_kernels3.hpp - third kernel generation, N = 16, 32, 64 (the patch sizes of the reference's own example,
+// docs/source/example.ipynb): sweep_kernel<C>.  One launch is the whole apply (regularizepsf/transform.py:117-177 without the saturation
+// branch): no colour planes, no plane-sum kernel, every output pixel written exactly once.
+//
+// A workgroup owns a REGION of output pixels (rpsf_plan3.hpp) and keeps N rows of it in LDS (the ring).  Its waves draw JOBS from the
+// region's list - one slab of 128 / N patches each - and run a job from the gather to the inverse transform without meeting the
+// other waves (rpsf_core3.hpp).  Only the last step is ordered: a job adds its slab into the ring after the jobs it overlaps have
+// added theirs (two flags per job, LDS words, polled by the wave), which fixes the order of the four additions of every pixel.
+// Phase-B jobs then write the band of H rows that their slab has just completed to the output image.  Patches on the border between two
+// regions are computed by both (nothing is handed from one workgroup to another).
+#pragma once
+
+struct SweepParams {
+  ImageView im;
+  Flush3 fl;
+  int lat_r0, lat_c0;  // image coordinates of the lattice origin
+  const Job3* jobs;
+  const Region3* regions;
+  int n_regions, group;  // group = regions per XCD (blocks b and b + 8 share an XCD)
+  const float* k3;
+  const float* win;    // N window weights
+  const float* zeros;  // 16 bytes of zeros
+  size_t im_frame_floats, out_frame_floats;
+  int aligned_in;  // 16-byte gathers allowed (image pointer, row stride and column origin multiples of four floats)
+};
+
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+__device__ __forceinline__ void lds_fence_wave() {
+  // the lanes of a wave exchange data through LDS without a barrier: DS instructions of one wave execute in order, the compiler only has to keep them so
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ uint32_t lds_u32_offset(const void* p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+
+template <class C, bool NT>
+__device__ __forceinline__ void sweep_body(const SweepParams& P) {
+  constexpr int N = C::N, H = C::H;
+  extern __shared__ __attribute__((aligned(16))) float lds3[];
+  float* ring = lds3;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* xb = ring + C::RINGF + wave * C::XF;
+  uint32_t* flags = reinterpret_cast<uint32_t*>(ring + C::RINGF + C::WAVES * C::XF);
+  uint32_t* next = flags + C::NFLAGS;
+  const int b = blockIdx.x;
+  const int region = (b & 7) * P.group + (b >> 3);
+  if (region >= P.n_regions) return;
+  const Region3 reg = P.regions[region];
+  for (int i = tid; i < C::NFLAGS + 4; i += C::WG) flags[i] = 0;
+  __syncthreads();
+  ImageView im = P.im;
+  Flush3 fl = P.fl;
+  im.img += (size_t)blockIdx.y * P.im_frame_floats;
+  fl.out += (size_t)blockIdx.y * P.out_frame_floats;
+  const int q = lane / H, p = lane % H;
+  const float w_re = P.win[p], w_im = P.win[p + H];
+  const uint32_t flags_off = lds_u32_offset(flags), next_off = lds_u32_offset(next);
+  for (;;) {
+    // ---- draw the next job of the region ----
+    uint32_t drawn = 0;
+    if (lane == 0) {
+      const uint32_t one = 1;
+      asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(drawn) : "v"(next_off), "v"(one) : "memory");
+    }
+    const int j = (int)__builtin_amdgcn_readfirstlane(drawn);
+    if (j >= reg.njobs) break;
+    const Job3* jd = P.jobs + reg.job0 + j;
+    const int jrow = jd->row, jcol = jd->col;
+    const uint32_t jflags = jd->flags;
+    const int row0 = P.lat_r0 + jrow, col0 = P.lat_c0 + jcol;
+    const int kslot = jd->kslot[q];
+    // ---- gather ----
+    f32x4 g[H];
+    const bool fast = P.aligned_in && row0 >= im.row0 && row0 + N <= im.row0 + im.rows && row0 >= 0 && row0 + N <= im.H && col0 >= 0 &&
+                      col0 + C::SLABW <= im.W;
+    if (fast) g3_load_fast<C>(lane, g, im.img + (size_t)(row0 - im.row0) * im.ld + col0, im.ld);
+    else g3_load_generic<C>(lane, g, im, row0, col0);
+    cf v[N];
+    // ---- rows ----
+    StaticFor<0, C::NSUB>::run([&]<int S>() RPSF_AI {
+      t0_write<C, 0, S>(lane, g, xb);
+      lds_fence_wave();
+      t0_read<C, 0, S>(lane, v, xb);
+      lds_fence_wave();
+      t0_write<C, 1, S>(lane, g, xb);
+      lds_fence_wave();
+      t0_read<C, 1, S>(lane, v, xb);
+      lds_fence_wave();
+    });
+    window_in<C>(v, w_re, w_im);
+    FftSmall<C::LOGN, false>::run(v);
+    unpack_rows<C>(v);
+    // ---- columns ----
+    StaticFor<0, C::NSUB>::run([&]<int S>() RPSF_AI {
+      t1_write<C, 0, S>(lane, v, xb);
+      lds_fence_wave();
+      t1_read<C, 0, S>(lane, v, xb);
+      lds_fence_wave();
+      t1_write<C, 1, S>(lane, v, xb);
+      lds_fence_wave();
+      t1_read<C, 1, S>(lane, v, xb);
+      lds_fence_wave();
+    });
+    FftSmall<C::LOGN, false>::run(v);
+    {
+      const float* kp = P.k3 + (size_t)kslot * C::K_FLOATS;
+      const bool col0lane = p == 0;
+      kmul3<C, NT>(v, kp + p * 4, col0lane ? kp + C::KA_FLOATS : P.zeros, col0lane ? 4 : 0);
+    }
+    FftSmall<C::LOGN, true>::run(v);
+    // ---- back to rows ----
+    StaticFor<0, C::NSUB>::run([&]<int S>() RPSF_AI {
+      t2_write<C, 0, S>(lane, v, xb);
+      lds_fence_wave();
+      t2_read<C, 0, S>(lane, v, xb);
+      lds_fence_wave();
+      t2_write<C, 1, S>(lane, v, xb);
+      lds_fence_wave();
+      t2_read<C, 1, S>(lane, v, xb);
+      lds_fence_wave();
+    });
+    repack_rows<C>(v);
+    FftSmall<C::LOGN, true>::run(v);
+    // ---- wait for the jobs this one overlaps, then add ----
+    {
+      const int d0 = jd->dep0, d1 = jd->dep1;
+      if (d0 >= 0) {
+        const uint32_t a0 = flags_off + 4u * ((uint32_t)d0 & (C::NFLAGS - 1)), want = (uint32_t)d0 + 1;
+        uint32_t seen;
+        do {
+          asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(a0) : "memory");
+          if (__builtin_amdgcn_readfirstlane(seen) >= want) break;
+          __builtin_amdgcn_s_sleep(2);
+        } while (true);
+      }
+      if (d1 >= 0) {
+        const uint32_t a1 = flags_off + 4u * ((uint32_t)d1 & (C::NFLAGS - 1)), want = (uint32_t)d1 + 1;
+        uint32_t seen;
+        do {
+          asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(a1) : "memory");
+          if (__builtin_amdgcn_readfirstlane(seen) >= want) break;
+          __builtin_amdgcn_s_sleep(2);
+        } while (true);
+      }
+    }
+    const int hs = (jflags & J3_RING_HALF) ? 1 : 0;
+    {
+      const bool valid = ((jflags >> (J3_VALID_SHIFT + q)) & 1u) != 0;
+      float* ru = ring + (hs * H + p) * C::RP + jd->ring_col + q * N;
+      float* rl = ring + ((hs ^ 1) * H + p) * C::RP + jd->ring_col + q * N;
+      accumulate3<C>(v, w_re, w_im, valid, ru, rl, (int)((jflags >> J3_UPPER_SHIFT) & 3u), (int)((jflags >> J3_LOWER_SHIFT) & 3u));
+    }
+    // ---- phase B: the band(s) this slab has completed go to the output image ----
+    if (jflags & (J3_FLUSH_UPPER | J3_FLUSH_LOWER)) {
+      lds_fence_wave();
+      auto st4 = [](float* dst, f32x4 x) RPSF_AI { __builtin_nontemporal_store(x, reinterpret_cast<f32x4*>(dst)); };
+      auto st1 = [](float* dst, float x) RPSF_AI { __builtin_nontemporal_store(x, dst); };
+      const int oc0 = P.lat_c0 + jd->own_c0, oc1 = P.lat_c0 + jd->own_c1;
+      if (jflags & J3_FLUSH_UPPER) flush3<C>(lane, ring + (hs * H) * C::RP + jd->ring_col, fl, row0, col0, oc0, oc1, st4, st1);
+      if (jflags & J3_FLUSH_LOWER) flush3<C>(lane, ring + ((hs ^ 1) * H) * C::RP + jd->ring_col, fl, row0 + H, col0, oc0, oc1, st4, st1);
+    }
+    // ---- done: LDS executes a wave's instructions in order, so whoever sees the flag sees the adds (and the flush has read its rows) ----
+    if (lane == 0) {
+      const uint32_t a = flags_off + 4u * ((uint32_t)j & (C::NFLAGS - 1)), val = (uint32_t)j + 1;
+      asm volatile("s_waitcnt lgkmcnt(0)\n\tds_write_b32 %0, %1" : : "v"(a), "v"(val) : "memory");
+    }
+  }
+}
+
+template <class C>
+__global__ __launch_bounds__(C::WG) void sweep_kernel(SweepParams P) {
+  sweep_body<C, true>(P);
+}
+// (K by plain loads: batches of frames share it, and small transfer kernels stay in the Infinity Cache from one apply to the next)
+template <class C>
+__global__ __launch_bounds__(C::WG) void sweep_kernel_kc(SweepParams P) {
+  sweep_body<C, false>(P);
+}
+
+// K pack for the sweep kernel (one-time): fold + reorder, see Cfg3 / pack_value3
+template <class C>
+__global__ void pack_kernel3(const cf* __restrict__ kfull, int n_patches, cf* __restrict__ k3) {
+  constexpr int per = C::K_FLOATS / 2;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)per * n_patches) return;
+  const int patch = (int)(idx / per), rem = (int)(idx % per);
+  const cf* kf = kfull + (size_t)patch * C::N * C::N;
+  k3[idx] = pack_value3<C>(kf, rem);
+}
+template <class C>
+__global__ void pack_spectra_kernel3(const cf* __restrict__ s_fft, const cf* __restrict__ t_fft, float alpha, float eps, int n_patches,
+                                     cf* __restrict__ k3) {
+  constexpr int per = C::K_FLOATS / 2;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)per * n_patches) return;
+  const int patch = (int)(idx / per), rem = (int)(idx % per);
+  const size_t off = (size_t)patch * C::N * C::N;
+  k3[idx] = pack_value3<C>(KFromSpectra{s_fft + off, t_fft + off, alpha, eps}, rem);
+}
+#endif
