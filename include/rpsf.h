@@ -80,7 +80,12 @@ int rpsf_plan_set_transfer_spectra_device(rpsf_plan* plan, const void* s_c64_dev
  * 1 = force atomics, 2 = force planes (error if the corners are not a lattice), 3 = direct: every
  * lattice tile is accumulated in the output image itself, through the L2 of the XCD that runs most of
  * its patches, in processing order (deterministic; 128- and 256-pixel patches on a lattice only;
- * measured slower than the planes, kept for comparison). */
+ * measured slower than the planes, kept for comparison).
+ * 4 = sweep (what 0 selects for 16-, 32- and 64-pixel patches on a complete lattice of at least 2 x 2 patches):
+ * a workgroup owns a region of OUTPUT pixels, walks every patch that touches it and adds the four
+ * contributions of a pixel in LDS, in a fixed order (lattice rows top-down, even patch columns before odd
+ * ones: bit-reproducible and independent of how the lattice is cut); every output pixel is written once,
+ * by the one launch that is the whole apply.  Patches on region borders are computed by both neighbours. */
 int rpsf_plan_set_overlap_mode(rpsf_plan* plan, int mode);
 /* Start-up stagger of the patch kernel's first resident workgroups (microseconds, 0 = off): spreads
  * the gather / K-stream / store phases of different CUs in time so that HBM traffic overlaps compute.

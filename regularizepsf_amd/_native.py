@@ -225,7 +225,7 @@ class Plan:
     def set_overlap_mode(self, mode: str) -> None:
         """'auto' (on lattices: 'direct' for 128/256-pixel patches, 'planes' for smaller ones; 'atomic' otherwise),
         'atomic', 'planes' or 'direct'."""
-        check(lib().rpsf_plan_set_overlap_mode(self._handle, {"auto": 0, "atomic": 1, "planes": 2, "direct": 3}[mode]))
+        check(lib().rpsf_plan_set_overlap_mode(self._handle, {"auto": 0, "atomic": 1, "planes": 2, "direct": 3, "sweep": 4}[mode]))
 
     def debug_stamps(self) -> np.ndarray:
         out = np.zeros((self.n_patches, 16), np.uint64)

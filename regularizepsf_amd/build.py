@@ -15,8 +15,8 @@ import sys
 
 PKG = pathlib.Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
-SOURCES = [CSRC / n for n in ("rpsf.hip", "k1_256.hip", "k1_128.hip", "k1_small.hip", "k2_256.hip", "k2_256p.hip", "k2_128.hip", "k2_128p.hip", "k2_128pc.hip", "k2_128pcs.hip")]
-HEADERS = [CSRC / n for n in ("rpsf_core.hpp", "rpsf_core2.hpp", "rpsf_kernels.hpp", "rpsf_kernels2.hpp", "rpsf_device.hpp", "rpsf_hostpipe.hpp")] + [
+SOURCES = [CSRC / n for n in ("rpsf.hip", "k1_256.hip", "k1_128.hip", "k1_small.hip", "k2_256.hip", "k2_256p.hip", "k2_128.hip", "k2_128p.hip", "k2_128pc.hip", "k2_128pcs.hip", "k3_16.hip", "k3_32.hip", "k3_64.hip")]
+HEADERS = [CSRC / n for n in ("rpsf_core.hpp", "rpsf_core2.hpp", "rpsf_core3.hpp", "rpsf_plan3.hpp", "rpsf_kernels.hpp", "rpsf_kernels2.hpp", "rpsf_kernels3.hpp", "rpsf_device.hpp", "rpsf_hostpipe.hpp")] + [
     PKG.parent / "include" / "rpsf.h"]
 TARGET = PKG / "librpsf_hip.so"
 OBJDIR = PKG / "build"

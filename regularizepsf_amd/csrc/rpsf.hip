@@ -36,6 +36,7 @@
 
 RPSF_PLANS_V1(RPSF_DECL_V1)
 RPSF_PLANS_V2(RPSF_DECL_V2)
+RPSF_PLANS_V3(RPSF_DECL_V3)
 
 // ------------------------------------------------------------------------------------------------
 // error plumbing
@@ -54,6 +55,17 @@ static int fail(int code, const std::string& msg) {
   } while (0)
 
 extern "C" const char* rpsf_last_error(void) { return g_err.c_str(); }
+
+template <class F>
+static int dispatch_v3(int N, F&& f) {
+  switch (N) {
+    case 64: return f.template operator()<Cfg3_64>();
+    case 32: return f.template operator()<Cfg3_32>();
+    case 16: return f.template operator()<Cfg3_16>();
+    default: return fail(RPSF_E_UNSUPPORTED, "no third-generation plan for this patch size");
+  }
+}
+static bool has_v3(int N) { return N == 64 || N == 32 || N == 16; }
 
 // Python's slice arithmetic for [start, stop) over a length-n axis (a negative bound wraps once): the window rule of the saturation fill
 static void py_slice(long start, long stop, long n, long* lo, long* hi) {
@@ -173,10 +185,22 @@ struct rpsf_plan {
   float* d_win_generic = nullptr;
   void* fft_plan = nullptr;    // hipfftHandle for fft_chunk patches
   int fft_chunk = 0;
+  // third generation (rpsf_kernels3.hpp, N <= 64 on a complete lattice of at least 2 x 2 patches): regions, job lists, packed K
+  bool sweep_ok = false;
+  Job3* d_jobs3 = nullptr;
+  Region3* d_regions3 = nullptr;
+  int n_regions3 = 0, ks3 = 0;
+  long slabs3 = 0, patch_slots3 = 0;
+  float* d_k3 = nullptr;      // n_patches x Cfg3::K_FLOATS (a view shares its parent's)
+  float* d_zero3 = nullptr;   // 16 bytes of zeros
+  size_t k3_floats = 0;
   float* d_planes = nullptr;
   size_t planes_floats = 0;  // per plane
   size_t planes_frames = 0;  // frames the allocation holds (4 planes each)
 };
+
+enum OverlapKind { OV_ATOMIC = 0, OV_PLANES = 1, OV_DIRECT = 2, OV_SWEEP = 3 };
+static OverlapKind overlap_kind(const rpsf_plan* p);
 
 static uint64_t morton2(uint32_t a, uint32_t b) {
   auto spread = [](uint64_t x) {
@@ -298,6 +322,25 @@ static int setup_lattice(rpsf_plan* p) {
   }
   if (!ok) return RPSF_OK;
   p->lat_r0 = r0, p->lat_c0 = c0, p->nti = nti, p->ntj = ntj;
+  // ---- third generation: regions and job lists (rpsf_plan3.hpp) when every lattice cell has its patch ----
+  if (has_v3(p->N) && nli >= 2 && nlj >= 2 && (size_t)nli * nlj == (size_t)n) {
+    std::vector<int32_t> slot((size_t)nli * nlj);
+    for (size_t c = 0; c < slot.size(); ++c) slot[c] = p->k_index.empty() ? cell[c] : p->k_index[cell[c]];
+    Plan3 plan;
+    const bool built = dispatch_v3(p->N, [&]<class C>() -> int {
+      return plan3_build(C::N, C::KSMAX, C::WAVES, nli, nlj, slot.data(), par_j, std::max(8, p->cu_count), plan) ? RPSF_OK : RPSF_E_STATE;
+    }) == RPSF_OK;
+    if (built) {
+      HIP_TRY(hipMalloc(&p->d_jobs3, plan.jobs.size() * sizeof(Job3)));
+      HIP_TRY(hipMemcpy(p->d_jobs3, plan.jobs.data(), plan.jobs.size() * sizeof(Job3), hipMemcpyHostToDevice));
+      HIP_TRY(hipMalloc(&p->d_regions3, plan.regions.size() * sizeof(Region3)));
+      HIP_TRY(hipMemcpy(p->d_regions3, plan.regions.data(), plan.regions.size() * sizeof(Region3), hipMemcpyHostToDevice));
+      HIP_TRY(hipMalloc(&p->d_zero3, 64));
+      HIP_TRY(hipMemset(p->d_zero3, 0, 64));
+      p->n_regions3 = (int)plan.regions.size(), p->ks3 = plan.ks, p->slabs3 = plan.slabs, p->patch_slots3 = plan.patch_slots;
+      p->sweep_ok = true;
+    }
+  }
   // ---- tiles: coverage, owner chunk, ranks ----
   std::vector<int> chunk_of(n), seq_of(n);
   for (int s2 = 0; s2 < n; ++s2) chunk_of[p->h_order[s2]] = s2 / chunk, seq_of[p->h_order[s2]] = s2;
@@ -671,6 +714,22 @@ static int plan_create_impl(rpsf_plan** out, int device, int patch_size, int n_p
     HIP_TRY(hipEventCreateWithFlags(&p->ev_busy, hipEventDisableTiming));
     rl = setup_lattice(p);
     if (rl != RPSF_OK) return rl;
+    if (p->sweep_ok) {
+      rl = dispatch_v3(N, [&]<class C>() -> int {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_kernel_kc<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+        if (!parent) {
+          p->k3_floats = (size_t)C::K_FLOATS * n_patches;
+          HIP_TRY(hipMalloc(&p->d_k3, p->k3_floats * sizeof(float)));
+        }
+        return RPSF_OK;
+      });
+      if (rl != RPSF_OK) return rl;
+      if (parent) {
+        if (parent->d_k3) p->d_k3 = parent->d_k3, p->k3_floats = parent->k3_floats;
+        else p->sweep_ok = false;  // (the parent's lattice was not complete: it has no third-generation K)
+      }
+    }
     if (parent) {  // tables and packed K are the parent's
       p->d_tab = parent->d_tab, p->d_pairtab = parent->d_pairtab, p->d_tw = parent->d_tw, p->d_win = parent->d_win;
       p->d_g = parent->d_g, p->d_gs = parent->d_gs, p->g_elems = parent->g_elems, p->gs_elems = parent->gs_elems;
@@ -736,6 +795,10 @@ extern "C" void rpsf_plan_destroy(rpsf_plan* p) {
     p->pipe->destroy();
     delete p->pipe;
   }
+  (void)hipFree(p->d_jobs3);
+  (void)hipFree(p->d_regions3);
+  (void)hipFree(p->d_zero3);
+  if (!p->parent) (void)hipFree(p->d_k3);
   (void)hipFree(p->d_cover);
   (void)hipFree(p->d_desc);
   (void)hipFree(p->d_stamps);
@@ -769,6 +832,16 @@ static void drop_bands(rpsf_plan* p) {
 }
 
 static int pack_range(rpsf_plan* p, const cf* d_kfull, int first_patch, int count) {
+  if (p->d_k3 && !p->parent) {
+    const int rc3 = dispatch_v3(p->N, [&]<class C>() -> int {
+      const size_t total = (size_t)(C::K_FLOATS / 2) * count;
+      pack_kernel3<C><<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, p->stream>>>(
+          d_kfull, count, reinterpret_cast<cf*>(p->d_k3 + (size_t)first_patch * C::K_FLOATS));
+      HIP_TRY(hipGetLastError());
+      return RPSF_OK;
+    });
+    if (rc3 != RPSF_OK) return rc3;
+  }
   if (p->v2)
     return dispatch_v2(p->N, [&]<class C>() -> int {
       const size_t total = ((size_t)C::G_PER_PATCH + C::GS_PER_PATCH) * count;
@@ -855,6 +928,16 @@ extern "C" int rpsf_plan_set_transfer_spectra_device(rpsf_plan* p, const void* s
       return RPSF_OK;
     });
   } else {
+    if (p->d_k3) {
+      rc = dispatch_v3(p->N, [&]<class C>() -> int {
+        const size_t total = (size_t)(C::K_FLOATS / 2) * p->n_patches;
+        pack_spectra_kernel3<C><<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, p->stream>>>(s, t, (float)alpha, (float)epsilon, p->n_patches,
+                                                                                                   reinterpret_cast<cf*>(p->d_k3));
+        HIP_TRY(hipGetLastError());
+        return RPSF_OK;
+      });
+      if (rc != RPSF_OK) return rc;
+    }
     rc = dispatch_n(p->N, [&]<class C>() -> int {
       const size_t total = (size_t)C::G_PER_PATCH * p->n_patches;
       pack_spectra_kernel<C><<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, p->stream>>>(s, t, (float)alpha, (float)epsilon, p->n_patches,
@@ -872,7 +955,8 @@ extern "C" int rpsf_plan_set_transfer_spectra_device(rpsf_plan* p, const void* s
 
 extern "C" int rpsf_plan_transfer_bytes(const rpsf_plan* p, size_t* bytes) {
   if (!p || !bytes) return fail(RPSF_E_BADARG, "null argument");
-  *bytes = (p->g_elems + p->gs_elems) * sizeof(cf);
+  // (the representation the plan's applies read: the third generation's when the sweep kernel runs them)
+  *bytes = p->sweep_ok && overlap_kind(p) == OV_SWEEP ? p->k3_floats * sizeof(float) : (p->g_elems + p->gs_elems) * sizeof(cf);
   return RPSF_OK;
 }
 
@@ -918,7 +1002,6 @@ struct Batch {
   size_t im_stride = 0, out_stride = 0;
 };
 
-enum OverlapKind { OV_ATOMIC = 0, OV_PLANES = 1, OV_DIRECT = 2 };
 
 // Summing workgroups that run beside the patches from the start of a fused launch (multiple of 8: one per XCD), by the
 // amount of work in the launch.  256-pixel plan (512-thread workgroups, one per CU): r02y, a band of 520 patches 130-138 us
@@ -1128,7 +1211,8 @@ static OverlapKind overlap_kind(const rpsf_plan* p) {
     case 1: return OV_ATOMIC;
     case 2: return OV_PLANES;
     case 3: return OV_DIRECT;
-    default: return p->lattice ? OV_PLANES : OV_ATOMIC;  // direct stays opt-in until it beats the planes
+    case 4: return OV_SWEEP;
+    default: return p->sweep_ok ? OV_SWEEP : p->lattice ? OV_PLANES : OV_ATOMIC;  // direct stays opt-in until it beats the planes
   }
 }
 static size_t plane_floats_needed(const rpsf_geometry& g) { return ((size_t)g.out_rows * g.width + 3) & ~(size_t)3; }
@@ -1175,10 +1259,52 @@ static int launch_apply_generic(rpsf_plan* p, const float* d_img, float* d_out, 
   return RPSF_OK;
 }
 
+// Third generation (N <= 64): the whole apply is this one launch (rpsf_kernels3.hpp); frames of a batch along grid.y
+static int launch_sweep(rpsf_plan* p, const float* d_img, float* d_out, const rpsf_geometry& g, hipStream_t st, hipEvent_t ev_k0, hipEvent_t ev_k1,
+                        Batch b) {
+  const int half = p->N / 2;
+  const long r0 = (long)p->lat_r0 + g.origin_row, c0 = (long)p->lat_c0 + g.origin_col;
+  // pixels of the resident window that the lattice does not cover are written by nobody: the reference leaves them zero
+  if (r0 > g.out_row0 || r0 + (long)p->nti * half < (long)g.out_row0 + g.out_rows || c0 > 0 || c0 + (long)p->ntj * half < g.width)
+    for (int f = 0; f < b.frames; ++f)
+      HIP_TRY(hipMemset2DAsync(d_out + (size_t)f * b.out_stride, (size_t)g.ld_out * sizeof(float), 0, (size_t)g.width * sizeof(float), g.out_rows, st));
+  SweepParams sp{};
+  sp.im = ImageView{d_img, g.height, g.width, g.ld_image, g.pad_mode, g.pad_value, g.image_row0, g.image_rows};
+  const bool col_aligned = (c0 & 3) == 0;
+  sp.aligned_in = col_aligned && g.ld_image % 4 == 0 && b.im_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(d_img) & 15) == 0;
+  const int aligned_out = col_aligned && g.ld_out % 4 == 0 && b.out_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0;
+  sp.fl = Flush3{d_out, g.ld_out, g.out_row0, g.out_rows, g.height, g.width, aligned_out};
+  sp.lat_r0 = (int)r0, sp.lat_c0 = (int)c0;
+  sp.jobs = p->d_jobs3, sp.regions = p->d_regions3, sp.n_regions = p->n_regions3, sp.group = (p->n_regions3 + 7) / 8;
+  sp.k3 = p->d_k3, sp.win = p->d_win, sp.zeros = p->d_zero3, sp.err = reinterpret_cast<uint32_t*>(p->d_zero3 + 8);
+  sp.im_frame_floats = b.im_stride, sp.out_frame_floats = b.out_stride;
+  // K by plain loads when frames share it or it is small enough to stay in the Infinity Cache from one apply to the next, else streamed
+  const bool k_plain = b.frames > 1 || p->k3_floats * sizeof(float) <= ((size_t)96 << 20);
+  if (ev_k0) HIP_TRY(hipEventRecord(ev_k0, st));
+  for (int f0 = 0; f0 < b.frames; f0 += 65535) {  // grid.y limit
+    SweepParams q = sp;
+    q.im.img += (size_t)f0 * b.im_stride, q.fl.out += (size_t)f0 * b.out_stride;
+    const dim3 grid((unsigned)(8 * sp.group), (unsigned)std::min(65535, b.frames - f0));
+    const int rc = dispatch_v3(p->N, [&]<class C>() -> int {
+      if (k_plain) sweep_kernel_kc<C><<<grid, dim3(C::WG), C::LDS_BYTES, st>>>(q);
+      else sweep_kernel<C><<<grid, dim3(C::WG), C::LDS_BYTES, st>>>(q);
+      HIP_TRY(hipGetLastError());
+      return RPSF_OK;
+    });
+    if (rc != RPSF_OK) return rc;
+  }
+  if (ev_k1) HIP_TRY(hipEventRecord(ev_k1, st));
+  return RPSF_OK;
+}
+
 static int launch_apply(rpsf_plan* p, const float* d_img, float* d_out, const rpsf_geometry& g, hipStream_t st,
                         hipEvent_t ev_k0, hipEvent_t ev_k1 = nullptr, Batch b = Batch()) {
   if (p->generic) return launch_apply_generic(p, d_img, d_out, g, st, ev_k0, ev_k1, b);
   const OverlapKind kind = overlap_kind(p);
+  if (kind == OV_SWEEP) {
+    if (!p->sweep_ok) return fail(RPSF_E_STATE, "the sweep kernel needs a 16-, 32- or 64-pixel patch on a complete lattice of at least 2 x 2 patches");
+    return launch_sweep(p, d_img, d_out, g, st, ev_k0, ev_k1, b);
+  }
   if (kind != OV_ATOMIC && !p->lattice) return fail(RPSF_E_STATE, "colour planes need a regular half-overlap lattice of patch corners");
   if (kind == OV_DIRECT && !p->direct_ok) return fail(RPSF_E_STATE, "direct overlap-add needs a lattice and a 128- or 256-pixel patch");
   if (kind == OV_DIRECT && (size_t)g.out_rows * g.ld_out * sizeof(float) >= ((size_t)1 << 32))
@@ -1271,7 +1397,8 @@ static int launch_apply(rpsf_plan* p, const float* d_img, float* d_out, const rp
 }
 
 extern "C" int rpsf_plan_set_overlap_mode(rpsf_plan* p, int mode) {
-  if (!p || mode < 0 || mode > 3) return fail(RPSF_E_BADARG, "mode must be 0 (auto), 1 (atomics), 2 (colour planes) or 3 (direct)");
+  if (!p || mode < 0 || mode > 4) return fail(RPSF_E_BADARG, "mode must be 0 (auto), 1 (atomics), 2 (colour planes), 3 (direct) or 4 (sweep)");
+  if (mode == 4 && !p->sweep_ok) return fail(RPSF_E_STATE, "the sweep kernel needs a 16-, 32- or 64-pixel patch on a complete lattice of at least 2 x 2 patches");
   if (mode == 2 && !p->lattice) return fail(RPSF_E_STATE, "colour planes need a regular half-overlap lattice of patch corners");
   if (mode == 3 && !p->direct_ok) return fail(RPSF_E_STATE, "direct overlap-add needs a regular half-overlap lattice and a 128- or 256-pixel patch");
   p->overlap_mode = mode;
@@ -1373,7 +1500,7 @@ extern "C" int rpsf_apply_device(rpsf_plan* p, const void* image_dev, void* out_
 // Frames per launch group: the colour planes take 16 bytes per output pixel per frame in flight; keep
 // them under a quarter of the device memory.
 static int batch_group_frames(const rpsf_plan* p, const rpsf_geometry& g, int n_frames) {
-  if (p->generic || overlap_kind(p) == OV_ATOMIC) return n_frames;
+  if (p->generic || overlap_kind(p) == OV_ATOMIC || overlap_kind(p) == OV_SWEEP) return n_frames;
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) total_b = (size_t)64 << 30;
   const size_t per_frame = 16 * plane_floats_needed(g);
@@ -1546,7 +1673,7 @@ static int ensure_bands(rpsf_plan* p, const rpsf_geometry& g, int want) {
   if (p->bands_h == g.height && p->bands_w == g.width && p->bands_mode == g.pad_mode && p->bands_want == want) return (int)p->bands.size();
   drop_bands(p);
   p->bands_h = g.height, p->bands_w = g.width, p->bands_mode = g.pad_mode, p->bands_want = want;  // (remembered also when the answer is "no bands")
-  if (p->generic || p->parent || !p->lattice || overlap_kind(p) != OV_PLANES || g.pad_mode == RPSF_PAD_WRAP || want < 2) return 0;
+  if (p->generic || p->parent || !p->lattice || (overlap_kind(p) != OV_PLANES && overlap_kind(p) != OV_SWEEP) || g.pad_mode == RPSF_PAD_WRAP || want < 2) return 0;
   const int N = p->N, H = g.height;
   std::vector<int> rows;
   for (int i = 0; i < p->n_patches; ++i) rows.push_back(p->h_coords[2 * i]);

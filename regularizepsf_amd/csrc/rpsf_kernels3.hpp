@@ -22,6 +22,7 @@ struct SweepParams {
   const float* zeros;  // 16 bytes of zeros
   size_t im_frame_floats, out_frame_floats;
   int aligned_in;  // 16-byte gathers allowed (image pointer, row stride and column origin multiples of four floats)
+  uint32_t* err;   // set to non-zero if a dependency wait ran into its bound (never, unless the job lists are wrong)
 };
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
@@ -58,10 +59,16 @@ __device__ __forceinline__ void sweep_body(const SweepParams& P) {
   const uint32_t flags_off = lds_u32_offset(flags), next_off = lds_u32_offset(next);
   for (;;) {
     // ---- draw the next job of the region ----
-    uint32_t drawn = 0;
-    if (lane == 0) {
+    // (one lane draws; the exec mask is narrowed inside the asm statement so that the compiler sees uniform control flow around it)
+    uint32_t drawn;
+    {
       const uint32_t one = 1;
-      asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(drawn) : "v"(next_off), "v"(one) : "memory");
+      uint64_t saved;
+      asm volatile(
+          "s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tds_add_rtn_u32 %0, %2, %3\n\ts_waitcnt lgkmcnt(0)\n\ts_mov_b64 exec, %1"
+          : "=&v"(drawn), "=&s"(saved)
+          : "v"(next_off), "v"(one)
+          : "memory");
     }
     const int j = (int)__builtin_amdgcn_readfirstlane(drawn);
     if (j >= reg.njobs) break;
@@ -125,24 +132,20 @@ __device__ __forceinline__ void sweep_body(const SweepParams& P) {
     // ---- wait for the jobs this one overlaps, then add ----
     {
       const int d0 = jd->dep0, d1 = jd->dep1;
-      if (d0 >= 0) {
-        const uint32_t a0 = flags_off + 4u * ((uint32_t)d0 & (C::NFLAGS - 1)), want = (uint32_t)d0 + 1;
-        uint32_t seen;
-        do {
-          asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(a0) : "memory");
-          if (__builtin_amdgcn_readfirstlane(seen) >= want) break;
+      // (bounded: a protocol error must not hang the GPU - it is reported through P.err instead; 2^22 polls of ~0.1 us are far beyond any real wait)
+      auto wait_for = [&](int d) RPSF_AI {
+        if (d < 0) return;
+        const uint32_t a = flags_off + 4u * ((uint32_t)d & (C::NFLAGS - 1)), want = (uint32_t)d + 1;
+        for (int spin = 0; spin < (1 << 22); ++spin) {
+          uint32_t seen;
+          asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(a) : "memory");
+          if (__builtin_amdgcn_readfirstlane(seen) >= want) return;
           __builtin_amdgcn_s_sleep(2);
-        } while (true);
-      }
-      if (d1 >= 0) {
-        const uint32_t a1 = flags_off + 4u * ((uint32_t)d1 & (C::NFLAGS - 1)), want = (uint32_t)d1 + 1;
-        uint32_t seen;
-        do {
-          asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(a1) : "memory");
-          if (__builtin_amdgcn_readfirstlane(seen) >= want) break;
-          __builtin_amdgcn_s_sleep(2);
-        } while (true);
-      }
+        }
+        if (lane == 0) atomicOr(P.err, 1u);
+      };
+      wait_for(d0);
+      wait_for(d1);
     }
     const int hs = (jflags & J3_RING_HALF) ? 1 : 0;
     {
@@ -161,7 +164,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& P) {
       if (jflags & J3_FLUSH_LOWER) flush3<C>(lane, ring + ((hs ^ 1) * H) * C::RP + jd->ring_col, fl, row0 + H, col0, oc0, oc1, st4, st1);
     }
     // ---- done: LDS executes a wave's instructions in order, so whoever sees the flag sees the adds (and the flush has read its rows) ----
-    if (lane == 0) {
+    {  // (every lane stores the same word: no branch)
       const uint32_t a = flags_off + 4u * ((uint32_t)j & (C::NFLAGS - 1)), val = (uint32_t)j + 1;
       asm volatile("s_waitcnt lgkmcnt(0)\n\tds_write_b32 %0, %1" : : "v"(a), "v"(val) : "memory");
     }
