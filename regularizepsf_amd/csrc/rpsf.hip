@@ -193,6 +193,7 @@ struct rpsf_plan {
   long slabs3 = 0, patch_slots3 = 0;
   float* d_k3 = nullptr;      // n_patches x Cfg3::K_FLOATS (a view shares its parent's)
   float* d_zero3 = nullptr;   // 16 bytes of zeros
+  unsigned long long* d_stamps3 = nullptr;  // development builds (-DRPSF3_STAMPS)
   size_t k3_floats = 0;
   float* d_planes = nullptr;
   size_t planes_floats = 0;  // per plane
@@ -339,6 +340,10 @@ static int setup_lattice(rpsf_plan* p) {
       HIP_TRY(hipMemset(p->d_zero3, 0, 64));
       p->n_regions3 = (int)plan.regions.size(), p->ks3 = plan.ks, p->slabs3 = plan.slabs, p->patch_slots3 = plan.patch_slots;
       p->sweep_ok = true;
+#if defined(RPSF3_STAMPS) || defined(RPSF3_DUMP)
+      HIP_TRY(hipMalloc(&p->d_stamps3, (size_t)std::max(512, p->n_regions3) * 8 * 8 * 16 * sizeof(unsigned long long)));
+      HIP_TRY(hipMemset(p->d_stamps3, 0, (size_t)std::max(512, p->n_regions3) * 8 * 8 * 16 * sizeof(unsigned long long)));
+#endif
     }
   }
   // ---- tiles: coverage, owner chunk, ranks ----
@@ -798,6 +803,7 @@ extern "C" void rpsf_plan_destroy(rpsf_plan* p) {
   (void)hipFree(p->d_jobs3);
   (void)hipFree(p->d_regions3);
   (void)hipFree(p->d_zero3);
+  (void)hipFree(p->d_stamps3);
   if (!p->parent) (void)hipFree(p->d_k3);
   (void)hipFree(p->d_cover);
   (void)hipFree(p->d_desc);
@@ -1276,7 +1282,7 @@ static int launch_sweep(rpsf_plan* p, const float* d_img, float* d_out, const rp
   sp.fl = Flush3{d_out, g.ld_out, g.out_row0, g.out_rows, g.height, g.width, aligned_out};
   sp.lat_r0 = (int)r0, sp.lat_c0 = (int)c0;
   sp.jobs = p->d_jobs3, sp.regions = p->d_regions3, sp.n_regions = p->n_regions3, sp.group = (p->n_regions3 + 7) / 8;
-  sp.k3 = p->d_k3, sp.win = p->d_win, sp.zeros = p->d_zero3, sp.err = reinterpret_cast<uint32_t*>(p->d_zero3 + 8);
+  sp.k3 = p->d_k3, sp.win = p->d_win, sp.zeros = p->d_zero3, sp.err = reinterpret_cast<uint32_t*>(p->d_zero3 + 8), sp.stamps = p->d_stamps3;
   sp.im_frame_floats = b.im_stride, sp.out_frame_floats = b.out_stride;
   // K by plain loads when frames share it or it is small enough to stay in the Infinity Cache from one apply to the next, else streamed
   const bool k_plain = b.frames > 1 || p->k3_floats * sizeof(float) <= ((size_t)96 << 20);
@@ -1409,6 +1415,13 @@ extern "C" int rpsf_plan_set_overlap_mode(rpsf_plan* p, int mode) {
 // Diagnostic builds only (-DRPSF_STAMPS): copy out the 16 per-patch phase timestamps (10 ns ticks).
 extern "C" int rpsf_plan_debug_stamps(rpsf_plan* p, unsigned long long* host, size_t count) {
   if (!p || !host) return fail(RPSF_E_BADARG, "null argument");
+  if (p->d_stamps3) {  // third generation: [region][wave][job slot < 8][16]
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipDeviceSynchronize());
+    count = std::min(count, (size_t)std::max(512, p->n_regions3) * 8 * 8 * 16);
+    HIP_TRY(hipMemcpy(host, p->d_stamps3, count * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return RPSF_OK;
+  }
   if (!p->d_stamps) return fail(RPSF_E_STATE, "phase timestamps exist only in builds with -DRPSF_STAMPS");
   HIP_TRY(hipSetDevice(p->device));
   HIP_TRY(hipDeviceSynchronize());

@@ -23,6 +23,8 @@
 //   inverse column DFT, back to rows, U'[k] = V_p[k] + i V_{p+H}[k], U'[N-k] = conj V_p[k] + i conj V_{p+H}[k], inverse row DFT:
 //   u'[c] = y[p][c] + i y[p+H][c], the patch's contribution before the second window.
 #pragma once
+#include <type_traits>
+
 #include "rpsf_core.hpp"
 
 namespace rpsf {
@@ -62,12 +64,12 @@ struct Cfg3 {
   static constexpr int P0 = N + 4, Q0 = pad_mod32(H * P0, H);
   static constexpr int P1 = H + 4, Q1 = pad_mod32(N * P1, H);
   static constexpr int XF = PPP * (Q0 > Q1 ? Q0 : Q1);  // floats per wave
-  // ring of the region's output rows in LDS: N rows x RP floats; RP / 2 odd (the 4-byte adds of 16 or 32 consecutive rows hit different
-  // banks; 8-byte reads of the flush stay aligned)
+  // ring of the region's output rows in LDS: N rows x RP floats; RP / 4 odd (the 16-byte accesses of 16 consecutive rows - one lane each -
+  // hit 64 different banks; the flush reads whole 16-byte units)
   static constexpr int KSMAX = KSMAX_;                 // slabs per parity and lattice row of a region
   static constexpr int RINGW = SLABW * KSMAX + H;
-  static constexpr int RP = RINGW + 2;
-  static_assert((RP / 2) % 2 == 1, "ring pitch");
+  static constexpr int RP = RINGW + 4;
+  static_assert(RP % 4 == 0 && (RP / 4) % 2 == 1, "ring pitch");
   static constexpr int RINGF = N * RP;
   static constexpr int NFLAGS = 256;
   static constexpr size_t LDS_BYTES = sizeof(float) * ((size_t)RINGF + (size_t)WAVES * XF) + sizeof(uint32_t) * (NFLAGS + 4);
@@ -259,18 +261,29 @@ enum Acc3 : int { ACC_SKIP = 0, ACC_STORE = 1, ACC_ADD = 2 };
 // upper: the lane's row p of the slab (real parts), lower: row p + H (imaginary parts); ru / rl: their ring rows at the patch's first column
 template <class C>
 RPSF_HD void accumulate3(const cf* v, float w_re, float w_im, bool valid, float* ru, float* rl, int mode_u, int mode_l) {
+  // (an invalid patch contributes exact zeros, whatever its pixels were)
   const float su = valid ? w_re : 0.0f, sl = valid ? w_im : 0.0f;
-  auto val = [&](float x, float s, float wc) RPSF_AI { return valid ? (x * s) * wc : 0.0f; };  // (an invalid patch contributes exact zeros, whatever its pixels were)
-  if (mode_u == ACC_STORE) {
-    StaticFor<0, C::N>::run([&]<int I>() RPSF_AI { ru[I] = val(v[I].x, su, win3<C::N>(I)); });
-  } else if (mode_u == ACC_ADD) {
-    StaticFor<0, C::N>::run([&]<int I>() RPSF_AI { lds_add1(ru + I, val(v[I].x, su, win3<C::N>(I))); });
-  }
-  if (mode_l == ACC_STORE) {
-    StaticFor<0, C::N>::run([&]<int I>() RPSF_AI { rl[I] = val(v[I].y, sl, win3<C::N>(I)); });
-  } else if (mode_l == ACC_ADD) {
-    StaticFor<0, C::N>::run([&]<int I>() RPSF_AI { lds_add1(rl + I, val(v[I].y, sl, win3<C::N>(I))); });
-  }
+  // The jobs of a region are ordered by their flags (rpsf_kernels3.hpp), so nobody else touches these words meanwhile: plain 16-byte
+  // read - add - write.  (LDS float atomics - ds_add_f32 - take about two clocks per LANE on gfx950: 64 of them per job kept the LDS of the
+  // CU busy for 9,750 of a job's 12,600 clocks, profiles/r06c.)
+  auto half = [&](auto re_part, float s, float* r, int mode) RPSF_AI {
+    if (mode == ACC_SKIP) return;
+    StaticFor<0, C::N / 4>::run([&]<int J>() RPSF_AI {
+      constexpr float w0 = win3<C::N>(4 * J), w1 = win3<C::N>(4 * J + 1), w2 = win3<C::N>(4 * J + 2), w3 = win3<C::N>(4 * J + 3);
+      constexpr bool RE = decltype(re_part)::value;
+      const float x0 = RE ? v[4 * J].x : v[4 * J].y, x1 = RE ? v[4 * J + 1].x : v[4 * J + 1].y;
+      const float x2 = RE ? v[4 * J + 2].x : v[4 * J + 2].y, x3 = RE ? v[4 * J + 3].x : v[4 * J + 3].y;
+      f32x4 t = f32x4{(x0 * s) * w0, (x1 * s) * w1, (x2 * s) * w2, (x3 * s) * w3};
+      if (!valid) t = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (mode == ACC_ADD) {
+        const f32x4 o = lds_ld4(r + 4 * J);
+        t = f32x4{o.x + t.x, o.y + t.y, o.z + t.z, o.w + t.w};
+      }
+      lds_st4(r + 4 * J, t);
+    });
+  };
+  half(std::true_type(), su, ru, mode_u);
+  half(std::false_type(), sl, rl, mode_l);
 }
 
 // ---- flush: H finished ring rows x the slab's 128 columns -> the output image (transform.py:174-177, float32 here) ------------------
@@ -289,7 +302,8 @@ RPSF_HD void flush3(int lane, const float* ring_band /*ring row of the band's fi
   StaticFor<0, C::H / 2>::run([&]<int I>() RPSF_AI {
     const int r = band_row + 2 * I + hf;
     const float* src = ring_band + (2 * I + hf) * C::RP + 4 * u;
-    const f32x2 a = lds_ld2(src), b = lds_ld2(src + 2);
+    const f32x4 ab = lds_ld4(src);
+    const f32x2 a = f32x2{ab.x, ab.y}, b = f32x2{ab.z, ab.w};
     if (r >= f.row0 && r < f.row0 + f.rows && r >= 0 && r < f.Himg) {
       float* dst = f.out + (size_t)(r - f.row0) * f.ld + c;
       if (f.aligned && c >= lo && c + 4 <= hi) {
@@ -327,8 +341,24 @@ RPSF_HD cf pack_value3(const KF& kfull, int idx) {
   return cf{(x0.x - xh.x) * (0.5f * C::SCALE), (x0.y - xh.y) * (0.5f * C::SCALE)};
 }
 
-using Cfg3_16 = Cfg3<4, 4>;
-using Cfg3_32 = Cfg3<5, 2>;
-using Cfg3_64 = Cfg3<6, 2>;
+// (development sweeps: -DRPSF3_W16=.. etc. select other wave counts)
+#if !defined(RPSF3_W16)
+#define RPSF3_W16 8
+#endif
+#if !defined(RPSF3_W32)
+#define RPSF3_W32 8
+#endif
+#if !defined(RPSF3_W64)
+#define RPSF3_W64 8
+#endif
+#if !defined(RPSF3_KS16)
+#define RPSF3_KS16 4
+#endif
+#if !defined(RPSF3_KS32)
+#define RPSF3_KS32 2
+#endif
+using Cfg3_16 = Cfg3<4, RPSF3_KS16, RPSF3_W16>;
+using Cfg3_32 = Cfg3<5, RPSF3_KS32, RPSF3_W32>;
+using Cfg3_64 = Cfg3<6, 2, RPSF3_W64>;
 
 }  // namespace rpsf

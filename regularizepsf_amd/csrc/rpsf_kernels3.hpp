@@ -22,6 +22,7 @@ struct SweepParams {
   const float* zeros;  // 16 bytes of zeros
   size_t im_frame_floats, out_frame_floats;
   int aligned_in;  // 16-byte gathers allowed (image pointer, row stride and column origin multiples of four floats)
+  unsigned long long* stamps;  // development builds: phase timestamps / dumps, else null
   uint32_t* err;   // set to non-zero if a dependency wait ran into its bound (never, unless the job lists are wrong)
 };
 

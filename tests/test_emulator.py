@@ -142,3 +142,76 @@ def test_slot_table_keeps_the_gid_indexed_exchange_free_of_bank_conflicts(emu2, 
     halves, runs = ns * (t // 64) * 2 * 2, ns * (t // 64) * 4 * 2
     assert read_cycles == halves, (read_cycles, halves)
     assert write_cycles <= runs + 4 and worst_write <= 2, (write_cycles, runs, worst_write)
+
+
+# ---- third generation (N = 16, 32, 64): the sweep kernel's per-lane phases and its job lists ----------------------------------
+EMU3_SRC = ROOT / "tests" / "emu" / "emu3.cpp"
+EMU3_LIB = ROOT / "tests" / "emu" / "libemu3.so"
+CORE3 = [ROOT / "regularizepsf_amd" / "csrc" / n for n in ("rpsf_core.hpp", "rpsf_core3.hpp", "rpsf_plan3.hpp")]
+
+
+@pytest.fixture(scope="module")
+def emu3():
+    if not EMU3_LIB.exists() or EMU3_LIB.stat().st_mtime < max([EMU3_SRC.stat().st_mtime] + [c.stat().st_mtime for c in CORE3]):
+        clang = "/opt/rocm/lib/llvm/bin/clang++"
+        if not pathlib.Path(clang).exists():
+            clang = shutil.which("clang++")
+        if clang is None:
+            pytest.skip("no clang++ to build the emulator")
+        subprocess.run([clang, "-std=c++20", "-O1", "-shared", "-fPIC", "-o", str(EMU3_LIB), str(EMU3_SRC)], check=True)
+    lib = ctypes.CDLL(str(EMU3_LIB))
+    lib.emu3_check_plan.restype = ctypes.c_long
+    return lib
+
+
+def _emu3_run(emu3, case, target_regions, order_seed, aligned):
+    fx, coords, k = load_apply_case(case)
+    image = np.ascontiguousarray(fx["image"], np.float32)
+    h, w = image.shape
+    c = np.ascontiguousarray(np.array(coords, np.int32))
+    kk = np.ascontiguousarray(k, np.complex64)
+    out = np.full((h, w), np.nan, np.float32)
+    stats = (ctypes.c_int64 * 4)()
+    vp = ctypes.c_void_p
+    rc = emu3.emu3_apply(k.shape[1], len(coords), c.ctypes.data_as(vp), h, w, MODES[str(fx["pad_mode"])], ctypes.c_float(0.0),
+                         image.ctypes.data_as(vp), kk.ctypes.data_as(vp), out.ctypes.data_as(vp), target_regions, order_seed, aligned, stats)
+    assert rc == 0, rc  # (-6: a pixel written twice, -7: a covered pixel never written, -4: a job waits for one not yet drawn)
+    return out, fx, list(stats)
+
+
+@pytest.mark.parametrize("case", [c[0] for c in APPLY_CASES if c[7] in MODES and c[3] <= 64])
+def test_emulated_sweep_kernel_matches_reference_golden(emu3, case):
+    """The lane phases of the third-generation kernel (transposes, row-pair packing, packed K with the a / b rule of column 0,
+    ring addressing, store / add / flush modes) over the library's own job lists, every output pixel written exactly once."""
+    out, fx, _ = _emu3_run(emu3, case, 8, 0, 1)
+    rel_max, rel_l2 = rel_errors(out, fx["expected"])
+    assert rel_max <= 1e-5 and rel_l2 <= 1e-5, (rel_max, rel_l2)
+
+
+@pytest.mark.parametrize("case", ["n32_sym", "n32_constant", "n16_sym", "n64_sym"])
+def test_sweep_result_does_not_depend_on_the_cut_or_on_the_waves_timing(emu3, case):
+    """Bit for bit the same image whatever the number of regions, whether the 16-byte paths are taken, and in whatever order
+    the dependency flags let the jobs of a region finish."""
+    base, _, _ = _emu3_run(emu3, case, 8, 0, 1)
+    for target, seed, aligned in ((8, 1, 1), (8, 2, 1), (64, 3, 1), (1, 4, 1), (256, 5, 0), (3, 0, 0)):
+        out, _, _ = _emu3_run(emu3, case, target, seed, aligned)
+        assert np.array_equal(out, base), (target, seed, aligned)
+
+
+def test_sweep_job_lists_order_every_conflicting_pair_and_flush_every_band_once(emu3):
+    """rpsf_plan3.hpp over a grid of lattice shapes: two jobs of a region that touch the same ring words inside the owned columns (one of
+    them writing) are ordered by the dependency lists, and every (row band, column band) cell is flushed by exactly one job."""
+    for n, ksmax in ((16, 4), (32, 2), (64, 2)):
+        for nli in (2, 3, 4, 5, 9, 17, 33, 65, 129):
+            for nlj in (2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 33, 63, 64, 65, 129):
+                for target in (1, 8, 256, 1024):
+                    stats = (ctypes.c_int64 * 4)()
+                    assert emu3.emu3_check_plan(n, ksmax, 8, nli, nlj, target, stats) == 0, (n, nli, nlj, target, list(stats))
+
+
+def test_sweep_recompute_factor_at_the_benchmark_sizes(emu3):
+    """Patches on region borders are computed twice: the planner keeps that below what the LDS ring allows at the sizes VERDICT round 5 names."""
+    for n, ksmax, lattice, bound in ((32, 2, 257, 1.16), (64, 2, 129, 1.30), (16, 4, 513, 1.09)):
+        stats = (ctypes.c_int64 * 4)()
+        assert emu3.emu3_check_plan(n, ksmax, 8, lattice, lattice, 256, stats) == 0
+        assert stats[2] / (lattice * lattice) <= bound, (n, list(stats))
