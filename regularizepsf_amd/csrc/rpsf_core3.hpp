@@ -258,23 +258,29 @@ RPSF_HD void t2_read(int lane, cf* v, const float* xb) {
 
 // ---- second window and overlap-add into the ring (transform.py:165-169) ---------------------------------------------------------
 enum Acc3 : int { ACC_SKIP = 0, ACC_STORE = 1, ACC_ADD = 2 };
-// upper: the lane's row p of the slab (real parts), lower: row p + H (imaginary parts); ru / rl: their ring rows at the patch's first column
+// second window, in place (transform.py:165); an invalid patch contributes exact zeros, whatever its pixels were
 template <class C>
-RPSF_HD void accumulate3(const cf* v, float w_re, float w_im, bool valid, float* ru, float* rl, int mode_u, int mode_l) {
-  // (an invalid patch contributes exact zeros, whatever its pixels were)
-  const float su = valid ? w_re : 0.0f, sl = valid ? w_im : 0.0f;
-  // The jobs of a region are ordered by their flags (rpsf_kernels3.hpp), so nobody else touches these words meanwhile: plain 16-byte
-  // read - add - write.  (LDS float atomics - ds_add_f32 - take about two clocks per LANE on gfx950: 64 of them per job kept the LDS of the
-  // CU busy for 9,750 of a job's 12,600 clocks, profiles/r06c.)
-  auto half = [&](auto re_part, float s, float* r, int mode) RPSF_AI {
+RPSF_HD void window_out(cf* v, float w_re, float w_im, bool valid) {
+  StaticFor<0, C::N>::run([&]<int I>() RPSF_AI {
+    constexpr float wc = win3<C::N>(I);
+    const float x = (v[I].x * w_re) * wc, y = (v[I].y * w_im) * wc;
+    v[I].x = valid ? x : 0.0f;
+    v[I].y = valid ? y : 0.0f;
+  });
+}
+// upper: the lane's row p of the slab (real parts), lower: row p + H (imaginary parts); ru / rl: their ring rows at the patch's first column.
+// The jobs of a region are ordered by their flags (rpsf_kernels3.hpp), so nobody else touches these words meanwhile: plain 16-byte
+// read - add - write.  (LDS float atomics - ds_add_f32 - take about two clocks per LANE on gfx950: 64 of them per job kept the LDS of the
+// CU busy for 9,750 of a job's 12,600 clocks, profiles/r06c.)
+template <class C>
+RPSF_HD void accumulate3(const cf* v, float* ru, float* rl, int mode_u, int mode_l) {
+  auto half = [&](auto re_part, float* r, int mode) RPSF_AI {
     if (mode == ACC_SKIP) return;
     StaticFor<0, C::N / 4>::run([&]<int J>() RPSF_AI {
-      constexpr float w0 = win3<C::N>(4 * J), w1 = win3<C::N>(4 * J + 1), w2 = win3<C::N>(4 * J + 2), w3 = win3<C::N>(4 * J + 3);
       constexpr bool RE = decltype(re_part)::value;
       const float x0 = RE ? v[4 * J].x : v[4 * J].y, x1 = RE ? v[4 * J + 1].x : v[4 * J + 1].y;
       const float x2 = RE ? v[4 * J + 2].x : v[4 * J + 2].y, x3 = RE ? v[4 * J + 3].x : v[4 * J + 3].y;
-      f32x4 t = f32x4{(x0 * s) * w0, (x1 * s) * w1, (x2 * s) * w2, (x3 * s) * w3};
-      if (!valid) t = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      f32x4 t = f32x4{x0, x1, x2, x3};
       if (mode == ACC_ADD) {
         const f32x4 o = lds_ld4(r + 4 * J);
         t = f32x4{o.x + t.x, o.y + t.y, o.z + t.z, o.w + t.w};
@@ -282,8 +288,8 @@ RPSF_HD void accumulate3(const cf* v, float w_re, float w_im, bool valid, float*
       lds_st4(r + 4 * J, t);
     });
   };
-  half(std::true_type(), su, ru, mode_u);
-  half(std::false_type(), sl, rl, mode_l);
+  half(std::true_type(), ru, mode_u);
+  half(std::false_type(), rl, mode_l);
 }
 
 // ---- flush: H finished ring rows x the slab's 128 columns -> the output image (transform.py:174-177, float32 here) ------------------
@@ -293,9 +299,9 @@ struct Flush3 {
   int ld, row0, rows, Himg, Wimg;
   int aligned;  // 16-byte stores allowed (ld, column origin and pointer multiples of four floats)
 };
+// G-layout: unit i < H / 2 = rows 2i and 2i + 1 of the band, lane = (row parity, 16-byte unit of the 128 columns)
 template <class C, class Store4, class Store1>
-RPSF_HD void flush3(int lane, const float* ring_band /*ring row of the band's first row, at the slab's first column*/, const Flush3& f, int band_row, int col0,
-                    int oc0, int oc1, Store4&& st4, Store1&& st1) {
+RPSF_HD void flush3(int lane, const float* ring_band, const Flush3& f, int band_row, int col0, int oc0, int oc1, Store4&& st4, Store1&& st1) {
   const int u = lane & 31, hf = lane >> 5;
   const int c = col0 + 4 * u;
   const int lo = oc0 > 0 ? oc0 : 0, hi = oc1 < f.Wimg ? oc1 : f.Wimg;
@@ -303,16 +309,15 @@ RPSF_HD void flush3(int lane, const float* ring_band /*ring row of the band's fi
     const int r = band_row + 2 * I + hf;
     const float* src = ring_band + (2 * I + hf) * C::RP + 4 * u;
     const f32x4 ab = lds_ld4(src);
-    const f32x2 a = f32x2{ab.x, ab.y}, b = f32x2{ab.z, ab.w};
     if (r >= f.row0 && r < f.row0 + f.rows && r >= 0 && r < f.Himg) {
       float* dst = f.out + (size_t)(r - f.row0) * f.ld + c;
       if (f.aligned && c >= lo && c + 4 <= hi) {
-        st4(dst, f32x4{a.x, a.y, b.x, b.y});
+        st4(dst, ab);
       } else {
-        if (c >= lo && c < hi) st1(dst, a.x);
-        if (c + 1 >= lo && c + 1 < hi) st1(dst + 1, a.y);
-        if (c + 2 >= lo && c + 2 < hi) st1(dst + 2, b.x);
-        if (c + 3 >= lo && c + 3 < hi) st1(dst + 3, b.y);
+        if (c >= lo && c < hi) st1(dst, ab.x);
+        if (c + 1 >= lo && c + 1 < hi) st1(dst + 1, ab.y);
+        if (c + 2 >= lo && c + 2 < hi) st1(dst + 2, ab.z);
+        if (c + 3 >= lo && c + 3 < hi) st1(dst + 3, ab.w);
       }
     }
   });

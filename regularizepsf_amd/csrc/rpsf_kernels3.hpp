@@ -41,7 +41,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& P) {
   constexpr int N = C::N, H = C::H;
   extern __shared__ __attribute__((aligned(16))) float lds3[];
   float* ring = lds3;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid = threadIdx.x, lane0 = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* xb = ring + C::RINGF + wave * C::XF;
   uint32_t* flags = reinterpret_cast<uint32_t*>(ring + C::RINGF + C::WAVES * C::XF);
   uint32_t* next = flags + C::NFLAGS;
@@ -55,10 +55,14 @@ __device__ __forceinline__ void sweep_body(const SweepParams& P) {
   Flush3 fl = P.fl;
   im.img += (size_t)blockIdx.y * P.im_frame_floats;
   fl.out += (size_t)blockIdx.y * P.out_frame_floats;
-  const int q = lane / H, p = lane % H;
-  const float w_re = P.win[p], w_im = P.win[p + H];
+  const float w_re = P.win[lane0 % H], w_im = P.win[lane0 % H + H];
   const uint32_t flags_off = lds_u32_offset(flags), next_off = lds_u32_offset(next);
   for (;;) {
+    // (per-lane addresses are recomputed every pass: hoisted out of the loop - the compiler's choice otherwise - they stay live across the
+    // whole body and cost registers)
+    int ln = lane0;
+    asm volatile("" : "+v"(ln));
+    const int lane = ln, q = lane / H, p = lane % H;
     // ---- draw the next job of the region ----
     // (one lane draws; the exec mask is narrowed inside the asm statement so that the compiler sees uniform control flow around it)
     uint32_t drawn;
@@ -74,8 +78,12 @@ __device__ __forceinline__ void sweep_body(const SweepParams& P) {
     const int j = (int)__builtin_amdgcn_readfirstlane(drawn);
     if (j >= reg.njobs) break;
     const Job3* jd = P.jobs + reg.job0 + j;
-    const int jrow = jd->row, jcol = jd->col;
-    const uint32_t jflags = jd->flags;
+    // the descriptor through the scalar cache (a uniform address in the constant address space)
+    typedef const int __attribute__((address_space(4))) cint_as4;
+    const cint_as4* jds = (const cint_as4*)(const void*)jd;
+    const int jrow = jds[0], jcol = jds[1], jring_col = jds[2];
+    const uint32_t jflags = (uint32_t)jds[3];
+    const int jdep0 = jds[4], jdep1 = jds[5], jown0 = jds[6], jown1 = jds[7];
     const int row0 = P.lat_r0 + jrow, col0 = P.lat_c0 + jcol;
     const int kslot = jd->kslot[q];
     // ---- gather ----
@@ -130,9 +138,11 @@ __device__ __forceinline__ void sweep_body(const SweepParams& P) {
     });
     repack_rows<C>(v);
     FftSmall<C::LOGN, true>::run(v);
+    // second window before the wait: what follows the wait is what the jobs behind this one wait for
+    window_out<C>(v, w_re, w_im, ((jflags >> (J3_VALID_SHIFT + q)) & 1u) != 0);
     // ---- wait for the jobs this one overlaps, then add ----
     {
-      const int d0 = jd->dep0, d1 = jd->dep1;
+      const int d0 = jdep0, d1 = jdep1;
       // (bounded: a protocol error must not hang the GPU - it is reported through P.err instead; 2^22 polls of ~0.1 us are far beyond any real wait)
       auto wait_for = [&](int d) RPSF_AI {
         if (d < 0) return;
@@ -141,33 +151,36 @@ __device__ __forceinline__ void sweep_body(const SweepParams& P) {
           uint32_t seen;
           asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(a) : "memory");
           if (__builtin_amdgcn_readfirstlane(seen) >= want) return;
-          __builtin_amdgcn_s_sleep(2);
+          __builtin_amdgcn_s_sleep(1);
         }
-        if (lane == 0) atomicOr(P.err, 1u);
+        if (lane0 == 0) atomicOr(P.err, 1u);
       };
       wait_for(d0);
       wait_for(d1);
     }
+    __builtin_amdgcn_s_setprio(3);  // (the adds of a job are what the jobs after it wait for: they go first in the SIMD's arbitration)
     const int hs = (jflags & J3_RING_HALF) ? 1 : 0;
     {
-      const bool valid = ((jflags >> (J3_VALID_SHIFT + q)) & 1u) != 0;
-      float* ru = ring + (hs * H + p) * C::RP + jd->ring_col + q * N;
-      float* rl = ring + ((hs ^ 1) * H + p) * C::RP + jd->ring_col + q * N;
-      accumulate3<C>(v, w_re, w_im, valid, ru, rl, (int)((jflags >> J3_UPPER_SHIFT) & 3u), (int)((jflags >> J3_LOWER_SHIFT) & 3u));
+      float* ru = ring + (hs * H + p) * C::RP + jring_col + q * N;
+      float* rl = ring + ((hs ^ 1) * H + p) * C::RP + jring_col + q * N;
+      accumulate3<C>(v, ru, rl, (int)((jflags >> J3_UPPER_SHIFT) & 3u), (int)((jflags >> J3_LOWER_SHIFT) & 3u));
     }
     // ---- phase B: the band(s) this slab has completed go to the output image ----
+    // (read and stored unit by unit: a version that read the band into a register array first, released the flag and stored afterwards
+    // gave wrong images on the GPU - and right ones in the emulator - in every form tried, profiles/r06i)
     if (jflags & (J3_FLUSH_UPPER | J3_FLUSH_LOWER)) {
       lds_fence_wave();
       auto st4 = [](float* dst, f32x4 x) RPSF_AI { __builtin_nontemporal_store(x, reinterpret_cast<f32x4*>(dst)); };
       auto st1 = [](float* dst, float x) RPSF_AI { __builtin_nontemporal_store(x, dst); };
-      const int oc0 = P.lat_c0 + jd->own_c0, oc1 = P.lat_c0 + jd->own_c1;
-      if (jflags & J3_FLUSH_UPPER) flush3<C>(lane, ring + (hs * H) * C::RP + jd->ring_col, fl, row0, col0, oc0, oc1, st4, st1);
-      if (jflags & J3_FLUSH_LOWER) flush3<C>(lane, ring + ((hs ^ 1) * H) * C::RP + jd->ring_col, fl, row0 + H, col0, oc0, oc1, st4, st1);
+      const int oc0 = P.lat_c0 + jown0, oc1 = P.lat_c0 + jown1;
+      if (jflags & J3_FLUSH_UPPER) flush3<C>(lane, ring + (hs * H) * C::RP + jring_col, fl, row0, col0, oc0, oc1, st4, st1);
+      if (jflags & J3_FLUSH_LOWER) flush3<C>(lane, ring + ((hs ^ 1) * H) * C::RP + jring_col, fl, row0 + H, col0, oc0, oc1, st4, st1);
     }
     // ---- done: LDS executes a wave's instructions in order, so whoever sees the flag sees the adds (and the flush has read its rows) ----
     {  // (every lane stores the same word: no branch)
       const uint32_t a = flags_off + 4u * ((uint32_t)j & (C::NFLAGS - 1)), val = (uint32_t)j + 1;
-      asm volatile("s_waitcnt lgkmcnt(0)\n\tds_write_b32 %0, %1" : : "v"(a), "v"(val) : "memory");
+      asm volatile("ds_write_b32 %0, %1" : : "v"(a), "v"(val) : "memory");
+      __builtin_amdgcn_s_setprio(0);
     }
   }
 }

@@ -141,7 +141,8 @@ static int emu3_apply_t(int n_patches, const int32_t* coords, int Himg, int Wimg
         if (d.ring_col < 0 || d.ring_col + C::SLABW > C::RINGW) std::abort();
         float* ru = ring.data() + (hs * H + p) * C::RP + d.ring_col + q * N;
         float* rl = ring.data() + ((hs ^ 1) * H + p) * C::RP + d.ring_col + q * N;
-        accumulate3<C>(vl, win[p], win[p + H], valid, ru, rl, (int)((d.flags >> J3_UPPER_SHIFT) & 3u), (int)((d.flags >> J3_LOWER_SHIFT) & 3u));
+        window_out<C>(vl, win[p], win[p + H], valid);
+        accumulate3<C>(vl, ru, rl, (int)((d.flags >> J3_UPPER_SHIFT) & 3u), (int)((d.flags >> J3_LOWER_SHIFT) & 3u));
       });
       const int oc0 = c0 + d.own_c0, oc1 = c0 + d.own_c1;
       if (d.flags & J3_FLUSH_UPPER)
