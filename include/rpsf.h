@@ -87,6 +87,13 @@ int rpsf_plan_set_transfer_spectra_device(rpsf_plan* plan, const void* s_c64_dev
  * ones: bit-reproducible and independent of how the lattice is cut); every output pixel is written once,
  * by the one launch that is the whole apply.  Patches on region borders are computed by both neighbours. */
 int rpsf_plan_set_overlap_mode(rpsf_plan* plan, int mode);
+/* Sweep kernel (mode 4): cut the lattice into about `target_regions` regions of output pixels (one workgroup each; default: the device's
+ * number of compute units).  More regions: shorter regions and a better balance over the CUs, more patches computed twice on region
+ * borders.  The result does not depend on the cut, bit for bit.  rpsf_plan_sweep_info reports the cut in use: regions, jobs (slabs of
+ * 128 / N patches), patch slots computed (/ the number of patches = the recompute factor), slabs per column parity and lattice row
+ * of a region.  (The reference has no counterpart: transform.py:157-169 is one NumPy expression per step.) */
+int rpsf_plan_set_sweep_regions(rpsf_plan* plan, int target_regions);
+int rpsf_plan_sweep_info(const rpsf_plan* plan, int* regions, long* jobs, long* patch_slots, int* slabs_per_phase);
 /* Start-up stagger of the patch kernel's first resident workgroups (microseconds, 0 = off): spreads
  * the gather / K-stream / store phases of different CUs in time so that HBM traffic overlaps compute.
  * Without this call the library decides: 12 us for the persistent launches of the 256-pixel plan from

@@ -58,6 +58,8 @@ _PROTOTYPES = {
     "rpsf_plan_set_transfer_spectra_device": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_double]),
     "rpsf_plan_transfer_bytes": (c_int, [c_void_p, POINTER(c_size_t)]),
     "rpsf_plan_set_overlap_mode": (c_int, [c_void_p, c_int]),
+    "rpsf_plan_set_sweep_regions": (c_int, [c_void_p, c_int]),
+    "rpsf_plan_sweep_info": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long), ctypes.POINTER(c_int)]),
     "rpsf_plan_set_stagger": (c_int, [c_void_p, c_int]),
     "rpsf_plan_set_image_prefetch": (c_int, [c_void_p, c_int]),
     "rpsf_plan_set_reserved_cus": (c_int, [c_void_p, c_int]),
@@ -226,6 +228,16 @@ class Plan:
         """'auto' (on lattices: 'direct' for 128/256-pixel patches, 'planes' for smaller ones; 'atomic' otherwise),
         'atomic', 'planes' or 'direct'."""
         check(lib().rpsf_plan_set_overlap_mode(self._handle, {"auto": 0, "atomic": 1, "planes": 2, "direct": 3, "sweep": 4}[mode]))
+
+    def set_sweep_regions(self, target_regions: int) -> None:
+        """Sweep kernel (N <= 64): cut the lattice into about this many regions of output pixels (default: one per compute unit)."""
+        check(lib().rpsf_plan_set_sweep_regions(self._handle, int(target_regions)))
+
+    def sweep_info(self) -> dict:
+        regions, slabs = c_int(0), c_int(0)
+        jobs, slots = ctypes.c_long(0), ctypes.c_long(0)
+        check(lib().rpsf_plan_sweep_info(self._handle, ctypes.byref(regions), ctypes.byref(jobs), ctypes.byref(slots), ctypes.byref(slabs)))
+        return {"regions": regions.value, "jobs": jobs.value, "patch_slots": slots.value, "slabs_per_phase": slabs.value}
 
     def debug_stamps(self) -> np.ndarray:
         out = np.zeros((self.n_patches, 16), np.uint64)

@@ -189,7 +189,8 @@ struct rpsf_plan {
   bool sweep_ok = false;
   Job3* d_jobs3 = nullptr;
   Region3* d_regions3 = nullptr;
-  int n_regions3 = 0, ks3 = 0;
+  int n_regions3 = 0, ks3 = 0, par_j3 = 0;
+  std::vector<int32_t> slot3;  // lattice cell -> transfer-kernel slot
   long slabs3 = 0, patch_slots3 = 0;
   float* d_k3 = nullptr;      // n_patches x Cfg3::K_FLOATS (a view shares its parent's)
   float* d_zero3 = nullptr;   // 16 bytes of zeros
@@ -214,6 +215,34 @@ static uint64_t morton2(uint32_t a, uint32_t b) {
     return x;
   };
   return (spread(a) << 1) | spread(b);
+}
+
+// Regions and job lists of the sweep kernel for `target_regions` workgroups (rpsf_plan3.hpp); replaces the plan's previous lists
+static int build_sweep_lists(rpsf_plan* p, int target_regions) {
+  const int nli = p->nti - 1, nlj = p->ntj - 1;
+  Plan3 plan;
+  const bool built = dispatch_v3(p->N, [&]<class C>() -> int {
+    return plan3_build(C::N, C::KSMAX, C::WAVES, nli, nlj, p->slot3.data(), p->par_j3, target_regions, plan) ? RPSF_OK : RPSF_E_STATE;
+  }) == RPSF_OK;
+  if (!built) return RPSF_OK;  // (the plan keeps its other paths)
+  (void)hipFree(p->d_jobs3), (void)hipFree(p->d_regions3);
+  p->d_jobs3 = nullptr, p->d_regions3 = nullptr, p->sweep_ok = false;
+  HIP_TRY(hipMalloc(&p->d_jobs3, plan.jobs.size() * sizeof(Job3)));
+  HIP_TRY(hipMemcpy(p->d_jobs3, plan.jobs.data(), plan.jobs.size() * sizeof(Job3), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&p->d_regions3, plan.regions.size() * sizeof(Region3)));
+  HIP_TRY(hipMemcpy(p->d_regions3, plan.regions.data(), plan.regions.size() * sizeof(Region3), hipMemcpyHostToDevice));
+  if (!p->d_zero3) {
+    HIP_TRY(hipMalloc(&p->d_zero3, 64));
+    HIP_TRY(hipMemset(p->d_zero3, 0, 64));
+  }
+  p->n_regions3 = (int)plan.regions.size(), p->ks3 = plan.ks, p->slabs3 = plan.slabs, p->patch_slots3 = plan.patch_slots;
+  p->sweep_ok = true;
+#if defined(RPSF3_STAMPS) || defined(RPSF3_DUMP)
+  (void)hipFree(p->d_stamps3);
+  HIP_TRY(hipMalloc(&p->d_stamps3, (size_t)std::max(512, p->n_regions3) * 8 * 8 * 16 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(p->d_stamps3, 0, (size_t)std::max(512, p->n_regions3) * 8 * 8 * 16 * sizeof(unsigned long long)));
+#endif
+  return RPSF_OK;
 }
 
 // Regular lattice test + colour classes + tile tables + processing order (host, at plan creation)
@@ -325,26 +354,11 @@ static int setup_lattice(rpsf_plan* p) {
   p->lat_r0 = r0, p->lat_c0 = c0, p->nti = nti, p->ntj = ntj;
   // ---- third generation: regions and job lists (rpsf_plan3.hpp) when every lattice cell has its patch ----
   if (has_v3(p->N) && nli >= 2 && nlj >= 2 && (size_t)nli * nlj == (size_t)n) {
-    std::vector<int32_t> slot((size_t)nli * nlj);
-    for (size_t c = 0; c < slot.size(); ++c) slot[c] = p->k_index.empty() ? cell[c] : p->k_index[cell[c]];
-    Plan3 plan;
-    const bool built = dispatch_v3(p->N, [&]<class C>() -> int {
-      return plan3_build(C::N, C::KSMAX, C::WAVES, nli, nlj, slot.data(), par_j, std::max(8, p->cu_count), plan) ? RPSF_OK : RPSF_E_STATE;
-    }) == RPSF_OK;
-    if (built) {
-      HIP_TRY(hipMalloc(&p->d_jobs3, plan.jobs.size() * sizeof(Job3)));
-      HIP_TRY(hipMemcpy(p->d_jobs3, plan.jobs.data(), plan.jobs.size() * sizeof(Job3), hipMemcpyHostToDevice));
-      HIP_TRY(hipMalloc(&p->d_regions3, plan.regions.size() * sizeof(Region3)));
-      HIP_TRY(hipMemcpy(p->d_regions3, plan.regions.data(), plan.regions.size() * sizeof(Region3), hipMemcpyHostToDevice));
-      HIP_TRY(hipMalloc(&p->d_zero3, 64));
-      HIP_TRY(hipMemset(p->d_zero3, 0, 64));
-      p->n_regions3 = (int)plan.regions.size(), p->ks3 = plan.ks, p->slabs3 = plan.slabs, p->patch_slots3 = plan.patch_slots;
-      p->sweep_ok = true;
-#if defined(RPSF3_STAMPS) || defined(RPSF3_DUMP)
-      HIP_TRY(hipMalloc(&p->d_stamps3, (size_t)std::max(512, p->n_regions3) * 8 * 8 * 16 * sizeof(unsigned long long)));
-      HIP_TRY(hipMemset(p->d_stamps3, 0, (size_t)std::max(512, p->n_regions3) * 8 * 8 * 16 * sizeof(unsigned long long)));
-#endif
-    }
+    p->slot3.resize((size_t)nli * nlj);
+    for (size_t c = 0; c < p->slot3.size(); ++c) p->slot3[c] = p->k_index.empty() ? cell[c] : p->k_index[cell[c]];
+    p->par_j3 = par_j;
+    const int rc3 = build_sweep_lists(p, std::max(8, p->cu_count));
+    if (rc3 != RPSF_OK) return rc3;
   }
   // ---- tiles: coverage, owner chunk, ranks ----
   std::vector<int> chunk_of(n), seq_of(n);
@@ -1413,6 +1427,24 @@ extern "C" int rpsf_plan_set_overlap_mode(rpsf_plan* p, int mode) {
 }
 
 // Diagnostic builds only (-DRPSF_STAMPS): copy out the 16 per-patch phase timestamps (10 ns ticks).
+extern "C" int rpsf_plan_set_sweep_regions(rpsf_plan* p, int target_regions) {
+  if (!p || target_regions < 1 || target_regions > (1 << 20)) return fail(RPSF_E_BADARG, "target_regions must be 1..2^20");
+  if (!p->sweep_ok) return fail(RPSF_E_STATE, "the sweep kernel needs a 16-, 32- or 64-pixel patch on a complete lattice of at least 2 x 2 patches");
+  HIP_TRY(hipSetDevice(p->device));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  HIP_TRY(hipDeviceSynchronize());  // (applies on other streams may still read the old lists)
+  drop_bands(p);
+  return build_sweep_lists(p, target_regions);
+}
+extern "C" int rpsf_plan_sweep_info(const rpsf_plan* p, int* regions, long* jobs, long* patch_slots, int* slabs_per_phase) {
+  if (!p) return fail(RPSF_E_BADARG, "null plan");
+  if (regions) *regions = p->sweep_ok ? p->n_regions3 : 0;
+  if (jobs) *jobs = p->sweep_ok ? p->slabs3 : 0;
+  if (patch_slots) *patch_slots = p->sweep_ok ? p->patch_slots3 : 0;
+  if (slabs_per_phase) *slabs_per_phase = p->sweep_ok ? p->ks3 : 0;
+  return RPSF_OK;
+}
+
 extern "C" int rpsf_plan_debug_stamps(rpsf_plan* p, unsigned long long* host, size_t count) {
   if (!p || !host) return fail(RPSF_E_BADARG, "null argument");
   if (p->d_stamps3) {  // third generation: [region][wave][job slot < 8][16]

@@ -72,7 +72,20 @@ struct Cfg3 {
   static_assert(RP % 4 == 0 && (RP / 4) % 2 == 1, "ring pitch");
   static constexpr int RINGF = N * RP;
   static constexpr int NFLAGS = 256;
-  static constexpr size_t LDS_BYTES = sizeof(float) * ((size_t)RINGF + (size_t)WAVES * XF) + sizeof(uint32_t) * (NFLAGS + 4);
+  // N = 64: the slab is requested half by half (128 registers of pixels beside 128 of the transform do not fit a lane)
+  static constexpr bool SPLIT_GATHER = N == 64;
+  // a words (rpsf_kernels3.hpp: the transfer kernel of the lane's column) that a lane requests at the start of its job, half a job before it uses
+  // them; the rest is requested where it is used (the register file does not hold all of them beside the patch)
+#if defined(RPSF3_KPRE)
+  static constexpr int KPRE = RPSF3_KPRE < H ? RPSF3_KPRE : H;
+#else
+  static constexpr int KPRE = N == 16 ? 8 : N == 32 ? 8 : 16;
+#endif
+  // N = 64: requested only once the pixels' registers are free (behind the first transposes), N <= 32: at the start of the job
+  static constexpr bool KPRE_LATE = N == 64;
+  // per wave: the b words of the slab's column-0 lanes (one 16-byte word per lane, requested by all 64 lanes in one coalesced load) + 16 bytes of zeros
+  static constexpr int SIDE_ZERO = 256, SIDEF = 260;
+  static constexpr size_t LDS_BYTES = sizeof(float) * ((size_t)RINGF + (size_t)WAVES * (XF + SIDEF)) + sizeof(uint32_t) * (NFLAGS + 4);
   // packed K, per patch (floats): A[j < H][k < H][4] = (K'[r][k], K'[r'][k]) for the row pair (r, r') = (0, H) if j = 0, else (j, N - j); K' = s K_h, column 0 holding a; then B[j < H][4] = (b[r], b[r'])
   static constexpr int KA_FLOATS = H * H * 4, KB_FLOATS = H * 4, K_FLOATS = KA_FLOATS + KB_FLOATS;
   static constexpr float SCALE = 1.0f / (2.0f * (float)N * (float)N);
@@ -94,18 +107,19 @@ RPSF_HD void lds_add1(float* p, float v) {
 
 // ---- gather (transform.py:117-123,141-149,157-162) ----------------------------------------------------------------------------
 // G-layout: load i < H covers slab rows 2i and 2i + 1; lane = (row parity, 16-byte unit u = lane & 31 of the 128 columns)
-template <class C>
+// PARTS = 2: both halves of the slab (rows [0, H) -> g[0 .. H/2), rows [H, N) -> g[H/2 .. H)); PARTS = 1: half PART only
+template <class C, int PART = 0, int PARTS = 2>
 RPSF_HD void g3_load_fast(int lane, f32x4* g, const float* slab, int ld) {
-  const float* base = slab + (size_t)(lane >> 5) * ld + 4 * (lane & 31);
-  StaticFor<0, C::H>::run([&]<int I>() RPSF_AI { g[I] = *reinterpret_cast<const f32x4*>(base + (size_t)(2 * I) * ld); });
+  const float* base = slab + (size_t)((lane >> 5) + PART * C::H) * ld + 4 * (lane & 31);
+  StaticFor<0, PARTS * C::H / 2>::run([&]<int I>() RPSF_AI { g[PART * (C::H / 2) + I] = *reinterpret_cast<const f32x4*>(base + (size_t)(2 * I) * ld); });
 }
 // any slab: np.pad's index maps, pixel by pixel (slabs on the rim of the image, unaligned geometry)
-template <class C>
+template <class C, int PART = 0, int PARTS = 2>
 RPSF_HD void g3_load_generic(int lane, f32x4* g, const ImageView& im, int row0, int col0) {
   int cx[4];
   for (int d = 0; d < 4; ++d) cx[d] = pad_index(col0 + 4 * (lane & 31) + d, im.W, im.pad_mode);
-  StaticFor<0, C::H>::run([&]<int I>() RPSF_AI {
-    int y = pad_index(row0 + 2 * I + (lane >> 5), im.H, im.pad_mode);
+  StaticFor<0, PARTS * C::H / 2>::run([&]<int I>() RPSF_AI {
+    int y = pad_index(row0 + PART * C::H + 2 * I + (lane >> 5), im.H, im.pad_mode);
     if (y >= 0) {
       y -= im.row0;
       if (y < 0 || y >= im.rows) y = -1;  // not resident: treated as fill (the launcher keeps every row a band needs resident)
@@ -116,7 +130,7 @@ RPSF_HD void g3_load_generic(int lane, f32x4* g, const ImageView& im, int row0, 
       const float t = row[cx[d] < 0 ? 0 : cx[d]];  // always in bounds; select afterwards
       px[d] = (y < 0 || cx[d] < 0) ? im.pad_value : t;
     }
-    g[I] = f32x4{px[0], px[1], px[2], px[3]};
+    g[PART * (C::H / 2) + I] = f32x4{px[0], px[1], px[2], px[3]};
   });
 }
 
@@ -212,11 +226,12 @@ RPSF_HD void t1_read(int lane, cf* v, const float* xb) {
 template <int N, int H>
 constexpr int k3_row(int j, int m) { return j == 0 ? (m ? H : 0) : (m ? N - j : j); }
 template <class C, bool NT>
-RPSF_HD void kmul3(cf* v, const float* ka, const float* kb, int kb_stride) {
+RPSF_HD void kmul3(cf* v, const f32x4* ka_pre, const float* ka, const float* kb, int kb_stride) {
   constexpr int N = C::N, H = C::H;
   StaticFor<0, H>::run([&]<int J>() RPSF_AI {
     cf ae, ao, be, bo;
-    load_k16<NT>(ka + (size_t)J * (H * 4), ae, ao);
+    if constexpr (J < C::KPRE) ae = cf{ka_pre[J].x, ka_pre[J].y}, ao = cf{ka_pre[J].z, ka_pre[J].w};
+    else load_k16<NT>(ka + (size_t)J * (H * 4), ae, ao);
     load_k16<false>(kb + (size_t)J * kb_stride, be, bo);
     constexpr int RE = k3_row<N, H>(J, 0), RO = k3_row<N, H>(J, 1);
     const cf x = v[RE], y = v[RO];
@@ -348,7 +363,7 @@ RPSF_HD cf pack_value3(const KF& kfull, int idx) {
 
 // (development sweeps: -DRPSF3_W16=.. etc. select other wave counts)
 #if !defined(RPSF3_W16)
-#define RPSF3_W16 8
+#define RPSF3_W16 16
 #endif
 #if !defined(RPSF3_W32)
 #define RPSF3_W32 8

@@ -43,13 +43,15 @@ __device__ __forceinline__ void sweep_body(const SweepParams& P) {
   float* ring = lds3;
   const int tid = threadIdx.x, lane0 = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* xb = ring + C::RINGF + wave * C::XF;
-  uint32_t* flags = reinterpret_cast<uint32_t*>(ring + C::RINGF + C::WAVES * C::XF);
+  float* side = ring + C::RINGF + C::WAVES * C::XF + wave * C::SIDEF;
+  uint32_t* flags = reinterpret_cast<uint32_t*>(ring + C::RINGF + C::WAVES * (C::XF + C::SIDEF));
   uint32_t* next = flags + C::NFLAGS;
   const int b = blockIdx.x;
   const int region = (b & 7) * P.group + (b >> 3);
   if (region >= P.n_regions) return;
   const Region3 reg = P.regions[region];
   for (int i = tid; i < C::NFLAGS + 4; i += C::WG) flags[i] = 0;
+  if (lane0 < 4) side[C::SIDE_ZERO + lane0] = 0.0f;
   __syncthreads();
   ImageView im = P.im;
   Flush3 fl = P.fl;
@@ -90,20 +92,55 @@ __device__ __forceinline__ void sweep_body(const SweepParams& P) {
     f32x4 g[H];
     const bool fast = P.aligned_in && row0 >= im.row0 && row0 + N <= im.row0 + im.rows && row0 >= 0 && row0 + N <= im.H && col0 >= 0 &&
                       col0 + C::SLABW <= im.W;
-    if (fast) g3_load_fast<C>(lane, g, im.img + (size_t)(row0 - im.row0) * im.ld + col0, im.ld);
-    else g3_load_generic<C>(lane, g, im, row0, col0);
+    const float* slab = im.img + (size_t)(row0 - im.row0) * im.ld + col0;
+    if constexpr (C::SPLIT_GATHER) {
+      if (fast) g3_load_fast<C, 0, 1>(lane, g, slab, im.ld);
+      else g3_load_generic<C, 0, 1>(lane, g, im, row0, col0);
+    } else {
+      if (fast) g3_load_fast<C>(lane, g, slab, im.ld);
+      else g3_load_generic<C>(lane, g, im, row0, col0);
+    }
+    // this job's transfer kernel: the first a words of the lane's column on their way while the rows are transformed; the b words of the slab's
+    // column-0 lanes - one word per lane, coalesced - go through LDS (every other lane multiplies by zeros from there)
+    const float* kp = P.k3 + (size_t)kslot * C::K_FLOATS;
+    f32x4 ka[C::KPRE > 0 ? C::KPRE : 1];
+    auto request_k = [&]() RPSF_AI {
+      StaticFor<0, C::KPRE>::run([&]<int J>() RPSF_AI {
+        if constexpr (NT) ka[J] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(kp + (size_t)(J * H + p) * 4));
+        else ka[J] = *reinterpret_cast<const f32x4*>(kp + (size_t)(J * H + p) * 4);
+      });
+    };
+    if constexpr (!C::KPRE_LATE) request_k();
+    const f32x4 kbw = *reinterpret_cast<const f32x4*>(kp + C::KA_FLOATS + p * 4);
     cf v[N];
     // ---- rows ----
-    StaticFor<0, C::NSUB>::run([&]<int S>() RPSF_AI {
-      t0_write<C, 0, S>(lane, g, xb);
-      lds_fence_wave();
-      t0_read<C, 0, S>(lane, v, xb);
-      lds_fence_wave();
-      t0_write<C, 1, S>(lane, g, xb);
-      lds_fence_wave();
-      t0_read<C, 1, S>(lane, v, xb);
-      lds_fence_wave();
-    });
+    if constexpr (C::SPLIT_GATHER) {
+      StaticFor<0, C::NSUB>::run([&]<int S>() RPSF_AI {
+        t0_write<C, 0, S>(lane, g, xb);
+        lds_fence_wave();
+        t0_read<C, 0, S>(lane, v, xb);
+        lds_fence_wave();
+      });
+      if (fast) g3_load_fast<C, 1, 1>(lane, g, slab, im.ld);
+      else g3_load_generic<C, 1, 1>(lane, g, im, row0, col0);
+      StaticFor<0, C::NSUB>::run([&]<int S>() RPSF_AI {
+        t0_write<C, 1, S>(lane, g, xb);
+        lds_fence_wave();
+        t0_read<C, 1, S>(lane, v, xb);
+        lds_fence_wave();
+      });
+    } else {
+      StaticFor<0, C::NSUB>::run([&]<int S>() RPSF_AI {
+        t0_write<C, 0, S>(lane, g, xb);
+        lds_fence_wave();
+        t0_read<C, 0, S>(lane, v, xb);
+        lds_fence_wave();
+        t0_write<C, 1, S>(lane, g, xb);
+        lds_fence_wave();
+        t0_read<C, 1, S>(lane, v, xb);
+        lds_fence_wave();
+      });
+    }
     window_in<C>(v, w_re, w_im);
     FftSmall<C::LOGN, false>::run(v);
     unpack_rows<C>(v);
@@ -118,11 +155,13 @@ __device__ __forceinline__ void sweep_body(const SweepParams& P) {
       t1_read<C, 1, S>(lane, v, xb);
       lds_fence_wave();
     });
+    if constexpr (C::KPRE_LATE) request_k();
+    lds_st4(side + 4 * lane, kbw);
+    lds_fence_wave();
     FftSmall<C::LOGN, false>::run(v);
     {
-      const float* kp = P.k3 + (size_t)kslot * C::K_FLOATS;
       const bool col0lane = p == 0;
-      kmul3<C, NT>(v, kp + p * 4, col0lane ? kp + C::KA_FLOATS : P.zeros, col0lane ? 4 : 0);
+      kmul3<C, NT>(v, ka, kp + p * 4, col0lane ? side + 4 * (q * H) : side + C::SIDE_ZERO, col0lane ? 4 : 0);
     }
     FftSmall<C::LOGN, true>::run(v);
     // ---- back to rows ----

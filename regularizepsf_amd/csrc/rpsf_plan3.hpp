@@ -65,8 +65,9 @@ inline bool plan3_build(int N, int ksmax, int waves, int nli, int nlj, const int
       const int rows = advr + 1;
       const double jobs = 2.0 * ks * rows;
       const double rounds = (double)std::max(1L, ((long)nstrips * nseg + target_regions - 1) / target_regions);
-      // a region runs its jobs `waves` at a time; the last lattice row of a region keeps only 2 ks waves busy
-      const double t = rounds * (std::max(jobs / waves, 1.0) + 1.0);
+      // a region runs its jobs `waves` at a time; the last lattice row of a region keeps only 2 ks waves busy; the ordered adds of its
+      // 2 x rows layers come one after the other (about a seventh of a job each: what decides between cuts of a small frame)
+      const double t = rounds * (std::max(jobs / waves, 1.0) + 1.0 + 0.15 * 2.0 * rows);
       const double w = (double)nstrips * nseg * jobs;
       if (t < best_t - 1e-9 || (t < best_t + 1e-9 && w < best_w)) best_t = t, best_w = w, best_ks = ks, best_seg = nseg;
     }

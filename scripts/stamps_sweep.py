@@ -34,16 +34,15 @@ check(lib().rpsf_plan_debug_stamps(plan._handle, _ptr(buf), buf.size))
 st = buf.reshape(-1, 8, 8, 16).astype(np.int64)
 st = st[st[:, 0, 0, 0] != 0]
 names = ["draw", "descriptor", "gather issue", "T0 (+ pixel latency)", "window + row FFT + unpack", "T1", "column FFT", "x K (+ K latency)", "inverse column FFT",
-         "T2", "repack + inverse row FFT", "dependency wait", "accumulate", "flush", "flag"]
-print(f"N = {a.n}, {a.size}^2: {st.shape[0]} regions stamped; times in us (10 ns ticks), mean over regions and waves")
-start = st[:, :, :, 0].min(axis=(1, 2), keepdims=True)
-for slot in range(8):
-    row = st[:, :, slot, :]
-    ok = row[:, :, 14] != 0
-    if not ok.any():
-        continue
-    d = np.diff(row, axis=2)[ok] / 100.0
-    begin = (row[:, :, 0] - start[:, :, 0])[ok] / 100.0
-    print(f"job slot {slot}: starts at {begin.mean():7.2f}, takes {d.sum(axis=1).mean():7.2f}: " + ", ".join(f"{names[i]} {d[:, i].mean():.2f}" for i in range(14)))
-end = st[:, :, :, 14].max(axis=(1, 2))
-print("last stamped job ends at (mean over regions)", ((end - start[:, 0, 0]) / 100.0).mean())
+         "T2", "repack + inverse row FFT + window", "dependency wait", "accumulate", "flush", "flag"]
+print(f"N = {a.n}, {a.size}^2: {st.shape[0]} regions stamped; times in us (10 ns ticks), mean over regions, waves and job slots 1..7")
+ok = (st[:, :, :, :15] != 0).all(axis=3)
+ok[:, :, 0] = False
+d = np.diff(st[:, :, :, :15], axis=3)[ok] / 100.0
+print(f"jobs: {d.shape[0]}, mean job time {d.sum(axis=1).mean():.2f} us")
+for i in range(14):
+    print(f"  {names[i]:42s} {d[:, i].mean():6.2f}   (p90 {np.percentile(d[:, i], 90):6.2f})")
+first = st[:, :, 0, 0].astype(np.float64)
+first[first == 0] = np.nan
+last = st[:, :, :, 14].max(axis=(1, 2)).astype(np.float64)
+print("stamped span per region (first draw -> last stamped flag), mean us:", float(np.nanmean(last - np.nanmin(first, axis=1)) / 100.0))

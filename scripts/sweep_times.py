@@ -15,6 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--cases", default="32:512,64:512,16:512,32:2048,32:4096,64:4096,16:4096")
 ap.add_argument("--iters", type=int, default=30)
 ap.add_argument("--mode", default="auto")
+ap.add_argument("--regions", default="0", help="comma-separated target region counts (0 = the library's own)")
 a = ap.parse_args()
 rng = np.random.default_rng(0)
 tag = pathlib.Path(os.environ.get("RPSF_LIB", "product")).stem
@@ -31,8 +32,14 @@ for case in a.cases.split(","):
     plan = _native.Plan(n, coords)
     plan.set_transfer(k)
     plan.set_overlap_mode(a.mode)
-    plan.apply_device_timed(d_img.ptr, d_out.ptr, geom, 5)
-    tot, ker = plan.apply_device_timed(d_img.ptr, d_out.ptr, geom, a.iters)
-    alg = plan.transfer_bytes + 2 * img.nbytes
-    print(json.dumps({"lib": tag, "n": n, "size": size, "mode": a.mode, "ms_med": round(float(np.median(tot)), 4), "ms_min": round(float(tot.min()), 4),
-                      "frac": round(float(alg / np.median(tot) / 1e6 / 8000), 4)}), flush=True)
+    for target in [int(t) for t in a.regions.split(",")]:
+        if target:
+            plan.set_sweep_regions(target)
+        info = plan.sweep_info()
+        plan.apply_device_timed(d_img.ptr, d_out.ptr, geom, 5)
+        tot, ker = plan.apply_device_timed(d_img.ptr, d_out.ptr, geom, a.iters)
+        alg = plan.transfer_bytes + 2 * img.nbytes
+        print(json.dumps({"lib": tag, "n": n, "size": size, "mode": a.mode, "target": target, "regions": info["regions"], "jobs": info["jobs"],
+                          "recompute": round(info["patch_slots"] / len(coords), 3), "ks": info["slabs_per_phase"],
+                          "ms_med": round(float(np.median(tot)), 4), "ms_min": round(float(tot.min()), 4),
+                          "frac": round(float(alg / np.median(tot) / 1e6 / 8000), 4)}), flush=True)

@@ -123,7 +123,9 @@ static int emu3_apply_t(int n_patches, const int32_t* coords, int Himg, int Wimg
         const int q = l / H, p = l % H;
         FftSmall<C::LOGN, false>::run(vl);
         const float* kp = k3.data() + (size_t)d.kslot[q] * C::K_FLOATS;
-        kmul3<C, false>(vl, kp + p * 4, p == 0 ? kp + C::KA_FLOATS : zeros, p == 0 ? 4 : 0);
+        f32x4 pre[C::KPRE > 0 ? C::KPRE : 1];
+        for (int jw = 0; jw < C::KPRE; ++jw) pre[jw] = *reinterpret_cast<const f32x4*>(kp + (size_t)(jw * H + p) * 4);
+        kmul3<C, false>(vl, pre, kp + p * 4, p == 0 ? kp + C::KA_FLOATS : zeros, p == 0 ? 4 : 0);
         FftSmall<C::LOGN, true>::run(vl);
       });
       StaticFor<0, C::NSUB>::run([&]<int S>() {
