@@ -45,8 +45,10 @@ CONFIGS = {  # name -> (height, width, patch, starfield seed)
     3: (4096, 4096, 256, 3),
     4: (8192, 8192, 256, 4),   # BASELINE.json configs[3]: one 8192^2 frame, row bands over the ranks (strong scaling)
     5: (2048, 2048, 128, 100),  # batch of frames sharing config 2's transfer kernel (BASELINE.json configs[4])
-    6: (4096, 4096, 64, 6),    # not a BASELINE config: the first-generation (two-stage) kernels at the frame size of the headline - the patch size
-                               # of the reference's own example (docs/source/example.ipynb: psf_size = 64)
+    6: (4096, 4096, 64, 6),    # not a BASELINE config: the patch size of the reference's own example (docs/source/example.ipynb: psf_size = 64) at
+                               # the frame size of the headline; since round 6 the third-generation (sweep) kernel
+    7: (4096, 4096, 32, 7),    # the same for 32-pixel patches (BASELINE config 1's patch size at the headline's frame size)
+    8: (4096, 4096, 16, 8),    # and for 16-pixel patches
 }
 
 
@@ -683,9 +685,15 @@ def main() -> None:
     for _ in range(args.warmup):
         run_step()
     barrier()
+    # N = 1, one plan, one frame: the K steps are launched back to back by ONE library call that also brackets them with a HIP event pair on the
+    # plan's stream - so the device time of the timed region itself (roofline.kernel_avg_ms) lies inside the wall-clock step by construction
+    timed_loop_event_ms = None
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run_step()
+    if world == 1 and not rotation and not pipeline:
+        timed_loop_event_ms = plan.apply_device_loop_ms(d_img.ptr, d_out.ptr, geom, args.steps)
+    else:
+        for _ in range(args.steps):
+            run_step()
     barrier()
     elapsed = time.perf_counter() - t0
     if comm is not None:
@@ -768,8 +776,10 @@ def main() -> None:
     kern_avg_ms, apply_avg_ms = float(np.mean(kernel_ms)), float(np.mean(total_ms))
     # (each per-apply event pair puts a marker packet between two launches, ~8 us of the 184 here: the loop as the device sees it is one pair of
     # events around `iters` back-to-back applies; with the plane sum fused into the patch launch - N = 128, 256 - an apply IS one launch of the kernel)
-    if n >= 128:
-        kern_avg_ms = loop_ms
+    sweep = plan.sweep_info() if n <= 64 else {"regions": 0}
+    one_launch = n >= 128 or sweep["regions"] > 0  # the whole apply is one launch of the dominant kernel
+    if one_launch:
+        kern_avg_ms = timed_loop_event_ms if timed_loop_event_ms is not None else loop_ms
     my_patches = plan.n_patches
     alg_bytes = my_patches * n * (n // 2 + 1) * 8 + band.image_rows * w * 4 + band.out_rows * w * 4
     # one rank's apply; at N = 1 the wall-clock step itself (with --in-flight > 1 the steps overlap: the single apply by events)
@@ -805,17 +815,29 @@ def main() -> None:
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
             "frac_of_measured_copy_ceiling": round(achieved / MEASURED_COPY_GBS, 4),
-            "kernel": "patch_kernel2_256p" if n == 256 else "patch_kernel2_128p" if n == 128 else "patch_kernel",
+            "kernel": "patch_kernel2_256p" if n == 256 else "patch_kernel2_128p" if n == 128 else "sweep_kernel" if sweep["regions"] else "patch_kernel",
             "whole_apply_ms": round(step_ms, 4), "kernel_avg_ms": round(kern_avg_ms, 4), "kernel_launches": iters,
             "frac_patch_kernel_only": round(achieved_kernel / HBM_PEAK_GBS, 4),
             "algorithmic_bytes": int(alg_bytes), "packed_k_bytes": int(plan.transfer_bytes),
             "bytes_model": "SURVEY 8d: folded K (n N (N/2+1) complex64) read once + image read once + output written once "
                            "(rank 0's band), divided by the whole device-resident apply",
             "apply_avg_ms_events": round(apply_avg_ms, 4), "apply_avg_ms_event_loop": round(loop_ms, 4), "patches_this_rank": my_patches,
-            "kernel_avg_ms_from": ("one HIP event pair around the back-to-back launches of the timed loop (apply = one launch)" if n >= 128 else
+            "kernel_avg_ms_from": ("one HIP event pair around the K back-to-back launches of the timed region itself (apply = one launch)" if one_launch and timed_loop_event_ms is not None else
+                                   "one HIP event pair around back-to-back launches after the timed loop (apply = one launch)" if one_launch else
                                    "HIP event pairs around every patch-kernel launch"),
         },
     }
+    if sweep["regions"]:  # third generation: how the lattice was cut (patches on region borders are computed by both neighbours)
+        line["config"]["sweep"] = {"regions": sweep["regions"], "jobs": sweep["jobs"], "slabs_per_phase": sweep["slabs_per_phase"],
+                                   "recompute_factor": round(sweep["patch_slots"] / max(1, my_patches), 3)}
+    if n == 256 and world == 1:  # what this kernel STRUCTURE can reach, as measured: not a tuning target but a bound
+        line["roofline"]["structure_ceiling"] = {
+            "frac": 0.32, "ms": 0.165,
+            "floors_ms": {"memory_system_alone": [0.145, 0.158], "on_chip_chain_alone": [0.153, 0.165], "without_lock_step_barriers": 0.167},
+            "what": "one 256-pixel patch per CU with four colour planes: the apply's 980 MB on the memory system alone, the on-chip chain alone, "
+                    "the product without its exchange barriers; a perfectly overlapped version of this structure lands at ~0.165 ms",
+            "profiles": ["profiles/r04a_persistent_kernel_decomposition.log", "profiles/r04an_cost_of_each_exchange_barrier.log",
+                         "profiles/r04b_split_patch_skeleton_upper_bound.log", "profiles/r05s_split_skeleton_audit.log"]}
     # ---------------- N > 1: the other seam mode, same steps, same barriers - AFTER the headline line exists, under a watchdog: a hang or an
     # error in this leg (RCCL send / recv between GPUs has never run before the first multi-GPU node this is launched on) must not cost the
     # headline its JSON line ----------------
@@ -891,6 +913,9 @@ def main() -> None:
     if new_frames_ms is not None:  # same bytes, same plan, every step a frame the caches have not seen for args.new_frames - 1 applies
         line["roofline"]["ms_per_step_new_frames"] = round(new_frames_ms, 4)
         line["roofline"]["frac_new_frames"] = round(alg_bytes / (new_frames_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        # (the production figure - a stream of frames - beside the repeated-frame one, in the metric string itself)
+        line["metric"] += f" [roofline frac {line['roofline']['frac']} on a repeated frame, {line['roofline']['frac_new_frames']} on a stream of new frames]"
+        line["value_new_frames"] = round(total_pixels / (new_frames_ms * 1e-3) / 1e6, 1)
         line["roofline"]["new_frames_in_rotation"] = args.new_frames
         if new_frames_prefetch_ms is not None:  # opt-in, not the default: it costs frames that are larger than the cache
             line["roofline"]["ms_per_step_new_frames_with_image_prefetch"] = round(new_frames_prefetch_ms, 4)
@@ -924,8 +949,8 @@ def main() -> None:
             print(f"[bench] end-to-end leg failed: {line['e2e_error']}", file=sys.stderr, flush=True)
         finally:
             os.sched_setaffinity(0, affinity)
-    traffic_file = ROOT / "profiles" / "traffic_latest.json"
-    if world == 1 and args.config == 3 and traffic_file.exists():  # PMC counters cannot be read from inside the process
+    traffic_file = ROOT / "profiles" / ("traffic_latest.json" if args.config == 3 else f"traffic_config{args.config}.json")
+    if world == 1 and traffic_file.exists():  # PMC counters cannot be read from inside the process
         tr = json.loads(traffic_file.read_text())
         line["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
         line["roofline"]["traffic_source"] = tr["source"]
