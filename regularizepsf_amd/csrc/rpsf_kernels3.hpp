@@ -59,6 +59,12 @@ __device__ __forceinline__ void sweep_body(const SweepParams& P) {
   fl.out += (size_t)blockIdx.y * P.out_frame_floats;
   const float w_re = P.win[lane0 % H], w_im = P.win[lane0 % H + H];
   const uint32_t flags_off = lds_u32_offset(flags), next_off = lds_u32_offset(next);
+#if defined(RPSF3_STAGGER_TICKS)
+  {  // development: the waves of a workgroup start RPSF3_STAGGER_TICKS x 10 ns apart
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)wave * RPSF3_STAGGER_TICKS) __builtin_amdgcn_s_sleep(8);
+  }
+#endif
   for (;;) {
     // (per-lane addresses are recomputed every pass: hoisted out of the loop - the compiler's choice otherwise - they stay live across the
     // whole body and cost registers)
