@@ -27,11 +27,13 @@ def _kernel_stamp(cube: IndexedCube) -> tuple:
 
     The reference multiplies by ``values`` as they are at every ``apply`` (transform.py:164), and ``IndexedCube`` does not
     copy them, so a caller may edit the array in place between two applies.  ``__setitem__`` is counted exactly; edits that
-    bypass it (``cube.values[i] = ...``, ``k *= 2``) are caught by hashing one 64-byte line of every patch (at most 4096
-    patches, evenly spaced beyond that; the line's position inside the patch varies from patch to patch) - 20 ... 60 us, where
-    the evenly strided 64 K-element sample of rounds 2-4 cost 0.3 ... 1.4 ms of cache misses per apply, more than a small frame's
-    whole correction.  An edit confined to a few elements of a patch is not seen - call :meth:`ArrayPSFTransform.invalidate`
-    after such surgical edits.
+    bypass it (``cube.values[i] = ...``, ``k *= 2``) cannot go unnoticed since round 6: the array is made READ-ONLY while a device copy
+    of it exists (``ArrayPSFTransform._freeze``), so such a write raises NumPy's ``ValueError: assignment destination is read-only``
+    instead of being silently missed; ``with transform.edit() as k:``, ``cube[coordinate] = patch`` and ``transform.invalidate()``
+    are the ways to edit.  The fingerprint below stays as the backstop for memory that is reachable through another, still writeable
+    array (a view taken before the upload, a base array): one 64-byte line of every patch (at most 4096 patches, evenly spaced beyond
+    that; the line's position inside the patch varies from patch to patch) - 20 ... 60 us, where the evenly strided 64 K-element sample
+    of rounds 2-4 cost 0.3 ... 1.4 ms of cache misses per apply, more than a small frame's whole correction.
     """
     if getattr(cube, "_loader", None) is not None:  # still on the GPU only (construct from device-resident spectra): nobody can have edited it
         return ("deferred", id(cube), cube._edits)
@@ -173,12 +175,48 @@ class ArrayPSFTransform:
 
     # ------------------------------------------------------------------ device plan
     def invalidate(self) -> None:
-        """Drop the device copy of the transfer kernel.  Edits of ``values`` are noticed by themselves (see
-        ``_kernel_stamp``) except single-element ones that fall between the fingerprint's samples: call this after those."""
+        """Drop the device copy of the transfer kernel; ``values`` becomes writeable again (it was made read-only when the copy was
+        taken).  The next ``apply`` uploads whatever the array holds then - the reference reads ``values`` at every apply (transform.py:164)."""
         with self._lock:
             if self._plan is not None:
                 self._plan.close()
             self._plan, self._plan_stamp = None, None
+            self._thaw()
+
+    def _freeze(self) -> None:
+        """A device copy of ``values`` exists: make the array read-only, so that an in-place edit raises instead of leaving the copy stale."""
+        cube = self._transfer_kernel
+        values = cube._values_array
+        if values is not None and values.flags.writeable:
+            try:
+                values.flags.writeable = False
+                cube._frozen = True
+            except ValueError:  # (an array that does not own its memory and whose base forbids it: the fingerprint remains)
+                pass
+
+    def _thaw(self) -> None:
+        cube = self._transfer_kernel
+        if getattr(cube, "_frozen", False) and cube._values_array is not None:
+            cube._values_array.flags.writeable = True
+            cube._frozen = False
+
+    def edit(self):
+        """``with transform.edit() as k: k[i, r, c] = x`` - the transfer kernel's array, writeable inside the block; the device copy is
+        refreshed at the next ``apply`` (every edit made this way is seen, however small)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def editing():
+            with self._lock:
+                cube = self._transfer_kernel
+                values = cube.values
+                self._thaw()
+                try:
+                    yield values
+                finally:
+                    cube._edits += 1  # the stamp changes: the next apply uploads the array again (and makes it read-only again)
+
+        return editing()
 
     def _checked_patch_size(self) -> int:
         n0, n1 = self.psf_shape
@@ -203,6 +241,7 @@ class ArrayPSFTransform:
             plan = _native.Plan(n, cube.coordinates, device=self._device)
             plan.set_transfer(cube.values)
             self._plan, self._plan_stamp = plan, stamp
+        self._freeze()
         return self._plan
 
     def _check_corners(self, n: int, height: int, width: int) -> None:

@@ -50,6 +50,7 @@ class IndexedCube:
         self._shape = values.shape
         self._where = {tuple(c): layer for layer, c in enumerate(coordinates)}
         self._edits = 0  # bumped by __setitem__, lets device-side copies notice they are stale
+        self._frozen = False  # a device copy exists and the array was made read-only for it (ArrayPSFTransform._freeze)
 
     @classmethod
     def _deferred(cls, coordinates: list[tuple[int, int]], shape: tuple[int, int, int], loader) -> "IndexedCube":
@@ -66,6 +67,7 @@ class IndexedCube:
         self._shape = tuple(shape)
         self._where = {tuple(c): layer for layer, c in enumerate(coordinates)}
         self._edits = 0
+        self._frozen = False
         return self
 
     @property
@@ -105,7 +107,11 @@ class IndexedCube:
         if value.shape != self.sample_shape:
             msg = f"Cannot assign value of shape {value.shape} to transfer kernel of shape {self.sample_shape}."
             raise IncorrectShapeError(msg)
-        self._values[layer] = value
+        values = self._values
+        if getattr(self, "_frozen", False):  # made read-only when a device copy was taken: this edit is counted, the copy is refreshed at the next apply
+            values.flags.writeable = True
+            self._frozen = False
+        values[layer] = value
         self._edits += 1
 
     def __len__(self) -> int:

@@ -805,18 +805,106 @@ def test_reference_written_h5_file_runs_on_the_gpu():
     check(out, orc.apply_transfer(image, t.coordinates, t._transfer_kernel.values))
 
 
-def test_in_place_edits_of_the_kernel_are_noticed():
-    """The reference reads `values` at every apply (transform.py:164); edits that bypass IndexedCube.__setitem__ must not
-    leave a stale device copy behind."""
+def test_in_place_edits_of_the_kernel_are_loud_or_seen():
+    """The reference reads `values` at every apply (transform.py:164).  Here a device copy is taken; while it exists the array is read-only,
+    so an edit that bypasses IndexedCube.__setitem__ raises instead of leaving a stale copy behind - however small it is and wherever
+    it lands (the fingerprint of rounds 2-5 sampled one 64-byte line per patch and missed the rest) - and every sanctioned way of
+    editing gives the reference's answer."""
     fx, coords, k = load_apply_case("n32_sym")
+    image = fx["image"]
     k = k.copy()
+    alias = k[:]  # a view taken before the upload stays writeable: edits through it are left to the fingerprint
     t = rp.ArrayPSFTransform(rp.IndexedCube(coords, k))
-    first = t.apply(fx["image"])
-    k *= 2  # the caller's own array
-    check(t.apply(fx["image"]), 2 * first, tol=2e-6)
-    t._transfer_kernel.values[1] = 0  # one patch through the cube's view
-    k2 = k.copy()
-    check(t.apply(fx["image"]), orc.apply_transfer(fx["image"], coords, k2))
+    t.apply(image)
+    assert not k.flags.writeable
+    with pytest.raises(ValueError):
+        k[3, 5, 7] = 0  # one element, off the fingerprint's line
+    with pytest.raises(ValueError):
+        t._transfer_kernel.values[3, 5, 7] = 0
+    with pytest.raises(ValueError):
+        k *= 2
+    with t.edit() as kk:  # any edit, however small
+        kk[3, 5, 7] = 1.5 - 2j
+    check(t.apply(image), orc.apply_transfer(image, coords, k.copy()))
+    assert not k.flags.writeable
+    t.invalidate()  # drop the device copy: the array is the caller's again
+    assert k.flags.writeable
+    k[4, 1, 1] *= 3
+    check(t.apply(image), orc.apply_transfer(image, coords, k.copy()))
+    t._transfer_kernel[coords[1]] = np.zeros(k.shape[1:], np.complex64)  # __setitem__ is counted
+    assert complex(k[1, 0, 0]) == 0
+    check(t.apply(image), orc.apply_transfer(image, coords, k.copy()))
+    before = t.apply(image)
+    alias *= 2  # through memory that was never frozen: the fingerprint's job
+    check(t.apply(image), 2 * before, tol=2e-6)
+
+
+@pytest.mark.parametrize(("n", "shape"), [(16, (200, 264)), (32, (512, 512)), (32, (300, 500)), (64, (512, 384)), (64, (700, 1000))])
+def test_sweep_kernel_against_the_other_overlap_adds_and_any_cut(n, shape):
+    """The third-generation kernel (N <= 64: a workgroup owns a region of output pixels and adds the four contributions of a pixel in LDS,
+    in a fixed order) against the oracle, against the colour planes and the float atomics, bit-reproducible, and bit-identical however the
+    lattice is cut into regions (rpsf_plan_set_sweep_regions)."""
+    from regularizepsf_amd import _native
+
+    coords, k, images = _random_case(n, shape, 5 * n + shape[0], 1)
+    image = images[0]
+    pad = _native.PAD_MODES["symmetric"]
+    plan = _native.Plan(n, coords)
+    plan.set_transfer(k)
+    info = plan.sweep_info()
+    assert info["regions"] > 0 and info["patch_slots"] >= len(coords)
+    base = plan.apply(image, pad)  # automatic = the sweep kernel
+    check(base.astype(np.float64), orc.apply_transfer(image, coords, k))
+    for _ in range(3):
+        assert np.array_equal(plan.apply(image, pad), base)
+    for target in (1, 7, 64, 1000, 100000):
+        plan.set_sweep_regions(target)
+        assert np.array_equal(plan.apply(image, pad), base), (target, plan.sweep_info())
+    scale = np.abs(base).max()
+    for mode in ("planes", "atomic"):
+        other = _native.Plan(n, coords)
+        other.set_transfer(k)
+        other.set_overlap_mode(mode)
+        assert np.abs(other.apply(image, pad).astype(np.float64) - base).max() <= 2e-6 * scale, mode
+    plan.set_overlap_mode("sweep")
+    assert np.array_equal(plan.apply(image, pad), base)
+
+
+def test_sweep_kernel_needs_a_complete_lattice():
+    """Corner lists that are not a complete lattice keep the earlier paths (atomics / planes); asking for the sweep kernel says why not."""
+    from regularizepsf_amd import _native
+
+    coords, k, images = _random_case(32, (200, 200), 9, 1)
+    sparse = coords[::3]
+    plan = _native.Plan(32, sparse)
+    plan.set_transfer(k[::3])
+    assert plan.sweep_info()["regions"] == 0
+    with pytest.raises(_native.NativeError):
+        plan.set_overlap_mode("sweep")
+    check(plan.apply(images[0], _native.PAD_MODES["symmetric"]).astype(np.float64), orc.apply_transfer(images[0], sparse, k[::3]))
+
+
+@pytest.mark.parametrize("n", [16, 64])
+def test_sweep_kernel_batches_and_row_windows(n):
+    """Frames that share the transfer kernel ride along grid.y of the one launch: every frame equals its own single apply bit for bit."""
+    from regularizepsf_amd import _native
+
+    shape, frames = (256, 384), 5
+    coords, k, images = _random_case(n, shape, 21 + n, frames)
+    h, w = shape
+    pad = _native.PAD_MODES["reflect"]
+    plan = _native.Plan(n, coords)
+    plan.set_transfer(k)
+    stack = np.ascontiguousarray(images, np.float32)
+    d_in = _native.DeviceBuffer(stack.nbytes).upload(stack)
+    d_out = _native.DeviceBuffer(stack.nbytes)
+    plan.apply_batch_device(d_in.ptr, d_out.ptr, frames, h * w, h * w, _native.Geometry.whole(h, w, pad))
+    plan.synchronize()
+    got = d_out.download((frames, h, w))
+    for f in range(frames):
+        single = plan.apply(images[f], pad)
+        assert np.array_equal(got[f], single), f
+        check(single.astype(np.float64), orc.apply_transfer(images[f], coords, k, pad_mode="reflect"))
 
 
 def test_one_transform_from_two_threads():
