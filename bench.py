@@ -937,11 +937,18 @@ def main() -> None:
                 e2e[label] = round(ms, 4)
             e2e["f32_to_f32_pinned_arrays"] = round(e2e_host_frames(plan, host_image, _native.PAD_MODES[pad], np.float32, pinned=True)[0], 4)
             line["e2e_ms"] = e2e["f32_to_f64"]
-            line["e2e"] = {"what": "one ArrayPSFTransform.apply-style call on host arrays (rpsf_apply_host: the frame cut into row bands so that staging on the "
-                                   "persistent host pool, H2D, the bands' patch launches, D2H and widening overlap), best of 5, result buffer reused",
-                           "ms": e2e, "pcie": {k: round(v, 4) for k, v in probe.items()},
-                           "pcie_floor_ms": round(probe["h2d_ms"] + probe["d2h_ms"], 4), "host_threads": _native.host_threads(),
-                           "over_pcie_floor": round(e2e["f32_to_f64"] / (probe["h2d_ms"] + probe["d2h_ms"]), 3),
+            # Floors: `serial` = the frame's float32 bytes in, then out (what an uncut frame pays); `duplex` = both directions at once (rpsf_pcie_probe
+            # on two streams) - a frame cut into B row bands cannot have less than duplex x (1 + 1/B): band 0 must be in before anything can go out.
+            bands = plan.host_bands()
+            duplex_floor = probe["duplex_ms"] * (1 + 1 / bands) if bands >= 2 else probe["h2d_ms"] + probe["d2h_ms"]
+            line["e2e"] = {"what": "one ArrayPSFTransform.apply-style call on host arrays (rpsf_apply_host: the frame cut into row bands; one job of the persistent host "
+                                   "pool stages the rows and widens landed bands while H2D, the bands' patch launches and D2H run), best of 5, result buffer reused",
+                           "ms": e2e, "pcie": {k: round(v, 4) for k, v in probe.items()}, "row_bands": bands,
+                           "pcie_floor_ms": round(duplex_floor, 4), "pcie_floor_serial_ms": round(probe["h2d_ms"] + probe["d2h_ms"], 4),
+                           "pcie_floor_what": "duplex_ms x (1 + 1/row_bands): both directions at once, plus the first band that nothing can overlap",
+                           "host_threads": _native.host_threads(),
+                           "over_pcie_floor": round(e2e["f32_to_f64"] / duplex_floor, 3),
+                           "over_pcie_floor_pinned_arrays": round(e2e["f32_to_f32_pinned_arrays"] / duplex_floor, 3),
                            "process_bound_to_numa_node": bound_node, "device_numa_node": _native.device_numa_node(device)}
             del host_image
         except Exception as e:  # noqa: BLE001

@@ -93,7 +93,27 @@ int rpsf_plan_set_overlap_mode(rpsf_plan* plan, int mode);
  * 128 / N patches), patch slots computed (/ the number of patches = the recompute factor), slabs per column parity and lattice row
  * of a region.  (The reference has no counterpart: transform.py:157-169 is one NumPy expression per step.) */
 int rpsf_plan_set_sweep_regions(rpsf_plan* plan, int target_regions);
+/* Launch options of a plan that tests and callers may pin (everything else is decided by the library; none changes a result beyond the
+ * round-off of a different addition order, and the persistent / fused forms are bit-identical to their plain counterparts).
+ * ENVIRONMENT: the shipped library reads exactly two variables, both for the host-side thread pool of the host-array entry points:
+ *   RPSF_HOST_THREADS  (threads of the pool, default: the cores of the device's NUMA node, at most 16)
+ *   RPSF_HOST_AFFINITY (0: do not bind the pool's threads to the device's NUMA node).
+ * The development knobs of earlier rounds (RPSF_STRIPS, RPSF_SUM_FIRST, RPSF_V1, ...) are compiled in only with -DRPSF_DEV_ENV. */
+enum {
+  RPSF_OPT_PERSIST = 1,       /* 0 / 1: persistent patch workgroups for 128- and 256-pixel plans (default 1) */
+  RPSF_OPT_FUSE = 2,          /* 0 / 1: colour-plane sum inside the patch launch where the geometry allows (default 1) */
+  RPSF_OPT_K_CACHED = 3,      /* 0 / 1: transfer kernel by plain instead of streaming loads (default: by its size) */
+  RPSF_OPT_PLANE_NT = 4,      /* -1 automatic, 0 / 1: streaming hint on the colour-plane stores of 128-pixel batches */
+  RPSF_OPT_HOST_BANDS = 5,    /* -1 automatic, else the row bands a single host frame is cut into (0 or 1: none) */
+  RPSF_OPT_STREAM_GROUP = 6,  /* 0 automatic, else frames per group of the streamed host path */
+  RPSF_OPT_STREAM_DEPTH = 7,  /* 0 automatic, else groups in flight of the streamed host path */
+  RPSF_OPT_DEBUG_ORPHAN = 8   /* testing aid of the direct overlap-add: every value-th workgroup behaves as if placed on a foreign XCD */
+};
+int rpsf_plan_set_option(rpsf_plan* plan, int option, int value);
 int rpsf_plan_sweep_info(const rpsf_plan* plan, int* regions, long* jobs, long* patch_slots, int* slabs_per_phase);
+/* Row bands the last single host frame (rpsf_apply_host / rpsf_apply, one frame) was cut into: 0 = it went as a whole.  A frame of B bands
+ * cannot take less than PCIe's duplex time x (1 + 1/B) (bench.py's e2e.pcie_floor_ms). */
+int rpsf_plan_host_bands(const rpsf_plan* plan, int* bands);
 /* Start-up stagger of the patch kernel's first resident workgroups (microseconds, 0 = off): spreads
  * the gather / K-stream / store phases of different CUs in time so that HBM traffic overlaps compute.
  * Without this call the library decides: 12 us for the persistent launches of the 256-pixel plan from

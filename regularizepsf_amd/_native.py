@@ -59,6 +59,8 @@ _PROTOTYPES = {
     "rpsf_plan_transfer_bytes": (c_int, [c_void_p, POINTER(c_size_t)]),
     "rpsf_plan_set_overlap_mode": (c_int, [c_void_p, c_int]),
     "rpsf_plan_set_sweep_regions": (c_int, [c_void_p, c_int]),
+    "rpsf_plan_set_option": (c_int, [c_void_p, c_int, c_int]),
+    "rpsf_plan_host_bands": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
     "rpsf_plan_sweep_info": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long), ctypes.POINTER(c_int)]),
     "rpsf_plan_set_stagger": (c_int, [c_void_p, c_int]),
     "rpsf_plan_set_image_prefetch": (c_int, [c_void_p, c_int]),
@@ -229,6 +231,12 @@ class Plan:
         'atomic', 'planes' or 'direct'."""
         check(lib().rpsf_plan_set_overlap_mode(self._handle, {"auto": 0, "atomic": 1, "planes": 2, "direct": 3, "sweep": 4}[mode]))
 
+    OPTIONS = {"persist": 1, "fuse": 2, "k_cached": 3, "plane_nt": 4, "host_bands": 5, "stream_group": 6, "stream_depth": 7, "debug_orphan": 8}
+
+    def set_option(self, name: str, value: int) -> None:
+        """Pin a launch option of the plan (include/rpsf.h, RPSF_OPT_*): what tests and callers may choose instead of environment variables."""
+        check(lib().rpsf_plan_set_option(self._handle, self.OPTIONS[name], int(value)))
+
     def set_sweep_regions(self, target_regions: int) -> None:
         """Sweep kernel (N <= 64): cut the lattice into about this many regions of output pixels (default: one per compute unit)."""
         check(lib().rpsf_plan_set_sweep_regions(self._handle, int(target_regions)))
@@ -238,6 +246,12 @@ class Plan:
         jobs, slots = ctypes.c_long(0), ctypes.c_long(0)
         check(lib().rpsf_plan_sweep_info(self._handle, ctypes.byref(regions), ctypes.byref(jobs), ctypes.byref(slots), ctypes.byref(slabs)))
         return {"regions": regions.value, "jobs": jobs.value, "patch_slots": slots.value, "slabs_per_phase": slabs.value}
+
+    def host_bands(self) -> int:
+        """Row bands the last single host frame was cut into (0: it went as a whole)."""
+        n = c_int(0)
+        check(lib().rpsf_plan_host_bands(self._handle, ctypes.byref(n)))
+        return n.value
 
     def debug_stamps(self) -> np.ndarray:
         out = np.zeros((self.n_patches, 16), np.uint64)

@@ -56,6 +56,19 @@ static int fail(int code, const std::string& msg) {
 
 extern "C" const char* rpsf_last_error(void) { return g_err.c_str(); }
 
+// Development sweeps read their knobs from the environment ONLY in builds made with -DRPSF_DEV_ENV (scripts/, never the product): a stray variable
+// in a production environment must not change which kernel runs.  The shipped library reads two variables, both about the host-side thread pool
+// (rpsf_hostpipe.hpp: RPSF_HOST_THREADS, RPSF_HOST_AFFINITY, documented in include/rpsf.h); everything a caller or a test may want to
+// choose is a plan option (rpsf_plan_set_option).
+static const char* dev_env(const char* name) {
+#if defined(RPSF_DEV_ENV)
+  return std::getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+
 template <class F>
 static int dispatch_v3(int N, F&& f) {
   switch (N) {
@@ -167,7 +180,9 @@ struct rpsf_plan {
   uint32_t* d_chunk_xcc = nullptr; // 8 words
   size_t flag_frames = 0;
   uint32_t epoch = 0;
-  int orphan_mod = 0;              // testing aid (RPSF_DEBUG_ORPHAN)
+  int orphan_mod = 0;              // testing aid (RPSF_OPT_DEBUG_ORPHAN)
+  int plane_nt_opt = -1, host_bands_opt = -1, stream_group_opt = 0, stream_depth_opt = 0;  // rpsf_plan_set_option; -1 / 0: the library decides
+  int last_host_bands = 0;  // row bands the last single host frame was cut into (rpsf_plan_host_bands)
   hipEvent_t ev_busy = nullptr;    // end of the last apply (applies on different streams are serialised)
   hipStream_t last_stream = nullptr;
   bool busy_valid = false;
@@ -287,10 +302,10 @@ static int setup_lattice(rpsf_plan* p) {
     // Column strips walked boustrophedon, cut into 8 equal runs: compact regions, so that the four patches over a
     // tile mostly run on one XCD (they read the same pixels through one L2, and the tile can be accumulated there).
     int strips = nlj >= 8 ? std::max(4, nlj / 8) : 1;  // strips about 8 patches wide (4096^2: 4 as before; 8192^2: 8, -1.2 % against 4)
-    if (const char* e = std::getenv("RPSF_STRIPS")) strips = std::max(1, std::min(nlj, std::atoi(e)));  // development sweeps
+    if (const char* e = dev_env("RPSF_STRIPS")) strips = std::max(1, std::min(nlj, std::atoi(e)));  // development sweeps
     int k = 0;
     bool meet = true;  // (4096^2 / 256: 0.1877 vs 0.1900 ms with alternating strip directions; RPSF_ORDER_MEET=0 selects those)
-    if (const char* e = std::getenv("RPSF_ORDER_MEET")) meet = std::atoi(e) != 0;
+    if (const char* e = dev_env("RPSF_ORDER_MEET")) meet = std::atoi(e) != 0;
     for (int s2 = 0; s2 < strips; ++s2) {
       const int ja = (int)((long)nlj * s2 / strips), jb = (int)((long)nlj * (s2 + 1) / strips);
       if (meet) {
@@ -316,7 +331,7 @@ static int setup_lattice(rpsf_plan* p) {
     // padded gather / cropped store path (+50 % per patch at N = 256); dispatched first, they are the long jobs of a
     // longest-job-first list schedule: a CU that drew one simply takes one patch fewer later on, instead of a late rim
     // patch stretching the last round.  (Round 1: N = 256 215 -> 207 us, 2048^2 / N = 128 67 -> 58 us.)
-    if (!std::getenv("RPSF_NO_RIM_FIRST")) {
+    if (!dev_env("RPSF_NO_RIM_FIRST")) {
       auto rim = [&](int32_t i) {
         const int r = p->h_coords[2 * i], c = p->h_coords[2 * i + 1];
         return r == r0 || r == r1 || c == c0 || c == c1;
@@ -325,7 +340,7 @@ static int setup_lattice(rpsf_plan* p) {
       // patch per CU (N = 256) they go LAST, so that the patches of the partial last round are the short ones (4096^2: -1 %,
       // profiles/r02av); with four workgroups per CU (N = 128) first is still the better order (2048^2: 0.0685 vs 0.0705 ms).
       bool rim_last = p->N == 256;
-      if (const char* e = std::getenv("RPSF_RIM_LAST")) rim_last = std::atoi(e) != 0;
+      if (const char* e = dev_env("RPSF_RIM_LAST")) rim_last = std::atoi(e) != 0;
       for (int x = 0; x < 8; ++x) {
         const int lo = std::min(n, x * chunk), hi = std::min(n, lo + chunk);
         if (rim_last)
@@ -482,7 +497,7 @@ static int dispatch_v2(int N, F&& f) {
     default: return fail(RPSF_E_UNSUPPORTED, "no second-generation plan for this patch size");
   }
 }
-static bool has_v2(int N) { return (N == 256 || N == 128) && !std::getenv("RPSF_V1"); }
+static bool has_v2(int N) { return (N == 256 || N == 128) && !dev_env("RPSF_V1"); }
 
 static void host_tables(int N, std::vector<cf>& tw, std::vector<float>& win) {
   tw.resize(N);
@@ -683,19 +698,19 @@ static int plan_create_impl(rpsf_plan** out, int device, int patch_size, int n_p
     HIP_TRY(hipMemset(p->d_stamps, 0, sizeof(unsigned long long) * 16 * STAMP_WAVES * (size_t)n_patches));
 #endif
     p->v2 = has_v2(N);
-    p->no_fuse = std::getenv("RPSF_NO_FUSE") != nullptr;
+    p->no_fuse = false;  // (rpsf_plan_set_option RPSF_OPT_FUSE)
     // (measured, profiles/r02u, r02v: 32 of them are worth -1 % at 4096^2 and -2.5 % at 8192^2; 48 cost more patch time than they hide)
     p->sum_first = -1;  // decided per launch (sum_first_for) unless the environment pins it
-    if (const char* e = std::getenv("RPSF_SUM_FIRST")) p->sum_first = std::max(0, std::atoi(e)) / 8 * 8;
-    if (const char* e = std::getenv("RPSF_HEAD_PATCHES")) p->head_patches = std::atoi(e) > 0 ? 1 : 0;
-    if (const char* e = std::getenv("RPSF_PREFETCH")) p->prefetch = std::atoi(e) != 0;
-    if (const char* e = std::getenv("RPSF_STAGGER_US")) p->stagger_us = std::max(0, std::atoi(e));  // development sweeps
-    if (const char* e = std::getenv("RPSF_RESERVED_CUS")) p->reserved_cus = std::min(128, std::max(0, std::atoi(e)));
+    if (const char* e = dev_env("RPSF_SUM_FIRST")) p->sum_first = std::max(0, std::atoi(e)) / 8 * 8;
+    if (const char* e = dev_env("RPSF_HEAD_PATCHES")) p->head_patches = std::atoi(e) > 0 ? 1 : 0;
+    if (const char* e = dev_env("RPSF_PREFETCH")) p->prefetch = std::atoi(e) != 0;
+    if (const char* e = dev_env("RPSF_STAGGER_US")) p->stagger_us = std::max(0, std::atoi(e));  // development sweeps
+    if (const char* e = dev_env("RPSF_RESERVED_CUS")) p->reserved_cus = std::min(128, std::max(0, std::atoi(e)));
     // (until the plane stores were kept in the Infinity Cache the fused sum cost the 128-pixel plan 3 %; now it gains 3 ... 6 %)
-    p->fuse_pays = N >= 128 || std::getenv("RPSF_FUSE_ALWAYS") != nullptr;
+    p->fuse_pays = N >= 128 || dev_env("RPSF_FUSE_ALWAYS") != nullptr;
     // (256-pixel plan: profiles/r02ag, -3.7 % per apply at 4096^2 from the re-entry alone; 128-pixel plan, whose four workgroups per CU
     // hide one another's dispatch: 8 x 2048^2 0.334 vs 0.343 ms, single frames unchanged)
-    p->persist = (N == 256 || N == 128) && std::getenv("RPSF_NO_PERSIST") == nullptr;
+    p->persist = N == 256 || N == 128;  // (rpsf_plan_set_option RPSF_OPT_PERSIST)
     if (p->persist) {
       if (N == 256)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_kernel2_256p), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -710,7 +725,6 @@ static int plan_create_impl(rpsf_plan** out, int device, int patch_size, int n_p
         // Plain instead of streaming loads of the pair words where the plan's K (66,560 B per patch) fits the 256 MiB Infinity Cache beside the
         // planes: measured (profiles/r04av) -6 % per apply at 72 MB of K, +6.6 % at 160 MB; RPSF_K_CACHED=0/1 overrides (tests run both forms).
         p->k_cached = (size_t)(parent ? parent->n_patches : n_patches) * Cfg128v2::G_PER_PATCH * sizeof(cf) <= ((size_t)96 << 20);
-        if (const char* e = std::getenv("RPSF_K_CACHED")) p->k_cached = std::atoi(e) != 0;
       }
     }
     int rl = p->v2 ? dispatch_v2(N, [&]<class C>() -> int {
@@ -729,7 +743,6 @@ static int plan_create_impl(rpsf_plan** out, int device, int patch_size, int n_p
       return RPSF_OK;
     });
     if (rl != RPSF_OK) return rl;
-    if (const char* e = std::getenv("RPSF_DEBUG_ORPHAN")) p->orphan_mod = std::atoi(e);  // testing aid, see direct_store
     HIP_TRY(hipEventCreateWithFlags(&p->ev_busy, hipEventDisableTiming));
     rl = setup_lattice(p);
     if (rl != RPSF_OK) return rl;
@@ -1099,7 +1112,7 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
         // patches leave idle (RPSF_FRAME_MAJOR=0/1 overrides).
         bool frame_major = std::is_same_v<C, Cfg256v2> && p->persist && b.frames > 1 && p->n_patches >= 1024 &&
                            16.0 * (double)p->planes_floats * b.frames > 256.0 * 1048576.0;  // (8 x 2048^2: 0.056 ms per frame side by side, 0.061 in turn)
-        if (const char* e = std::getenv("RPSF_FRAME_MAJOR"))  // development sweeps: 0 = never, 2 = any persistent batch
+        if (const char* e = dev_env("RPSF_FRAME_MAJOR"))  // development sweeps: 0 = never, 2 = any persistent batch
           frame_major = std::atoi(e) == 2 ? (p->persist && b.frames > 1) : (frame_major && std::atoi(e) != 0);
         pp.frame_major = ts.frame_major = frame_major ? 1 : 0;
         // Frames of a batch side by side keep the planes of ALL of them live at once (8 x 2048^2: 537 MB against a 256 MiB Infinity Cache): the 128-pixel
@@ -1107,7 +1120,7 @@ static int launch_patches(rpsf_plan* p, const float* d_img, float* d_out, const 
         // plan at either size (profiles/r04bd).  RPSF_PLANE_NT=0/1 overrides (development sweeps).
         // (needs the plain-load form of K - a batch shares it - and planes well beyond the Infinity Cache: 4 x 2048^2, 268 MB, still loses 3 %; 6 x, 403 MB, gains 5 %)
         pp.plane_nt = std::is_same_v<C, Cfg128v2> && p->k_cached && b.frames > 1 && !frame_major && 16.0 * (double)p->planes_floats * b.frames > 300.0 * 1048576.0;
-        if (const char* e = std::getenv("RPSF_PLANE_NT")) pp.plane_nt = std::atoi(e) != 0 && std::is_same_v<C, Cfg128v2> && p->k_cached;
+        if (p->plane_nt_opt >= 0) pp.plane_nt = p->plane_nt_opt != 0 && std::is_same_v<C, Cfg128v2> && p->k_cached;  // (RPSF_OPT_PLANE_NT)
         const int tune_frames = b.frames;  // (the settings of a single apply measured worse here: 0.203 vs 0.186 ms per frame at 8 x 4096^2)
         pp.sum_first = sum_first_for(p, tune_frames);
         ts.planes_frame_floats = 4 * p->planes_floats, ts.out_frame_floats = b.out_stride;
@@ -1427,6 +1440,47 @@ extern "C" int rpsf_plan_set_overlap_mode(rpsf_plan* p, int mode) {
 }
 
 // Diagnostic builds only (-DRPSF_STAMPS): copy out the 16 per-patch phase timestamps (10 ns ticks).
+extern "C" int rpsf_plan_set_option(rpsf_plan* p, int option, int value) {
+  if (!p) return fail(RPSF_E_BADARG, "null plan");
+  switch (option) {
+    case RPSF_OPT_PERSIST:
+      if (value != 0 && value != 1) return fail(RPSF_E_BADARG, "RPSF_OPT_PERSIST takes 0 or 1");
+      p->persist = value != 0 && (p->N == 256 || p->N == 128);
+      break;
+    case RPSF_OPT_FUSE:
+      if (value != 0 && value != 1) return fail(RPSF_E_BADARG, "RPSF_OPT_FUSE takes 0 or 1");
+      p->no_fuse = value == 0;
+      break;
+    case RPSF_OPT_K_CACHED:
+      if (value != 0 && value != 1) return fail(RPSF_E_BADARG, "RPSF_OPT_K_CACHED takes 0 or 1");
+      p->k_cached = value != 0;
+      break;
+    case RPSF_OPT_PLANE_NT:
+      if (value < -1 || value > 1) return fail(RPSF_E_BADARG, "RPSF_OPT_PLANE_NT takes -1 (automatic), 0 or 1");
+      p->plane_nt_opt = value;
+      break;
+    case RPSF_OPT_HOST_BANDS:
+      if (value < -1 || value > 64) return fail(RPSF_E_BADARG, "RPSF_OPT_HOST_BANDS takes -1 (automatic) or 0..64");
+      p->host_bands_opt = value;
+      break;
+    case RPSF_OPT_STREAM_GROUP:
+      if (value < 0 || value > 64) return fail(RPSF_E_BADARG, "RPSF_OPT_STREAM_GROUP takes 0 (automatic) or 1..64");
+      p->stream_group_opt = value;
+      break;
+    case RPSF_OPT_STREAM_DEPTH:
+      if (value < 0 || value > 16) return fail(RPSF_E_BADARG, "RPSF_OPT_STREAM_DEPTH takes 0 (automatic) or 1..16");
+      p->stream_depth_opt = value;
+      break;
+    case RPSF_OPT_DEBUG_ORPHAN:
+      if (value < 0) return fail(RPSF_E_BADARG, "RPSF_OPT_DEBUG_ORPHAN takes 0 (off) or a positive modulus");
+      p->orphan_mod = value;
+      break;
+    default: return fail(RPSF_E_BADARG, "unknown plan option");
+  }
+  drop_bands(p);  // (views inherit nothing: they are rebuilt with the parent's settings at the next host frame)
+  return RPSF_OK;
+}
+
 extern "C" int rpsf_plan_set_sweep_regions(rpsf_plan* p, int target_regions) {
   if (!p || target_regions < 1 || target_regions > (1 << 20)) return fail(RPSF_E_BADARG, "target_regions must be 1..2^20");
   if (!p->sweep_ok) return fail(RPSF_E_STATE, "the sweep kernel needs a 16-, 32- or 64-pixel patch on a complete lattice of at least 2 x 2 patches");
@@ -1435,6 +1489,11 @@ extern "C" int rpsf_plan_set_sweep_regions(rpsf_plan* p, int target_regions) {
   HIP_TRY(hipDeviceSynchronize());  // (applies on other streams may still read the old lists)
   drop_bands(p);
   return build_sweep_lists(p, target_regions);
+}
+extern "C" int rpsf_plan_host_bands(const rpsf_plan* p, int* bands) {
+  if (!p || !bands) return fail(RPSF_E_BADARG, "null argument");
+  *bands = p->last_host_bands;
+  return RPSF_OK;
 }
 extern "C" int rpsf_plan_sweep_info(const rpsf_plan* p, int* regions, long* jobs, long* patch_slots, int* slabs_per_phase) {
   if (!p) return fail(RPSF_E_BADARG, "null plan");
@@ -1725,9 +1784,10 @@ static int ensure_bands(rpsf_plan* p, const rpsf_geometry& g, int want) {
   std::sort(rows.begin(), rows.end());
   rows.erase(std::unique(rows.begin(), rows.end()), rows.end());
   const int L = (int)rows.size();
-  const int B = std::min({want, (int)HostPipe::MAX_BANDS, L / 4});  // at least four lattice rows per band
+  const int B = std::min({want, (int)HostPipe::MAX_BANDS, L / 2});  // at least two lattice rows per band (it runs a third: the one above)
   if (B < 2) return 0;
   std::vector<int> cut(B + 1);
+  // (equal bands: a first band of two lattice rows - an earlier first download - bought nothing, profiles/r06y_host_frame_knobs.log)
   for (int b = 0; b < B; ++b) cut[b] = b == 0 ? 0 : std::min(H, std::max(0, rows[(size_t)L * b / B]));
   cut[B] = H;
   for (int b = 0; b < B; ++b)
@@ -1758,6 +1818,154 @@ static int ensure_bands(rpsf_plan* p, const rpsf_geometry& g, int want) {
   return B;
 }
 
+// One large frame in row bands, ONE pool job for both directions.  The workers stage the input piece by piece in row order (256 KiB
+// pieces, claimed with fetch_add: no barrier between chunks, so the sixteen of them stream at the rate scripts/micro/host_copy.hip measures
+// instead of the 78 GB/s of a job per 4 MiB chunk) and count finished pieces per chunk; the calling thread watches the counters, enqueues
+// a chunk's H2D the moment it is complete, launches a band behind the chunk that completes the rows it reads, enqueues the band's D2H
+// in pieces, polls the pieces' events and publishes each landed piece to the same workers, which widen it into the caller's array once
+// no staging piece is left.  Widening of band 0 therefore runs while the last chunks are still going in (round 5 staged everything, then
+// widened: "staged 1.0" + "out: waits 0.5 + conversions 0.9" one after the other, profiles/r05l_host_frame_row_bands.log).
+static int host_one_frame_banded(rpsf_plan* p, const void* image, int in_f64, void* out, int out_f64, const rpsf_geometry& g, int B,
+                                 bool direct_in, bool direct_out) {
+  HostPipe& q = *p->pipe;
+  HostPool& pool = HostPool::get(p->device);
+  const int W = g.width, H = g.height;
+  const size_t count = (size_t)H * W, bytes = count * sizeof(float);
+  constexpr size_t PIECE = (size_t)1 << 16;                      // floats per unit of work of a worker
+  static const bool trace = dev_env("RPSF_HOST_TRACE") != nullptr;
+  static const int frame_every = dev_env("RPSF_FRAME_EVERY") ? std::atoi(dev_env("RPSF_FRAME_EVERY")) : 0;
+  static const int frame_workers = dev_env("RPSF_FRAME_WORKERS") ? std::atoi(dev_env("RPSF_FRAME_WORKERS")) : 0;
+  const auto t_start = std::chrono::steady_clock::now();
+  auto ms_since = [&](std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  };
+  struct Range {
+    size_t lo, hi;
+  };
+  // input pieces: chunk by chunk, in row order
+  std::vector<Range> in_pieces;
+  std::vector<int> piece_chunk, chunk_pieces;
+  std::vector<Range> chunks;
+  // One upload per band - the rows it reads beyond the band before it - because every copy on a stream costs about 10 us of dead time
+  // before the next one starts (sixteen 4 MiB uploads: 45 GB/s against the 57 GB/s of one copy, profiles/r06v_host_frame_timeline.txt); a
+  // staged frame sends the first band's rows in four copies, so that the first one leaves when a sixteenth of the band is staged.
+  std::vector<int> cuts{0};
+  for (int b = 0; b < B; ++b) {
+    const int hi = b + 1 == B ? H : p->band_in_rows[b], lo = cuts.back();
+    if (hi <= lo) continue;
+    if (b == 0 && !direct_in)
+      for (int part = 1; part < 4; ++part) cuts.push_back(lo + (int)((long)(hi - lo) * part / 4));
+    cuts.push_back(hi);
+  }
+  for (size_t i = 0; i + 1 < cuts.size(); ++i) {
+    const size_t lo = (size_t)cuts[i] * W, hi = (size_t)cuts[i + 1] * W;
+    if (hi <= lo) continue;
+    int n = 0;
+    for (size_t a = lo; a < hi && !direct_in; a += PIECE, ++n) in_pieces.push_back({a, std::min(hi, a + PIECE)}), piece_chunk.push_back((int)chunks.size());
+    chunks.push_back({lo, hi}), chunk_pieces.push_back(n);
+  }
+  std::vector<std::atomic<int>> chunk_done(chunks.size());
+  for (auto& c : chunk_done) c.store(0, std::memory_order_relaxed);
+  // output pieces: appended by the calling thread as D2H pieces land (storage reserved up front: the workers index it while it grows)
+  std::vector<Range> out_pieces(direct_out ? 0 : count / PIECE + HostPipe::MAX_PIECES + 2);
+  std::atomic<size_t> next_in{0}, next_out{0}, out_avail{0};
+  std::atomic<int> closed{0};
+  const size_t n_in = in_pieces.size();
+  auto worker = [&](int) {
+    for (;;) {
+      if (next_in.load(std::memory_order_relaxed) < n_in) {
+        const size_t i = next_in.fetch_add(1, std::memory_order_relaxed);
+        if (i < n_in) {
+          rpsf_host::narrow_or_copy(q.h_in[0], image, in_f64 != 0, in_pieces[i].lo, in_pieces[i].hi);
+          chunk_done[piece_chunk[i]].fetch_add(1, std::memory_order_release);
+          continue;
+        }
+      }
+      size_t o = next_out.load(std::memory_order_relaxed);
+      if (o < out_avail.load(std::memory_order_acquire)) {
+        if (next_out.compare_exchange_weak(o, o + 1, std::memory_order_relaxed))
+          rpsf_host::widen_or_copy(out, out_f64 != 0, q.h_out[0], out_pieces[o].lo, out_pieces[o].hi);
+        continue;
+      }
+      if (closed.load(std::memory_order_acquire) && next_out.load(std::memory_order_relaxed) >= out_avail.load(std::memory_order_acquire)) return;
+      __builtin_ia32_pause();
+    }
+  };
+  hipError_t err = hipSuccess;
+  std::vector<Range> landed;  // D2H pieces in the order they were enqueued; event c is q.ev_chunk[c]
+  double t_enqueued = 0.0, t_first_out = 0.0, t_last_out = 0.0;
+  auto conductor = [&] {
+    size_t c = 0, published = 0, n_avail = 0;
+    int next_band = 0;
+    while (err == hipSuccess && (c < chunks.size() || published < landed.size())) {
+      bool progress = false;
+      if (c < chunks.size() && (direct_in || chunk_done[c].load(std::memory_order_acquire) == chunk_pieces[c])) {
+        const size_t lo = chunks[c].lo, hi = chunks[c].hi;
+        const int r1 = (int)(hi / W);
+        err = hipMemcpyAsync(q.d_in[0] + lo, (direct_in ? static_cast<const float*>(image) : q.h_in[0]) + lo, (hi - lo) * sizeof(float),
+                             hipMemcpyHostToDevice, q.st_in);
+        while (err == hipSuccess && next_band < B && p->band_in_rows[next_band] <= r1) {
+          const int b = next_band++;
+          const int R0 = p->band_rows[b], R1 = p->band_rows[b + 1];
+          rpsf_geometry gb = g;
+          gb.out_row0 = R0, gb.out_rows = R1 - R0;
+          err = hipEventRecord(q.ev_band_in[b], q.st_in);
+          if (err == hipSuccess) err = hipStreamWaitEvent(p->stream, q.ev_band_in[b], 0);
+          float* const host_out = direct_out ? static_cast<float*>(out) : q.h_out[0];
+          if (err == hipSuccess && launch_apply(p->bands[b], q.d_in[0], q.d_out[0] + (size_t)R0 * W, gb, p->stream, nullptr) != RPSF_OK)
+            err = hipErrorUnknown;
+          if (err == hipSuccess) err = hipEventRecord(q.ev_band_k[b], p->stream);
+          // (one download stream: a second one for every other band - to hide the 20 us between two copies of a stream - made the frame 8 % slower,
+          // and letting the band's kernel write the page-locked rows itself instead of a download 5 %: profiles/r06y, r06z_host_frame_knobs.log)
+          const hipStream_t so = q.st_out;
+          if (err == hipSuccess) err = hipStreamWaitEvent(so, q.ev_band_k[b], 0);
+          // one download per band; the last band of a frame that is widened afterwards in four, so that only a quarter of it is left
+          // to widen when the last byte has landed
+          const int sub = (b + 1 == B && !direct_out) ? 4 : 1;
+          const int rows_per_piece = (R1 - R0 + sub - 1) / sub;
+          for (int s0 = R0; s0 < R1 && err == hipSuccess; s0 += rows_per_piece) {
+            const size_t plo = (size_t)s0 * W, phi = (size_t)std::min(R1, s0 + rows_per_piece) * W;
+            err = hipMemcpyAsync(host_out + plo, q.d_out[0] + plo, (phi - plo) * sizeof(float), hipMemcpyDeviceToHost, so);
+            if (err == hipSuccess) err = hipEventRecord(q.ev_chunk[landed.size()], so);
+            landed.push_back({plo, phi});
+          }
+        }
+        if (++c == chunks.size()) t_enqueued = ms_since(t_start);
+        progress = true;
+      }
+      if (err == hipSuccess && published < landed.size()) {
+        // (while chunks are still to go in: a look; afterwards: a wait - nothing else is left for this thread to do)
+        const hipError_t qe = c < chunks.size() ? hipEventQuery(q.ev_chunk[published]) : hipEventSynchronize(q.ev_chunk[published]);
+        if (qe == hipSuccess) {
+          if (published == 0) t_first_out = ms_since(t_start);
+          if (!direct_out) {
+            for (size_t a = landed[published].lo; a < landed[published].hi; a += PIECE) out_pieces[n_avail++] = {a, std::min(landed[published].hi, a + PIECE)};
+            out_avail.store(n_avail, std::memory_order_release);
+          }
+          ++published, progress = true;
+        } else if (qe != hipErrorNotReady) {
+          err = qe;
+        }
+      }
+      if (!progress) __builtin_ia32_pause();
+    }
+    t_last_out = ms_since(t_start);
+    closed.store(1, std::memory_order_release);
+  };
+  if (direct_in && direct_out) conductor();  // nothing for the pool: the copy engines read and write the caller's pages
+  else {
+    // every second worker (one per CCD at the default width): sixteen threads streaming beside the copy engines slow the copies down more than they
+    // gain (H2D busy 1.78 ms of a 67 MB frame with 16 workers, 1.48 with 8, 1.28 with 4 - which then cannot keep up: profiles/r06x_host_frame_matrix.log)
+    const int every = frame_every > 0 ? frame_every : (pool.width() >= 16 ? 2 : 1);
+    pool.run(std::max(1, (frame_workers > 0 ? std::min(frame_workers, pool.width()) : pool.width()) / every), worker, conductor, every);
+  }
+  if (trace)
+    std::fprintf(stderr, "[rpsf host frame] %zu chunks, %d bands, %zu + %zu pieces: last chunk enqueued %.3f ms, first piece back %.3f, last %.3f, total %.3f ms\\n",
+                 chunks.size(), B, n_in, (size_t)out_avail.load(), t_enqueued, t_first_out, t_last_out, ms_since(t_start));
+  if (err != hipSuccess) return drain_after_error(p, err, "host frame");
+  return RPSF_OK;
+}
+
 // One frame.  The conversions run chunk by chunk (>= 4 MiB) on the pool, each chunk's H2D copy starts as soon as it is staged,
 // and on the way back each chunk is widened as soon as it has landed: conversion and PCIe overlap inside the frame.
 static int host_one_frame(rpsf_plan* p, const void* image, int in_f64, void* out, int out_f64, const rpsf_geometry& g) {
@@ -1771,7 +1979,7 @@ static int host_one_frame(rpsf_plan* p, const void* image, int in_f64, void* out
   const size_t per_chunk = ((count + n_chunks - 1) / n_chunks + 1023) & ~(size_t)1023;
   auto chunk_range = [&](int c, size_t& lo, size_t& hi) { lo = std::min(count, c * per_chunk), hi = std::min(count, lo + per_chunk); };
   hipError_t err = hipSuccess;
-  static const bool trace = std::getenv("RPSF_HOST_TRACE") != nullptr;  // development: where a host frame's milliseconds go (stderr)
+  static const bool trace = dev_env("RPSF_HOST_TRACE") != nullptr;  // development: where a host frame's milliseconds go (stderr)
   const auto t_start = std::chrono::steady_clock::now();
   auto ms_since = [&](std::chrono::steady_clock::time_point t0) {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -1780,55 +1988,17 @@ static int host_one_frame(rpsf_plan* p, const void* image, int in_f64, void* out
   const bool direct_in = !in_f64 && is_pinned_host(image), direct_out = !out_f64 && is_pinned_host(out);
   // Large frames are cut into row bands (views of this plan) so that the upload of band b + 1, the patches of band b and the download of
   // band b - 1 overlap (RPSF_HOST_BANDS=0: off, =n: that many).
-  int want_bands = bytes >= ((size_t)24 << 20) ? (int)(bytes >> 24) : 0;
-  if (const char* e = std::getenv("RPSF_HOST_BANDS")) want_bands = std::atoi(e);
+  // (a band per 8 MiB, at most eight: 4096^2 end to end 2.30 / 2.21 / 2.20 ms at 4 / 6 / 8 bands, page-locked 1.83 / 1.80 / 1.79, profiles/r06w_host_bands.log)
+  int want_bands = bytes >= ((size_t)24 << 20) ? (int)std::min<size_t>(8, bytes >> 23) : 0;
+  if (p->host_bands_opt >= 0) want_bands = p->host_bands_opt;  // (RPSF_OPT_HOST_BANDS)
   const int B = ensure_bands(p, g, want_bands);
+  p->last_host_bands = B;
   struct OutChunk {
     size_t lo, hi;
   };
   std::vector<OutChunk> out_chunks;  // in the order their download was enqueued; event c is q.ev_chunk[c]
-  if (B >= 2) {
-    // chunks of whole rows, in row order; a band is launched behind the chunk that completes the rows it reads
-    const int W = g.width, H = g.height;
-    const int rows_per_chunk = (H + n_chunks - 1) / n_chunks;
-    const int sub = std::max(1, (int)HostPipe::MAX_CHUNKS / B);  // download pieces per band
-    int next_band = 0;
-    for (int r0 = 0; r0 < H && err == hipSuccess; r0 += rows_per_chunk) {
-      const int r1 = std::min(H, r0 + rows_per_chunk);
-      const size_t lo = (size_t)r0 * W, hi = (size_t)r1 * W;
-      if (!direct_in) {
-        const auto t0 = std::chrono::steady_clock::now();
-        pool.run(T, [&](int t) {
-          size_t a, b;
-          rpsf_host::split_range(lo, hi, t, T, a, b);
-          rpsf_host::narrow_or_copy(q.h_in[0], image, in_f64 != 0, a, b);
-        });
-        t_conv_in += ms_since(t0);
-      }
-      err = hipMemcpyAsync(q.d_in[0] + lo, (direct_in ? static_cast<const float*>(image) : q.h_in[0]) + lo, (hi - lo) * sizeof(float),
-                           hipMemcpyHostToDevice, q.st_in);
-      while (err == hipSuccess && next_band < B && p->band_in_rows[next_band] <= r1) {
-        const int b = next_band++;
-        const int R0 = p->band_rows[b], R1 = p->band_rows[b + 1];
-        rpsf_geometry gb = g;
-        gb.out_row0 = R0, gb.out_rows = R1 - R0;
-        err = hipEventRecord(q.ev_band_in[b], q.st_in);
-        if (err == hipSuccess) err = hipStreamWaitEvent(p->stream, q.ev_band_in[b], 0);
-        if (err == hipSuccess && launch_apply(p->bands[b], q.d_in[0], q.d_out[0] + (size_t)R0 * W, gb, p->stream, nullptr) != RPSF_OK)
-          err = hipErrorUnknown;
-        if (err == hipSuccess) err = hipEventRecord(q.ev_band_k[b], p->stream);
-        if (err == hipSuccess) err = hipStreamWaitEvent(q.st_out, q.ev_band_k[b], 0);
-        const int rows_per_piece = (R1 - R0 + sub - 1) / sub;
-        for (int s0 = R0; s0 < R1 && err == hipSuccess; s0 += rows_per_piece) {
-          const size_t plo = (size_t)s0 * W, phi = (size_t)std::min(R1, s0 + rows_per_piece) * W;
-          err = hipMemcpyAsync((direct_out ? static_cast<float*>(out) : q.h_out[0]) + plo, q.d_out[0] + plo, (phi - plo) * sizeof(float),
-                               hipMemcpyDeviceToHost, q.st_out);
-          if (err == hipSuccess) err = hipEventRecord(q.ev_chunk[out_chunks.size()], q.st_out);
-          out_chunks.push_back({plo, phi});
-        }
-      }
-    }
-  } else {
+  if (B >= 2) return host_one_frame_banded(p, image, in_f64, out, out_f64, g, B, direct_in, direct_out);
+  {
   // (a frame of one chunk - under 8 MiB - has nothing to overlap with itself: everything on the plan's stream, no events to tie three together;
   // 512^2: 0.179 -> see profiles/r05v)
   const bool one_stream = n_chunks == 1;
@@ -1902,9 +2072,9 @@ static int host_one_frame(rpsf_plan* p, const void* image, int in_f64, void* out
 // Frames per group of the streamed pipeline: small frames go through the shared-K batch launch a few at a time (the packed K is
 // read once per group, and a launch / a copy of a few hundred KiB is all overhead: up to 32 frames or 16 MiB per group); from 16 MiB per
 // frame on (2048^2), where a frame's copies take several times its kernel, one by one - a short batch then pays the shortest ramp.
-static int stream_group_frames(size_t frame_bytes, int n_frames) {
+static int stream_group_frames(size_t frame_bytes, int n_frames, int stream_group_opt) {
   int g = (int)std::max<size_t>(1, std::min<size_t>(32, ((size_t)16 << 20) / std::max<size_t>(1, frame_bytes)));
-  if (const char* e = std::getenv("RPSF_STREAM_GROUP")) g = std::max(1, std::min(64, std::atoi(e)));  // development sweeps
+  if (stream_group_opt > 0) g = std::max(1, std::min(64, stream_group_opt));  // (RPSF_OPT_STREAM_GROUP)
   return std::min(g, n_frames);
 }
 
@@ -1920,13 +2090,13 @@ static int host_frames(rpsf_plan* p, const void* const* images, int in_f64, void
   // Groups: `first[i]` ... `first[i + 1]` are the frames of group i.  Small frames: equal groups.  Frames that go one by one (16 MiB and more) go two
   // by two in the MIDDLE of a long sequence - a staging job and an enqueue per two frames instead of per frame: 32 x 2048^2 float32 0.473 -> 0.415 ms
   // per frame - while the first and the last groups stay single frames, so that the ramps (the first upload, the last download) stay short
-  // (groups of two throughout cost an 8-frame batch 0.48 -> 0.57 ms per frame; profiles/r05y).  RPSF_STREAM_GROUP fixes one size for all.
-  const int G0 = stream_group_frames(bytes, n_frames);
+  // (groups of two throughout cost an 8-frame batch 0.48 -> 0.57 ms per frame; profiles/r05y).  RPSF_OPT_STREAM_GROUP fixes one size for all.
+  const int G0 = stream_group_frames(bytes, n_frames, p->stream_group_opt);
   std::vector<int> first{0};
   {
-    const bool pinned_size = std::getenv("RPSF_STREAM_GROUP") != nullptr;
+    const bool pinned_size = p->stream_group_opt > 0;
     int pairs_from = 12;
-    if (const char* e = std::getenv("RPSF_STREAM_PAIRS_FROM")) pairs_from = std::max(4, std::atoi(e));  // development sweeps
+    if (const char* e = dev_env("RPSF_STREAM_PAIRS_FROM")) pairs_from = std::max(4, std::atoi(e));  // development sweeps
     const bool pairs = !pinned_size && G0 == 1 && n_frames >= pairs_from && bytes * 2 <= ((size_t)128 << 20);
     while (first.back() < n_frames) {
       const int at = first.back(), left = n_frames - at;
@@ -1938,7 +2108,7 @@ static int host_frames(rpsf_plan* p, const void* const* images, int in_f64, void
   int G = 1;
   for (int i = 0; i < n_groups; ++i) G = std::max(G, first[i + 1] - first[i]);
   int depth = bytes * G >= ((size_t)128 << 20) ? 3 : HostPipe::MAX_DEPTH;
-  if (const char* e = std::getenv("RPSF_STREAM_DEPTH")) depth = std::max(1, std::min((int)HostPipe::MAX_DEPTH, std::atoi(e)));
+  if (p->stream_depth_opt > 0) depth = std::max(1, std::min((int)HostPipe::MAX_DEPTH, p->stream_depth_opt));  // (RPSF_OPT_STREAM_DEPTH)
   depth = std::min(depth, n_groups);
   int rc = pipe_ensure(p, count * G, depth);
   if (rc != RPSF_OK) return rc;
@@ -1950,7 +2120,7 @@ static int host_frames(rpsf_plan* p, const void* const* images, int in_f64, void
   const bool direct_out = !out_f64 && all_pinned(const_cast<const void* const*>(outs), n_frames);
   hipError_t err = hipSuccess;
   int next_in = 0, next_out = 0;
-  static const bool trace = std::getenv("RPSF_HOST_TRACE") != nullptr;  // development: where the host's time goes (stderr)
+  static const bool trace = dev_env("RPSF_HOST_TRACE") != nullptr;  // development: where the host's time goes (stderr)
   double t_jobs = 0.0, t_enqueue = 0.0, t_wait = 0.0;
   const auto t_start = std::chrono::steady_clock::now();
   auto ms_since = [&](std::chrono::steady_clock::time_point t0) {

@@ -53,8 +53,10 @@ class HostPool {
     run(parts, fn, [] {});
   }
   // ... with something for the calling thread to do while the workers are at it (the streamed path enqueues the previous group's copies and launch)
+  // `every`: only every n-th worker takes parts (the workers are spaced evenly over the node's cores, two per CCD at the default width: every = 2
+  // is one per CCD - the same set of cores every time, where "the first 8 of 16 to arrive" would be a different set per call)
   template <class F, class M>
-  void run(int parts, F&& fn, M&& meanwhile) {
+  void run(int parts, F&& fn, M&& meanwhile, int every = 1) {
     if (parts <= 0) {
       meanwhile();
       return;
@@ -67,7 +69,7 @@ class HostPool {
     std::lock_guard<std::mutex> one_job(submit_);
     Job job;
     job.call = [](void* ctx, int i) { (*static_cast<std::remove_reference_t<F>*>(ctx))(i); };
-    job.ctx = &fn, job.parts = parts;
+    job.ctx = &fn, job.parts = parts, job.every = std::max(1, std::min(every, std::max(1, n_workers_)));
     current_.store(&job);
     epoch_.fetch_add(1);
     if (sleepers_.load() > 0) {
@@ -91,7 +93,7 @@ class HostPool {
   struct Job {
     void (*call)(void*, int) = nullptr;
     void* ctx = nullptr;
-    int parts = 0;
+    int parts = 0, every = 1;
     alignas(64) std::atomic<int> next{0};
     alignas(64) std::atomic<int> done{0};
   };
@@ -139,23 +141,24 @@ class HostPool {
     }
     for (int i = 0; i < n_workers_; ++i) {
       const int cpu = cores.empty() ? -1 : cores[(size_t)i * cores.size() / n_workers_];
-      std::thread([this, cpu] {
+      std::thread([this, cpu, i] {
         if (cpu >= 0) {
           cpu_set_t set;
           CPU_ZERO(&set);
           CPU_SET(cpu, &set);
           (void)sched_setaffinity(0, sizeof(set), &set);
         }
-        worker();
+        worker(i);
       }).detach();
     }
   }
 
-  void worker() {
+  void worker(int index) {
     unsigned seen = 0;
     for (;;) {
       inside_.fetch_add(1);
-      if (Job* job = current_.load()) work_on(*job);
+      if (Job* job = current_.load())
+        if (index % job->every == 0) work_on(*job);
       inside_.fetch_sub(1);
       // wait for the next job: it usually follows within a few hundred microseconds (chunk after chunk of a frame, group after group of a batch)
       const auto t0 = std::chrono::steady_clock::now();
@@ -233,7 +236,7 @@ inline void split_range(size_t lo, size_t hi, int t, int T, size_t& a, size_t& b
 // Owned by the plan, grown on demand, freed with it; no entry point allocates per call once the sizes have been seen.
 // ------------------------------------------------------------------------------------------------
 struct HostPipe {
-  static constexpr int MAX_DEPTH = 4, MAX_CHUNKS = 16, MAX_BANDS = 8;
+  static constexpr int MAX_DEPTH = 4, MAX_CHUNKS = 16, MAX_BANDS = 16, MAX_PIECES = 2 * MAX_BANDS + 8;
   int depth = 0;
   size_t slot_floats = 0;
   hipStream_t st_in = nullptr, st_out = nullptr;
@@ -242,7 +245,7 @@ struct HostPipe {
   float* d_in[MAX_DEPTH] = {};
   float* d_out[MAX_DEPTH] = {};
   hipEvent_t ev_in[MAX_DEPTH] = {}, ev_k[MAX_DEPTH] = {}, ev_out[MAX_DEPTH] = {};
-  hipEvent_t ev_chunk[MAX_CHUNKS] = {};
+  hipEvent_t ev_chunk[MAX_PIECES] = {};  // download pieces of one frame (>= MAX_CHUNKS)
   hipEvent_t ev_band_in[MAX_BANDS] = {}, ev_band_k[MAX_BANDS] = {};  // a single frame cut into row bands (host_one_frame)
 
   void release_buffers() {

@@ -27,18 +27,16 @@ while time.time() < t_end:
         w = (w + 31) // 32 * 32  # the fused / HOT geometries
     pad_mode = str(rng.choice(["symmetric", "reflect", "constant", "edge", "wrap"]))
     frames = int(rng.integers(1, 9))
-    os.environ["RPSF_HOST_BANDS"] = str(int(rng.choice([0, 2, 3, 4, 8])))
-    os.environ["RPSF_STREAM_GROUP"] = str(int(rng.integers(1, 5)))
-    os.environ["RPSF_STREAM_DEPTH"] = str(int(rng.integers(1, 5)))
+    bands, group, depth = int(rng.choice([0, 2, 3, 4, 8])), int(rng.integers(1, 5)), int(rng.integers(1, 5))
     coords = [tuple(int(v) for v in c) for c in rp.calculate_covering((h, w), n)]
     k = ((rng.standard_normal((len(coords), n, n)) + 1j * rng.standard_normal((len(coords), n, n))) * 0.2).astype(np.complex64)
     dt_in = rng.choice([np.float32, np.float64])
     images = (rng.standard_normal((frames, h, w)) * 10 + 100).astype(dt_in)
     t = rp.ArrayPSFTransform(rp.IndexedCube(coords, k))
-    os.environ["RPSF_HOST_BANDS"], bands = "0", os.environ["RPSF_HOST_BANDS"]
+    plan = t._device_plan()  # (plan options: the shipped library reads none of this from the environment)
+    plan.set_option("stream_group", group), plan.set_option("stream_depth", depth), plan.set_option("host_bands", 0)
     whole = np.stack([t.apply(im, pad_mode=pad_mode) for im in images])
-    t.invalidate()
-    os.environ["RPSF_HOST_BANDS"] = bands
+    plan.set_option("host_bands", bands)
     loop = np.stack([t.apply(im, pad_mode=pad_mode) for im in images])
     assert np.array_equal(loop, whole), ("bands", n, h, w, pad_mode, bands)
     batch = t.apply_batch(images, pad_mode=pad_mode)

@@ -112,6 +112,7 @@ def test_development_switches_still_compile(tmp_path):
         "k2_256p.hip": ["-DRPSF_STAMPS", "-DRPSF_WAVE_STAMPS", "-DRPSF2_ABL_NOGATHER", "-DRPSF2_ABL_NOK", "-DRPSF2_ABL_NOSTORE",
                         "-DRPSF2_ABL_NOVALU", "-DRPSF2_ABL_NOLDS", "-DRPSF2_ABL_NOBAR"],
         "k2_128p.hip": ["-DRPSF_STAMPS", "-DRPSF2_ABL_NOBAR_MASK=20"],
+        "rpsf.hip": ["-DRPSF_DEV_ENV"],  # the environment knobs of the development sweeps
     }
     for source, defines in sets.items():
         out = tmp_path / (source + ".o")
@@ -119,6 +120,31 @@ def test_development_switches_still_compile(tmp_path):
                               capture_output=True, text=True)
         assert done.returncode == 0, done.stderr[-2000:]
         assert out.stat().st_size > 0
+
+
+def test_the_shipped_library_reads_two_environment_variables():
+    """A stray variable in a production environment must not change which kernel runs: the product sources call getenv for the host
+    pool's two variables only (documented in include/rpsf.h); the development knobs go through dev_env(), which compiles to nothing
+    without -DRPSF_DEV_ENV, and everything a test or a caller may pin is rpsf_plan_set_option."""
+    import re
+
+    from regularizepsf_amd import build as hip_build
+
+    reads = {}
+    for path in sorted(p for p in hip_build.CSRC.glob("*") if p.is_file()):
+        text = path.read_text()
+        for name in re.findall(r'std::getenv\("([A-Z_0-9]+)"\)', text):
+            reads.setdefault(name, path.name)
+    assert set(reads) == {"RPSF_HOST_THREADS", "RPSF_HOST_AFFINITY"}, reads
+    header = (ROOT / "include" / "rpsf.h").read_text()
+    assert all(name in header for name in reads)
+    # the one other getenv of the sources is dev_env's own, under the define the product build never sets
+    host = (hip_build.CSRC / "rpsf.hip").read_text()
+    assert host.count("std::getenv(") == 1 and "#if defined(RPSF_DEV_ENV)\n  return std::getenv(name);" in host
+    assert "RPSF_DEV_ENV" not in " ".join(hip_build.FLAGS)
+    binary = (ROOT / "regularizepsf_amd" / "librpsf_hip.so").read_bytes()
+    for knob in (b"RPSF_STRIPS", b"RPSF_SUM_FIRST", b"RPSF_V1\0", b"RPSF_NO_PERSIST", b"RPSF_K_CACHED", b"RPSF_STREAM_GROUP"):
+        assert knob not in binary, knob
 
 
 @pytest.mark.parametrize("threads", ["1", "3", "16"])

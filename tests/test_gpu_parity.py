@@ -262,7 +262,7 @@ def test_forced_atomic_mode_matches_planes():
 def test_direct_overlap_add_matches_planes_and_is_reproducible(n, shape, monkeypatch):
     """The three overlap-add strategies on a lattice - direct accumulation through the XCD's L2 (default for 128/256-px
     patches), colour planes + plane sum, float atomics - agree to round-off; the direct one is bit-reproducible, and
-    so is its run-time demotion path (RPSF_DEBUG_ORPHAN makes every third workgroup behave as if it had been placed on
+    so is its run-time demotion path (RPSF_OPT_DEBUG_ORPHAN makes every third workgroup behave as if it had been placed on
     a foreign XCD: its tiles go through the colour planes and the fix-up kernel)."""
     from regularizepsf_amd import _native
 
@@ -274,17 +274,15 @@ def test_direct_overlap_add_matches_planes_and_is_reproducible(n, shape, monkeyp
     pad = _native.PAD_MODES["reflect"]
     outs = {}
     for mode in ("direct", "planes", "atomic", "orphans"):
-        if mode == "orphans":
-            monkeypatch.setenv("RPSF_DEBUG_ORPHAN", "3")
-        plan = _native.Plan(n, coords)  # the knob is read when the plan is created
+        plan = _native.Plan(n, coords)
         plan.set_transfer(k)
         plan.set_overlap_mode("direct" if mode == "orphans" else mode)
+        if mode == "orphans":
+            plan.set_option("debug_orphan", 3)
         outs[mode] = plan.apply(image, pad)
         if mode in ("direct", "orphans"):
             for _ in range(3):
                 assert np.array_equal(plan.apply(image, pad), outs[mode]), mode
-        if mode == "orphans":
-            monkeypatch.delenv("RPSF_DEBUG_ORPHAN")
     scale = np.abs(outs["planes"]).max()
     assert np.isfinite(outs["direct"]).all()
     for mode in ("direct", "atomic", "orphans"):
@@ -956,14 +954,10 @@ def test_fused_plane_sum_epochs_origins_and_fallback():
     plan = _native.Plan(n, coords)
     plan.set_transfer(k)
     a = plan.apply(big, 1)
-    import os
-    os.environ["RPSF_NO_FUSE"] = "1"
-    try:
-        plan2 = _native.Plan(n, coords)
-        plan2.set_transfer(k)
-        b = plan2.apply(big, 1)
-    finally:
-        del os.environ["RPSF_NO_FUSE"]
+    plan2 = _native.Plan(n, coords)
+    plan2.set_transfer(k)
+    plan2.set_option("fuse", 0)
+    b = plan2.apply(big, 1)
     assert np.array_equal(a, b)
 
 
@@ -973,7 +967,7 @@ def test_persistent_patch_workgroups_bit_identical(shape):
     from a queue and jumps back to the kernel's first instruction (the queues and the tile counters are never reset, the
     previous patch is counted on its tiles from inside the next pass).  Repeated applies of one plan, more patches than the
     chip holds workgroups (2048 x 2304: 323 > 256 - 8), fewer patches than XCDs have slots (512^2: 25) - against the oracle
-    and bit-identical to the one-patch-per-workgroup launch (RPSF_NO_PERSIST)."""
+    and bit-identical to the one-patch-per-workgroup launch (RPSF_OPT_PERSIST = 0)."""
     import os
 
     from regularizepsf_amd import _native
@@ -993,13 +987,10 @@ def test_persistent_patch_workgroups_bit_identical(shape):
     plan.set_reserved_cus(0)
     plan.set_stagger(0)
     assert np.array_equal(plan.apply(image, 1), outs[0])
-    os.environ["RPSF_NO_PERSIST"] = "1"
-    try:
-        plain = _native.Plan(n, coords)
-        plain.set_transfer(k)
-        assert np.array_equal(plain.apply(image, 1), outs[0])
-    finally:
-        del os.environ["RPSF_NO_PERSIST"]
+    plain = _native.Plan(n, coords)
+    plain.set_transfer(k)
+    plain.set_option("persist", 0)
+    assert np.array_equal(plain.apply(image, 1), outs[0])
 
 
 def test_image_prefetch_changes_nothing_but_the_timing():
@@ -1104,14 +1095,11 @@ def test_specialised_persistent_kernels_and_the_geometries_they_hand_back():
         for mode in ("symmetric", "constant", "wrap", "reflect", "edge"):
             outs[mode] = plan.apply(image, _native.PAD_MODES[mode])
             check(outs[mode].astype(np.float64), orc.apply_transfer(image, coords, k, pad_mode=mode))
-        os.environ["RPSF_NO_PERSIST"] = "1"
-        try:
-            plain = _native.Plan(n, coords)
-            plain.set_transfer(k)
-            for mode in ("symmetric", "wrap", "reflect"):
-                assert np.array_equal(plain.apply(image, _native.PAD_MODES[mode]), outs[mode]), mode
-        finally:
-            del os.environ["RPSF_NO_PERSIST"]
+        plain = _native.Plan(n, coords)
+        plain.set_transfer(k)
+        plain.set_option("persist", 0)
+        for mode in ("symmetric", "wrap", "reflect"):
+            assert np.array_equal(plain.apply(image, _native.PAD_MODES[mode]), outs[mode]), mode
         # device-resident views: the image one float into its buffer (rows no longer 16-byte aligned) with an odd stride
         h, w = shape
         ld = w + 3
@@ -1144,8 +1132,8 @@ def test_fused_sum_of_tiles_the_image_clips_to_an_odd_width():
 
 def test_every_form_of_the_128_pixel_persistent_kernel():
     """The 128-pixel persistent kernel exists three times: with streaming loads of the pair words of K (patch_kernel2_128p), with plain ones
-    (patch_kernel2_128pc, chosen at plan creation when K fits the Infinity Cache beside the planes; RPSF_K_CACHED overrides) and with streaming
-    plane stores on top (patch_kernel2_128pcs, chosen per launch for large batches; RPSF_PLANE_NT overrides).  Same frame, same K, every form,
+    (patch_kernel2_128pc, chosen at plan creation when K fits the Infinity Cache beside the planes; RPSF_OPT_K_CACHED overrides) and with streaming
+    plane stores on top (patch_kernel2_128pcs, chosen per launch for large batches; RPSF_OPT_PLANE_NT overrides).  Same frame, same K, every form,
     single frame and a batch of three that share K: against the oracle, and bit-identical to each other."""
     import os
 
@@ -1158,11 +1146,8 @@ def test_every_form_of_the_128_pixel_persistent_kernel():
     frames = (rng.standard_normal((3, *shape)) * 10 + 30).astype(np.float32)
     outs = {}
     for form in ("0", "1"):
-        os.environ["RPSF_K_CACHED"] = form
-        try:
-            plan = _native.Plan(n, coords)
-        finally:
-            del os.environ["RPSF_K_CACHED"]
+        plan = _native.Plan(n, coords)
+        plan.set_option("k_cached", int(form))
         plan.set_transfer(k)
         single = plan.apply(frames[0], _native.PAD_MODES["symmetric"])
         check(single.astype(np.float64), orc.apply_transfer(frames[0], coords, k, pad_mode="symmetric"))
@@ -1172,11 +1157,9 @@ def test_every_form_of_the_128_pixel_persistent_kernel():
         outs[form] = (single, batch)
     assert np.array_equal(outs["0"][0], outs["1"][0]) and np.array_equal(outs["0"][1], outs["1"][1])
     # the third form (patch_kernel2_128pcs: streaming plane stores, taken by large batches) on the same batch
-    os.environ["RPSF_PLANE_NT"] = "1"
-    try:
-        streamed = plan.apply_batch(frames, _native.PAD_MODES["symmetric"])
-    finally:
-        del os.environ["RPSF_PLANE_NT"]
+    plan.set_option("plane_nt", 1)
+    streamed = plan.apply_batch(frames, _native.PAD_MODES["symmetric"])
+    plan.set_option("plane_nt", -1)
     assert np.array_equal(streamed, outs["1"][1])
 
 

@@ -49,13 +49,13 @@ def test_config5_eight_2048_frames_streamed_equals_the_loop_and_the_oracle():
 @pytest.mark.parametrize(("n", "shape", "frames", "group", "depth"), [
     (32, (96, 80), 11, 1, 4), (32, (96, 80), 11, 3, 2), (64, (200, 256), 7, 2, 3), (128, (384, 512), 9, 1, 1),
     (128, (384, 512), 9, 4, 4), (256, (512, 768), 5, 1, 4), (256, (512, 768), 5, 2, 2), (20, (50, 60), 6, 4, 3)])
-def test_streamed_groups_depths_and_dtypes(n, shape, frames, group, depth, monkeypatch):
+def test_streamed_groups_depths_and_dtypes(n, shape, frames, group, depth):
     """Every group size / pipeline depth (short last group, slots reused several times), float32 and float64 on either
     side, stacks and lists of arrays: the streamed result is the loop's, bit for bit."""
-    monkeypatch.setenv("RPSF_STREAM_GROUP", str(group))
-    monkeypatch.setenv("RPSF_STREAM_DEPTH", str(depth))
     coords, k, images = _case(n, shape, frames, 13 * n + frames)
     t = rp.ArrayPSFTransform(rp.IndexedCube(coords, k))
+    t._device_plan().set_option("stream_group", group)  # (plan options, include/rpsf.h: the shipped library reads no such thing from the environment)
+    t._device_plan().set_option("stream_depth", depth)
     loop = np.stack([t.apply(im) for im in images])
     if n in _native.SUPPORTED_PATCH_SIZES:
         same = np.array_equal
@@ -165,23 +165,21 @@ def test_streamed_errors_are_reported():
 
 @pytest.mark.parametrize(("n", "shape", "pad_mode"), [(256, (3072, 2048), "symmetric"), (128, (2560, 2304), "reflect"),
                                                       (64, (2200, 3000), "constant"), (256, (4096, 4096), "symmetric")])
-def test_a_large_frame_cut_into_row_bands_is_bit_identical_to_the_whole_frame(n, shape, pad_mode, monkeypatch):
+def test_a_large_frame_cut_into_row_bands_is_bit_identical_to_the_whole_frame(n, shape, pad_mode):
     """Host frames of 24 MiB and more are cut into row bands (views of the plan that share its K) so that upload, patches and
     download of ONE frame overlap; the bands take their plane colours from the whole lattice, so the result is the whole-frame
     apply's bit for bit - with two, four or eight bands, odd shapes, and from page-locked arrays."""
     coords, k, images = _case(n, shape, 1, 5 * n)
     image = images[0]
     t = rp.ArrayPSFTransform(rp.IndexedCube(coords, k))
-    monkeypatch.setenv("RPSF_HOST_BANDS", "0")
+    t._device_plan().set_option("host_bands", 0)
     whole = t.apply(image, pad_mode=pad_mode)
     check(whole, orc.apply_transfer(image, coords, k, pad_mode=pad_mode, workers=-1))
-    for bands in ("2", "4", "8"):
-        monkeypatch.setenv("RPSF_HOST_BANDS", bands)
-        t.invalidate()  # (a plan keeps the bands it built for a frame shape: a new plan per setting)
+    for bands in (2, 4, 8):
+        t._device_plan().set_option("host_bands", bands)  # (setting an option drops the bands built for the setting before)
         assert np.array_equal(t.apply(image, pad_mode=pad_mode), whole), bands
         assert np.array_equal(t.apply(image.astype(np.float64), pad_mode=pad_mode), whole), bands
-    monkeypatch.delenv("RPSF_HOST_BANDS")
-    t.invalidate()
+    t._device_plan().set_option("host_bands", -1)
     assert np.array_equal(t.apply(image, pad_mode=pad_mode), whole)  # the default choice for this size
     pin = rp.pinned_empty(shape, np.float32)
     pin[...] = image
