@@ -477,6 +477,9 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default=None, choices=[str(c) for c in sorted(CONFIGS)] + ["construct"],
                     help="default: 3 (BASELINE headline) on one GPU, 4 (one 8192^2 frame, row bands, strong scaling) on several")
+    ap.add_argument("--patch", type=int, default=None,
+                    help="N = 1: a 4096^2 frame with patches of this size instead of a numbered config - any size the reference takes (transform.py:151-155); "
+                         "sizes other than 16, 32, 64, 128, 256 run the hipFFT fallback")
     ap.add_argument("--weak", action="store_true", help="N > 1: grow the image with the ranks instead of cutting one frame")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--prewarm-ms", type=float, default=100.0,
@@ -547,7 +550,13 @@ def main() -> None:
     from regularizepsf_amd import _native
     from regularizepsf_amd.sharding import ShardedApply
 
+    if args.patch is not None:
+        if world > 1:
+            raise SystemExit("--patch is a one-GPU line")
+        CONFIGS[9] = (4096, 4096, args.patch, 9)
+        args.config = 9
     h1, w, n, seed = CONFIGS[args.config]
+    compiled = n in (16, 32, 64, 128, 256)  # a hand-written plan; everything else: gather -> hipFFT -> x K -> hipFFT -> overlap-add
     strong = args.config == 4 or not args.weak  # one frame cut into `world` bands; --weak: the image grows with the ranks
     height = h1 if strong else h1 * world
     device = local_rank % max(1, _native.device_count())  # (one process per GPU; on a box with fewer GPUs than ranks - debugging - ranks share devices)
@@ -777,7 +786,7 @@ def main() -> None:
     # (each per-apply event pair puts a marker packet between two launches, ~8 us of the 184 here: the loop as the device sees it is one pair of
     # events around `iters` back-to-back applies; with the plane sum fused into the patch launch - N = 128, 256 - an apply IS one launch of the kernel)
     sweep = plan.sweep_info() if n <= 64 else {"regions": 0}
-    one_launch = n >= 128 or sweep["regions"] > 0  # the whole apply is one launch of the dominant kernel
+    one_launch = compiled and (n >= 128 or sweep["regions"] > 0)  # the whole apply is one launch of the dominant kernel
     if one_launch:
         kern_avg_ms = timed_loop_event_ms if timed_loop_event_ms is not None else loop_ms
     my_patches = plan.n_patches
@@ -815,7 +824,9 @@ def main() -> None:
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
             "frac_of_measured_copy_ceiling": round(achieved / MEASURED_COPY_GBS, 4),
-            "kernel": "patch_kernel2_256p" if n == 256 else "patch_kernel2_128p" if n == 128 else "sweep_kernel" if sweep["regions"] else "patch_kernel",
+            "kernel": ("hipFFT fallback: generic_gather + hipFFT C2C forward + generic_multiply + hipFFT C2C inverse + 4 x generic_scatter (colour classes) per chunk"
+                       if not compiled else
+                       "patch_kernel2_256p" if n == 256 else "patch_kernel2_128p" if n == 128 else "sweep_kernel" if sweep["regions"] else "patch_kernel"),
             "whole_apply_ms": round(step_ms, 4), "kernel_avg_ms": round(kern_avg_ms, 4), "kernel_launches": iters,
             "frac_patch_kernel_only": round(achieved_kernel / HBM_PEAK_GBS, 4),
             "algorithmic_bytes": int(alg_bytes), "packed_k_bytes": int(plan.transfer_bytes),
@@ -827,6 +838,14 @@ def main() -> None:
                                    "HIP event pairs around every patch-kernel launch"),
         },
     }
+    if not compiled:  # the path the reference allows for every N: what it costs, with the bytes it really moves beside the algorithmic ones
+        per = n * n * 8
+        line["roofline"]["fallback"] = {
+            "what": "no hand-written plan for this patch size: full complex transforms through hipFFT on a staging buffer, the caller's unfolded K",
+            "bytes_moved_model": int(band.image_rows * w * 4 * 4 + my_patches * per * (1 + 2 + 3 + 2 + 1) + band.out_rows * w * 4 * (1 + 2 * 4)),
+            "bytes_moved_what": "gather (4 x image read, buffer write) + forward FFT (read + write) + multiply (buffer read + write, K read) + inverse FFT "
+                                "(read + write) + scatter (buffer read, 4 x output read-modify-write) + the output memset, if nothing stayed in a cache",
+            "overlap_add": "colour classes, fixed order (bit-reproducible)"}
     if sweep["regions"]:  # third generation: how the lattice was cut (patches on region borders are computed by both neighbours)
         line["config"]["sweep"] = {"regions": sweep["regions"], "jobs": sweep["jobs"], "slabs_per_phase": sweep["slabs_per_phase"],
                                    "recompute_factor": round(sweep["patch_slots"] / max(1, my_patches), 3)}

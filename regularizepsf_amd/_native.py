@@ -227,8 +227,8 @@ class Plan:
         check(lib().rpsf_plan_set_transfer_spectra_device(self._handle, s_ptr, t_ptr, float(alpha), float(epsilon)))
 
     def set_overlap_mode(self, mode: str) -> None:
-        """'auto' (on lattices: 'direct' for 128/256-pixel patches, 'planes' for smaller ones; 'atomic' otherwise),
-        'atomic', 'planes' or 'direct'."""
+        """'auto' (complete lattices of 16-, 32-, 64-pixel patches: 'sweep'; other lattices - and the fallback's colour classes on a covering -
+        'planes'; 'atomic' otherwise), 'atomic', 'planes', 'direct' or 'sweep'."""
         check(lib().rpsf_plan_set_overlap_mode(self._handle, {"auto": 0, "atomic": 1, "planes": 2, "direct": 3, "sweep": 4}[mode]))
 
     OPTIONS = {"persist": 1, "fuse": 2, "k_cached": 3, "plane_nt": 4, "host_bands": 5, "stream_group": 6, "stream_depth": 7, "debug_orphan": 8}

@@ -198,6 +198,7 @@ struct rpsf_plan {
   cf* d_kfull = nullptr;       // the caller's K, (n, N, N) complex64, unfolded
   cf* d_fft_buf = nullptr;     // fft_chunk x N x N complex work buffer
   float* d_win_generic = nullptr;
+  uint8_t* d_colour_generic = nullptr;  // colour class per patch when the corners allow one (generic_colours), else null: atomic adds
   void* fft_plan = nullptr;    // hipfftHandle for fft_chunk patches
   int fft_chunk = 0;
   // third generation (rpsf_kernels3.hpp, N <= 64 on a complete lattice of at least 2 x 2 patches): regions, job lists, packed K
@@ -584,6 +585,32 @@ extern "C" int rpsf_device_info(int device, int* compute_units, char* name, size
 
 
 // ------------------------------------------------------------------------------------------------
+// Colour classes for the fallback's overlap-add (any N, odd ones too): calculate_covering (regularizepsf/util.py:10-53) lays four sub-grids of
+// pitch N - corner rows k N and k N - ceil(N / 2), the same for columns - so the corner rows of a covering take at most two residues modulo
+// N, and so do the columns.  Colour = (row residue class, column residue class): two distinct patches of one colour differ by a multiple of N
+// in a coordinate, i.e. they do not overlap.  False (atomic adds) for corner lists without that structure or with a corner listed twice.
+static bool generic_colours(int N, const int32_t* coords_rc, int n, std::vector<uint8_t>& colours) {
+  int res[2][2], nres[2] = {0, 0};
+  colours.assign((size_t)n, 0);
+  std::vector<std::pair<int32_t, int32_t>> seen((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    seen[(size_t)i] = {coords_rc[2 * i], coords_rc[2 * i + 1]};
+    for (int axis = 0; axis < 2; ++axis) {
+      const int r = ((coords_rc[2 * i + axis] % N) + N) % N;
+      int cls = -1;
+      for (int k = 0; k < nres[axis]; ++k)
+        if (res[axis][k] == r) cls = k;
+      if (cls < 0) {
+        if (nres[axis] == 2) return false;
+        cls = nres[axis], res[axis][nres[axis]++] = r;
+      }
+      colours[(size_t)i] |= (uint8_t)(cls << (1 - axis));
+    }
+  }
+  std::sort(seen.begin(), seen.end());
+  return std::adjacent_find(seen.begin(), seen.end()) == seen.end();
+}
+
 // Any other patch size: fallback through hipFFT (loaded with dlopen, like RCCL).
 // The reference accepts every square patch size (odd ones included, transform.py:151-164); the
 // hand-written plans cover 16..256.  For the rest: gather+pad+window into a complex batch, batched
@@ -667,6 +694,14 @@ static int plan_create_impl(rpsf_plan** out, int device, int patch_size, int n_p
       for (int i = 0; i < N; ++i) win[i] = (float)std::sin((i + 0.5) * M_PI / N);  // transform.py:151-155
       HIP_TRY(hipMalloc(&p->d_win_generic, sizeof(float) * N));
       HIP_TRY(hipMemcpy(p->d_win_generic, win.data(), sizeof(float) * N, hipMemcpyHostToDevice));
+      {
+        std::vector<uint8_t> colours;
+        if (generic_colours(N, p->h_coords.data(), n_patches, colours)) {
+          HIP_TRY(hipMalloc(&p->d_colour_generic, colours.size()));
+          HIP_TRY(hipMemcpy(p->d_colour_generic, colours.data(), colours.size(), hipMemcpyHostToDevice));
+          p->lattice = true;  // (what rpsf_plan_set_overlap_mode(2) and the automatic mode ask for)
+        }
+      }
       const size_t per = (size_t)N * N;
       HIP_TRY(hipMalloc(&p->d_kfull, per * n_patches * sizeof(cf)));
       p->g_elems = per * n_patches;
@@ -839,6 +874,7 @@ extern "C" void rpsf_plan_destroy(rpsf_plan* p) {
   (void)hipFree(p->d_kfull);
   (void)hipFree(p->d_fft_buf);
   (void)hipFree(p->d_win_generic);
+  (void)hipFree(p->d_colour_generic);
   if (p->fft_plan && g_hipfft.destroy) (void)g_hipfft.destroy(p->fft_plan);
   (void)hipFree(p->d_planes);
   (void)hipFree(p->d_prefetch_tiles);
@@ -1280,7 +1316,12 @@ static int launch_apply_generic(rpsf_plan* p, const float* d_img, float* d_out, 
       generic_multiply_kernel<<<dim3(grid), dim3(256), 0, st>>>(p->d_fft_buf, p->d_kfull + (size_t)first * per, total, scale);
       if (g_hipfft.exec_c2c(p->fft_plan, p->d_fft_buf, p->d_fft_buf, /*HIPFFT_BACKWARD*/ 1) != 0)
         return fail(RPSF_E_HIP, "hipfftExecC2C (inverse) failed");
-      generic_scatter_kernel<<<dim3(grid), dim3(256), 0, st>>>(gg, p->d_coords, p->d_win_generic, p->d_fft_buf);
+      if (p->d_colour_generic && overlap_kind(p) != OV_ATOMIC) {
+        for (int colour = 0; colour < 4; ++colour)
+          generic_scatter_kernel<<<dim3(grid), dim3(256), 0, st>>>(gg, p->d_coords, p->d_win_generic, p->d_fft_buf, p->d_colour_generic, colour);
+      } else {
+        generic_scatter_kernel<<<dim3(grid), dim3(256), 0, st>>>(gg, p->d_coords, p->d_win_generic, p->d_fft_buf, nullptr, -1);
+      }
       HIP_TRY(hipGetLastError());
     }
   }

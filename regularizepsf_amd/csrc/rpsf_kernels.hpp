@@ -975,15 +975,22 @@ __global__ void generic_multiply_kernel(cf* __restrict__ buf, const cf* __restri
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < count) buf[i] = cmul(buf[i], k[i]) * scale;
 }
+// `colour` < 0: every patch of the chunk, atomic adds (any corner list).  `colour` 0 .. 3: only the patches of that colour class, which do not
+// overlap one another (rpsf.hip generic_colours), with plain read-add-write: the four passes of a chunk run one after the other on the
+// stream, so every pixel receives its contributions in a fixed order and the fallback is bit-reproducible like the compiled sizes.
 __global__ void generic_scatter_kernel(GenericGeom gg, const int32_t* __restrict__ coords, const float* __restrict__ win,
-                                       const cf* __restrict__ buf) {
+                                       const cf* __restrict__ buf, const uint8_t* __restrict__ colours, int colour) {
   const size_t per = (size_t)gg.N * gg.N;
   size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= per * gg.count) return;
   const int k = (int)(idx / per), rem = (int)(idx % per), r = rem / gg.N, c = rem % gg.N;
+  if (colour >= 0 && colours[gg.first + k] != colour) return;
   const int y = coords[2 * (gg.first + k)] + gg.origin_row + r, x = coords[2 * (gg.first + k) + 1] + gg.origin_col + c;
   if (y < 0 || y >= gg.ov.H || x < 0 || x >= gg.ov.W) return;  // the crop of transform.py:174-177
-  unsafeAtomicAdd(gg.ov.out + (size_t)(y - gg.ov.row0) * gg.ov.ld + x, buf[idx].x * (win[r] * win[c]));
+  float* dst = gg.ov.out + (size_t)(y - gg.ov.row0) * gg.ov.ld + x;
+  const float v = buf[idx].x * (win[r] * win[c]);
+  if (colour >= 0) *dst += v;
+  else unsafeAtomicAdd(dst, v);
 }
 
 

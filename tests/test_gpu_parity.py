@@ -564,6 +564,39 @@ def test_any_patch_size_goes_through_the_hipfft_fallback(n, shape, pad_mode):
     assert t.apply(image, saturation_threshold=55.0).shape == shape  # host-padded route (shifted origin) also works
 
 
+@pytest.mark.parametrize(("n", "shape"), [(96, (700, 900)), (45, (300, 260))])
+def test_the_fallback_adds_in_a_fixed_order_on_a_covering(n, shape):
+    """On the corners calculate_covering lays (util.py:10-53; odd sizes too) the fallback's overlap-add goes colour class by colour class with plain
+    adds - four passes per chunk, patches of one class do not overlap - so its results are bit-reproducible like the compiled sizes'; float atomics
+    (mode "atomic", and every corner list without that structure) meet the tolerance but not the bits."""
+    from regularizepsf_amd import _native
+
+    rng = np.random.default_rng(n)
+    coords = [tuple(int(v) for v in c) for c in rp.calculate_covering(shape, n)]
+    k = (rng.standard_normal((len(coords), n, n)) + 1j * rng.standard_normal((len(coords), n, n))).astype(np.complex64)
+    image = (rng.standard_normal(shape) * 10 + 40).astype(np.float32)
+    ref = orc.apply_transfer(image, coords, k)
+    plan = _native.Plan(n, coords)
+    plan.set_transfer(k)
+    pad = _native.PAD_MODES["symmetric"]
+    first = plan.apply(image, pad)
+    check(first.astype(np.float64), ref)
+    for _ in range(6):
+        assert np.array_equal(plan.apply(image, pad), first)
+    # the same patches listed in another order: other chunks, the same colour order inside every pixel only if one chunk holds them all
+    plan.set_overlap_mode("atomic")
+    check(plan.apply(image, pad).astype(np.float64), ref)
+    plan.set_overlap_mode("planes")
+    assert np.array_equal(plan.apply(image, pad), first)
+    # corners off any covering: atomics, within the tolerance
+    moved = [(r + (3 if i % 5 == 0 else 0), c) for i, (r, c) in enumerate(coords)]
+    other = _native.Plan(n, moved)
+    other.set_transfer(k)
+    with pytest.raises(_native.NativeError, match="lattice"):
+        other.set_overlap_mode("planes")
+    check(other.apply(image, pad).astype(np.float64), orc.apply_transfer(image, moved, k))
+
+
 def test_integration_stub_call_sequence():
     """The reference-side binding shown in INTEGRATION.md, call for call (raw ctypes, no helper layer)."""
     import ctypes
