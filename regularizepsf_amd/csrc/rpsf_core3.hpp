@@ -55,7 +55,11 @@ template <int LOGN_, int KSMAX_ = 2, int WAVES_ = 8>
 struct Cfg3 {
   static constexpr int LOGN = LOGN_, N = 1 << LOGN_, H = N / 2;
   static constexpr int SLABW = 128, PPW = SLABW / N;  // patches per slab
+#if defined(RPSF3_PPP32)
+  static constexpr int PPP = N == 32 ? RPSF3_PPP32 : N <= 32 ? PPW : 1;  // (development sweeps)
+#else
   static constexpr int PPP = N <= 32 ? PPW : 1;       // patches per exchange pass (N = 64: one, the buffer holds half a slab)
+#endif
   static constexpr int NSUB = PPW / PPP;
   static constexpr int WAVES = WAVES_, WG = 64 * WAVES_;
   // exchange sub-layouts (floats): X0[q][row < H][c < N] (gather -> rows, and columns -> rows on the way back as X2[q][k][r]),
@@ -155,16 +159,39 @@ RPSF_HD void t0_read(int lane, cf* v, const float* xb) {
   });
 }
 
-// first window (transform.py:151-155,163): rows by the lane's two row weights, columns by compile-time constants
+// first window (transform.py:151-155,163) and the forward row transform.  The rows' weights (the lane's two) are plain multiplications; the columns'
+// - compile-time constants - ride on the first butterflies of the decimation-in-time recursion, which pair element i with i + N/2 and have no twiddle:
+// (wa e + wb o, wa e - wb o) is one multiplication and two fused multiply-adds per component where "weigh, then add and subtract" takes four operations.
+template <int N, int LOG, int BASE, int STRIDE>
+struct FftRowsW {  // forward, natural order in and out, elements x[i] stand for original positions BASE + i STRIDE
+  static RPSF_HD void run(cf* x) {
+    constexpr int h = 1 << (LOG - 1);
+    if constexpr (LOG == 1) {
+      constexpr float wa = win3<N>(BASE), wb = win3<N>(BASE + STRIDE);
+      const cf e = x[0], o = x[1];
+      const float tx = wa * e.x, ty = wa * e.y;
+      x[0] = cf{__builtin_fmaf(wb, o.x, tx), __builtin_fmaf(wb, o.y, ty)};
+      x[1] = cf{__builtin_fmaf(-wb, o.x, tx), __builtin_fmaf(-wb, o.y, ty)};
+    } else {
+      cf ev[h], od[h];
+      StaticFor<0, h>::run([&]<int I>() RPSF_AI {
+        ev[I] = x[2 * I];
+        od[I] = x[2 * I + 1];
+      });
+      FftRowsW<N, LOG - 1, BASE, 2 * STRIDE>::run(ev);
+      FftRowsW<N, LOG - 1, BASE + STRIDE, 2 * STRIDE>::run(od);
+      StaticFor<0, h>::run([&]<int I>() RPSF_AI { butterfly_dit<I, LOG, false>(ev[I], od[I], x[I], x[I + h]); });
+    }
+  }
+};
 template <class C>
-RPSF_HD void window_in(cf* v, float w_re, float w_im) {
+RPSF_HD void window_in_fft_rows(cf* v, float w_re, float w_im) {
   StaticFor<0, C::N>::run([&]<int I>() RPSF_AI {
-    constexpr float wc = win3<C::N>(I);
-    v[I].x = (v[I].x * w_re) * wc;
-    v[I].y = (v[I].y * w_im) * wc;
+    v[I].x *= w_re;
+    v[I].y *= w_im;
   });
+  FftRowsW<C::N, C::LOGN, 0, 1>::run(v);
 }
-
 // row spectra of the two packed rows, in place: v[k] (k < H) = column k of row p (k = 0: D[p]); v[H + j] = column (j ? H - j : 0) of row p + H
 template <class C>
 RPSF_HD void unpack_rows(cf* v) {
@@ -273,14 +300,16 @@ RPSF_HD void t2_read(int lane, cf* v, const float* xb) {
 
 // ---- second window and overlap-add into the ring (transform.py:165-169) ---------------------------------------------------------
 enum Acc3 : int { ACC_SKIP = 0, ACC_STORE = 1, ACC_ADD = 2 };
-// second window, in place (transform.py:165); an invalid patch contributes exact zeros, whatever its pixels were
+// second window, in place (transform.py:165).  An invalid patch (a virtual column beside the lattice, an empty slot of a slab) gets row weights of zero: its
+// pixels are image pixels that a real patch of the same rows covers too, so where they are finite it contributes exact zeros and where they are not
+// the real patch has spread the NaN over the same pixels already (one select per job instead of one per value: 2 N fewer instructions).
 template <class C>
 RPSF_HD void window_out(cf* v, float w_re, float w_im, bool valid) {
+  const float wr = valid ? w_re : 0.0f, wi = valid ? w_im : 0.0f;
   StaticFor<0, C::N>::run([&]<int I>() RPSF_AI {
     constexpr float wc = win3<C::N>(I);
-    const float x = (v[I].x * w_re) * wc, y = (v[I].y * w_im) * wc;
-    v[I].x = valid ? x : 0.0f;
-    v[I].y = valid ? y : 0.0f;
+    v[I].x = (v[I].x * wr) * wc;
+    v[I].y = (v[I].y * wi) * wc;
   });
 }
 // upper: the lane's row p of the slab (real parts), lower: row p + H (imaginary parts); ru / rl: their ring rows at the patch's first column.

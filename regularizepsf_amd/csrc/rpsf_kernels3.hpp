@@ -93,12 +93,20 @@ __device__ __forceinline__ void sweep_body(const SweepParams& P) {
     const uint32_t jflags = (uint32_t)jds[3];
     const int jdep0 = jds[4], jdep1 = jds[5], jown0 = jds[6], jown1 = jds[7];
     const int row0 = P.lat_r0 + jrow, col0 = P.lat_c0 + jcol;
+#if defined(RPSF3_ABL_ONE_K)  // ablation (wrong results): every patch multiplies by the transfer kernel of slot q - K comes from the caches
+    const int kslot = q;
+#else
     const int kslot = jd->kslot[q];
+#endif
     // ---- gather ----
     f32x4 g[H];
     const bool fast = P.aligned_in && row0 >= im.row0 && row0 + N <= im.row0 + im.rows && row0 >= 0 && row0 + N <= im.H && col0 >= 0 &&
                       col0 + C::SLABW <= im.W;
+#if defined(RPSF3_ABL_ONE_SLAB)  // ablation (wrong results): every job reads the image's first slab - pixels come from the caches
+    const float* slab = im.img + (size_t)(wave * 2) * im.ld;
+#else
     const float* slab = im.img + (size_t)(row0 - im.row0) * im.ld + col0;
+#endif
     if constexpr (C::SPLIT_GATHER) {
       if (fast) g3_load_fast<C, 0, 1>(lane, g, slab, im.ld);
       else g3_load_generic<C, 0, 1>(lane, g, im, row0, col0);
@@ -147,8 +155,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& P) {
         lds_fence_wave();
       });
     }
-    window_in<C>(v, w_re, w_im);
-    FftSmall<C::LOGN, false>::run(v);
+    window_in_fft_rows<C>(v, w_re, w_im);
     unpack_rows<C>(v);
     // ---- columns ----
     StaticFor<0, C::NSUB>::run([&]<int S>() RPSF_AI {
@@ -164,12 +171,16 @@ __device__ __forceinline__ void sweep_body(const SweepParams& P) {
     if constexpr (C::KPRE_LATE) request_k();
     lds_st4(side + 4 * lane, kbw);
     lds_fence_wave();
+#if !defined(RPSF3_ABL_NO_COLUMN_FFTS)  // ablation (wrong results): the two column transforms left out - how much of a job is arithmetic?
     FftSmall<C::LOGN, false>::run(v);
+#endif
     {
       const bool col0lane = p == 0;
       kmul3<C, NT>(v, ka, kp + p * 4, col0lane ? side + 4 * (q * H) : side + C::SIDE_ZERO, col0lane ? 4 : 0);
     }
+#if !defined(RPSF3_ABL_NO_COLUMN_FFTS)
     FftSmall<C::LOGN, true>::run(v);
+#endif
     // ---- back to rows ----
     StaticFor<0, C::NSUB>::run([&]<int S>() RPSF_AI {
       t2_write<C, 0, S>(lane, v, xb);
@@ -213,7 +224,11 @@ __device__ __forceinline__ void sweep_body(const SweepParams& P) {
     // ---- phase B: the band(s) this slab has completed go to the output image ----
     // (read and stored unit by unit: a version that read the band into a register array first, released the flag and stored afterwards
     // gave wrong images on the GPU - and right ones in the emulator - in every form tried, profiles/r06i)
+#if defined(RPSF3_ABL_NO_FLUSH)  // ablation (wrong results): nothing is written to the output image
+    if (false) {
+#else
     if (jflags & (J3_FLUSH_UPPER | J3_FLUSH_LOWER)) {
+#endif
       lds_fence_wave();
       auto st4 = [](float* dst, f32x4 x) RPSF_AI { __builtin_nontemporal_store(x, reinterpret_cast<f32x4*>(dst)); };
       auto st1 = [](float* dst, float x) RPSF_AI { __builtin_nontemporal_store(x, dst); };

@@ -109,8 +109,7 @@ static int emu3_apply_t(int n_patches, const int32_t* coords, int Himg, int Wimg
         lanes([&](int l, f32x4*, cf* vl) { t0_read<C, 1, S>(l, vl, xb.data()); });
       });
       lanes([&](int l, f32x4*, cf* vl) {
-        window_in<C>(vl, win[l % H], win[l % H + H]);
-        FftSmall<C::LOGN, false>::run(vl);
+        window_in_fft_rows<C>(vl, win[l % H], win[l % H + H]);
         unpack_rows<C>(vl);
       });
       StaticFor<0, C::NSUB>::run([&]<int S>() {
