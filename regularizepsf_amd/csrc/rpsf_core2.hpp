@@ -833,6 +833,10 @@ RPSF_HD void store_patch2(int t, const cf* v, const OutView& pv, const OutView& 
         const cf a = v[2 * (R1 * NCOL + C1)], b = v[2 * (R1 * NCOL + C1) + 1];
         f32x4 val = {a.x * (w4.x * wr), a.y * (w4.y * wr), b.x * (w4.z * wr), b.y * (w4.w * wr)};
         if (!qw || quad_mode(qw[QD]) == QUAD_SIDE) {
+#if defined(RPSF2_SKEL_PRESUM)
+          if constexpr (C1 >= NCOL / 2) (void)val;  // (not stored - and not kept alive: the register file of these kernels has no room for it)
+          else
+#endif
           pstore4(prow_t + R1 * pstep + 4 * cp, val);
         } else if (quad_mode(qw[QD]) == QUAD_DIRECT) {
           val += old[U];
@@ -854,6 +858,9 @@ RPSF_HD void store_patch2(int t, const cf* v, const OutView& pv, const OutView& 
       const bool row_ok = y >= 0 && y < pv.H && yl >= 0 && yl < pv.rows;
       StaticFor<0, NCOL>::run([&]<int C1>() RPSF_AI {
         const int cp = (C1 << C::B2) + tp.c2, x = pc + 4 * cp;
+#if defined(RPSF2_SKEL_PRESUM)
+        if (C1 < NCOL / 2)
+#endif
         if (row_ok && x >= 0 && x + 4 <= pv.W) {
           const f32x4 w4 = *reinterpret_cast<const f32x4*>(win + 4 * cp);
           const cf a = v[2 * (R1 * NCOL + C1)], b = v[2 * (R1 * NCOL + C1) + 1];

@@ -98,7 +98,11 @@ __device__ __forceinline__ void sum_tile(const TileSum& p0, uint32_t entry_any_l
   if (p.done) p.done += (size_t)frame * p0.n_tiles;
   const int ti = tile / p.ntj, tj = tile % p.ntj;
   const int cov_all = p.cover[tile];
+#if defined(RPSF2_SKEL_PRESUM)  // (timing skeleton, rpsf_kernels2.hpp: only the planes of the patches whose LEFT half lies over this tile are read)
+  const int cov = cov_all & ((tj & 1) ? 10 : 5);
+#else
   const int cov = cov_all;
+#endif
   const bool fused = KNOWN_FUSED || p.done != nullptr;
   if (fused && !known_complete) {  // wait until every contributor of the tile has published its stores
     if (tid == 0) {
