@@ -211,8 +211,10 @@ __device__ __forceinline__ void sweep_body(const SweepParams& P) {
         }
         if (lane0 == 0) atomicOr(P.err, 1u);
       };
+#if !defined(RPSF3_ABL_NO_WAIT)  // ablation (races: wrong results): the adds are not ordered - what does the order cost?
       wait_for(d0);
       wait_for(d1);
+#endif
     }
     __builtin_amdgcn_s_setprio(3);  // (the adds of a job are what the jobs after it wait for: they go first in the SIMD's arbitration)
     const int hs = (jflags & J3_RING_HALF) ? 1 : 0;
