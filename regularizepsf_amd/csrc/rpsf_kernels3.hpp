@@ -60,9 +60,12 @@ __device__ __forceinline__ void sweep_body(const SweepParams& P) {
   const float w_re = P.win[lane0 % H], w_im = P.win[lane0 % H + H];
   const uint32_t flags_off = lds_u32_offset(flags), next_off = lds_u32_offset(next);
 #if defined(RPSF3_STAGGER_TICKS)
-  {  // development: the waves of a workgroup start RPSF3_STAGGER_TICKS x 10 ns apart
+  {  // development: the waves of a workgroup start RPSF3_STAGGER_TICKS x 10 ns apart, RPSF3_STAGGER_GROUP of them together (the jobs of one phase)
+#if !defined(RPSF3_STAGGER_GROUP)
+#define RPSF3_STAGGER_GROUP 1
+#endif
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)wave * RPSF3_STAGGER_TICKS) __builtin_amdgcn_s_sleep(8);
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)(wave / RPSF3_STAGGER_GROUP) * RPSF3_STAGGER_TICKS) __builtin_amdgcn_s_sleep(8);
   }
 #endif
   for (;;) {
