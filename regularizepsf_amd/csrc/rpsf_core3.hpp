@@ -79,11 +79,11 @@ struct Cfg3 {
   // N = 64: the slab is requested half by half (128 registers of pixels beside 128 of the transform do not fit a lane)
   static constexpr bool SPLIT_GATHER = N == 64;
   // a words (rpsf_kernels3.hpp: the transfer kernel of the lane's column) that a lane requests at the start of its job, half a job before it uses
-  // them; the rest is requested where it is used (the register file does not hold all of them beside the patch)
+  // them; the words behind them roll through the same registers (kmul3: a used word's register requests the word KPRE further on)
 #if defined(RPSF3_KPRE)
   static constexpr int KPRE = RPSF3_KPRE < H ? RPSF3_KPRE : H;
 #else
-  static constexpr int KPRE = N == 16 ? 8 : N == 32 ? 8 : 16;
+  static constexpr int KPRE = 8;  // (N = 64: 16 rolling words spill 17 registers, 0.198 -> 0.214 ms; 8 do not)
 #endif
   // N = 64: requested only once the pixels' registers are free (behind the first transposes), N <= 32: at the start of the job
   static constexpr bool KPRE_LATE = N == 64;
@@ -252,13 +252,28 @@ RPSF_HD void t1_read(int lane, cf* v, const float* xb) {
 // bytes of zeros (every other column, kb_stride = 0: b = 0, so that the rule of column 0 costs no branch).
 template <int N, int H>
 constexpr int k3_row(int j, int m) { return j == 0 ? (m ? H : 0) : (m ? N - j : j); }
+template <bool NT>
+RPSF_HD f32x4 load_k3(const float* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+#endif
+  return *reinterpret_cast<const f32x4*>(p);
+}
+// ka_pre: the first KPRE words, requested at the start of the job.  The words behind them ROLL through the same registers: as soon as word J has been
+// used its register requests word J + KPRE, so KPRE loads stay in flight and the lane waits for memory once, not once per word (a frame of a few
+// hundred patches has no other wave to hide a load's latency behind).  4096^2 / 32: -2.5 %, N = 64: -1 %, 512^2 frames: 0 (profiles/r06zl_sweep_rolling_k.log).
 template <class C, bool NT>
-RPSF_HD void kmul3(cf* v, const f32x4* ka_pre, const float* ka, const float* kb, int kb_stride) {
-  constexpr int N = C::N, H = C::H;
+RPSF_HD void kmul3(cf* v, f32x4* ka_pre, const float* ka, const float* kb, int kb_stride) {
+  constexpr int N = C::N, H = C::H, KP = C::KPRE;
   StaticFor<0, H>::run([&]<int J>() RPSF_AI {
     cf ae, ao, be, bo;
-    if constexpr (J < C::KPRE) ae = cf{ka_pre[J].x, ka_pre[J].y}, ao = cf{ka_pre[J].z, ka_pre[J].w};
-    else load_k16<NT>(ka + (size_t)J * (H * 4), ae, ao);
+    if constexpr (KP > 0) {
+      const f32x4 w = ka_pre[J % KP];
+      ae = cf{w.x, w.y}, ao = cf{w.z, w.w};
+      if constexpr (J + KP < H) ka_pre[J % KP] = load_k3<NT>(ka + (size_t)(J + KP) * (H * 4));
+    } else {
+      load_k16<NT>(ka + (size_t)J * (H * 4), ae, ao);
+    }
     load_k16<false>(kb + (size_t)J * kb_stride, be, bo);
     constexpr int RE = k3_row<N, H>(J, 0), RO = k3_row<N, H>(J, 1);
     const cf x = v[RE], y = v[RO];

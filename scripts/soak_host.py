@@ -21,13 +21,13 @@ rng = np.random.default_rng(a.seed)
 t_end = time.time() + a.seconds
 cases = checks = 0
 while time.time() < t_end:
-    n = int(rng.choice([32, 64, 128, 256]))
+    n = int(rng.choice([16, 32, 64, 128, 256]))
     h, w = (int(rng.integers(n, 9 * n)) for _ in range(2))
     if rng.random() < 0.5:
         w = (w + 31) // 32 * 32  # the fused / HOT geometries
     pad_mode = str(rng.choice(["symmetric", "reflect", "constant", "edge", "wrap"]))
     frames = int(rng.integers(1, 9))
-    bands, group, depth = int(rng.choice([0, 2, 3, 4, 8])), int(rng.integers(1, 5)), int(rng.integers(1, 5))
+    bands, group, depth = int(rng.choice([0, 2, 3, 4, 8, 16])), int(rng.integers(1, 5)), int(rng.integers(1, 5))
     coords = [tuple(int(v) for v in c) for c in rp.calculate_covering((h, w), n)]
     k = ((rng.standard_normal((len(coords), n, n)) + 1j * rng.standard_normal((len(coords), n, n))) * 0.2).astype(np.complex64)
     dt_in = rng.choice([np.float32, np.float64])
