@@ -155,7 +155,8 @@ def e2e_host_frames(plan, images, pad_mode, out_dtype=np.float64, reps=5, pinned
         out = _native.pinned_empty((frames, h, w), out_dtype, plan.device)
         out[...] = 0
     else:
-        out = np.zeros((frames, h, w), out_dtype)
+        out = np.empty((frames, h, w), out_dtype)
+        out.fill(0)  # (np.zeros maps its pages lazily: the first apply would take the page faults inside the clock)
     loop_ms = stream_ms = float("inf")
     for _ in range(reps):
         t0 = time.perf_counter()

@@ -86,7 +86,11 @@ struct Cfg3 {
   static constexpr int KPRE = 8;  // (N = 64: 16 rolling words spill 17 registers, 0.198 -> 0.214 ms; 8 do not)
 #endif
   // N = 64: requested only once the pixels' registers are free (behind the first transposes), N <= 32: at the start of the job
+#if defined(RPSF3_KPRE_EARLY)
+  static constexpr bool KPRE_LATE = false;  // (development sweeps)
+#else
   static constexpr bool KPRE_LATE = N == 64;
+#endif
   // per wave: the b words of the slab's column-0 lanes (one 16-byte word per lane, requested by all 64 lanes in one coalesced load) + 16 bytes of zeros
   static constexpr int SIDE_ZERO = 256, SIDEF = 260;
   static constexpr size_t LDS_BYTES = sizeof(float) * ((size_t)RINGF + (size_t)WAVES * (XF + SIDEF)) + sizeof(uint32_t) * (NFLAGS + 4);
