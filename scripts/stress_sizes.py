@@ -1,7 +1,7 @@
 """One-off robustness run: the persistent fused launch against the one-patch-per-workgroup launch and the separate sum kernel, bit
 for bit, over many frame sizes (whole and partial rounds, one to many rounds, square and not), repeated applies of each.
     python scripts/stress_sizes.py [repeats]"""
-import os, pathlib, sys
+import pathlib, sys
 import numpy as np
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
 from regularizepsf_amd import _native, calculate_covering
@@ -15,11 +15,10 @@ for (h, w) in ((512, 512), (768, 2048), (1024, 1280), (2048, 2048), (2304, 2304)
     k = (rng.standard_normal((len(coords), n, n), dtype=np.float32) + 1j * rng.standard_normal((len(coords), n, n), dtype=np.float32)).astype(np.complex64)
     img = (100 + 5 * rng.standard_normal((h, w), dtype=np.float32)).astype(np.float32)
     outs = {}
-    for mode, env in (("persistent", {}), ("one patch per workgroup", {"RPSF_NO_PERSIST": "1"}), ("separate sum", {"RPSF_NO_FUSE": "1"})):
-        os.environ.update(env)
+    for mode, options in (("persistent", {}), ("one patch per workgroup", {"persist": 0}), ("separate sum", {"fuse": 0})):
         plan = _native.Plan(n, coords)
-        for key in env:
-            del os.environ[key]
+        for name, value in options.items():  # (plan options since round 6: the shipped library reads no such environment variable)
+            plan.set_option(name, value)
         plan.set_transfer(k)
         first = plan.apply(img, 1)
         reps = repeats if mode == "persistent" else 3
