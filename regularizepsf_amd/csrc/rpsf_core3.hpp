@@ -76,6 +76,7 @@ struct Cfg3 {
   static_assert(RP % 4 == 0 && (RP / 4) % 2 == 1, "ring pitch");
   static constexpr int RINGF = N * RP;
   static constexpr int NFLAGS = 256;
+  static constexpr bool DESC_PREFETCH = N >= 32;  // (rpsf_kernels3.hpp: the job descriptor WAVES jobs ahead is touched early)
   // N = 64: the slab is requested half by half (128 registers of pixels beside 128 of the transform do not fit a lane)
   static constexpr bool SPLIT_GATHER = N == 64;
   // a words (rpsf_kernels3.hpp: the transfer kernel of the lane's column) that a lane requests at the start of its job, half a job before it uses

@@ -89,6 +89,17 @@ __device__ __forceinline__ void sweep_body(const SweepParams& P) {
     const int j = (int)__builtin_amdgcn_readfirstlane(drawn);
     if (j >= reg.njobs) break;
     const Job3* jd = P.jobs + reg.job0 + j;
+    // The descriptor this wave will most likely draw next (WAVES jobs on) is requested now and thrown away: a job's 64 bytes are read once per launch, so
+    // they come from HBM (0.8 us of a 14 us job, profiles/r06k) unless somebody has asked for the line before.  The eight scalar registers stay reserved
+    // until the wait for this job's own descriptor - which is a wait for every scalar load in flight - has passed (the statement behind it).
+    // 4096^2: N = 64 -1.5 %, N = 32 -0.5 %, N = 16 nothing (profiles/r06zo_sweep_descriptor_prefetch.log).
+    typedef int int8v __attribute__((ext_vector_type(8)));
+    int8v ahead = {};
+    if constexpr (C::DESC_PREFETCH) {
+      const int jn = j + C::WAVES < reg.njobs ? j + C::WAVES : reg.njobs - 1;
+      const Job3* jp = P.jobs + reg.job0 + jn;
+      asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=&s"(ahead) : "s"(jp) : "memory");
+    }
     // the descriptor through the scalar cache (a uniform address in the constant address space)
     typedef const int __attribute__((address_space(4))) cint_as4;
     const cint_as4* jds = (const cint_as4*)(const void*)jd;
@@ -96,6 +107,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& P) {
     const uint32_t jflags = (uint32_t)jds[3];
     const int jdep0 = jds[4], jdep1 = jds[5], jown0 = jds[6], jown1 = jds[7];
     const int row0 = P.lat_r0 + jrow, col0 = P.lat_c0 + jcol;
+    if constexpr (C::DESC_PREFETCH) asm volatile("s_waitcnt lgkmcnt(0)" : : "s"(ahead), "s"(row0), "s"(col0) : "memory");
 #if defined(RPSF3_ABL_ONE_K)  // ablation (wrong results): every patch multiplies by the transfer kernel of slot q - K comes from the caches
     const int kslot = q;
 #else
