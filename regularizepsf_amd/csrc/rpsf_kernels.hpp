@@ -567,6 +567,17 @@ __device__ __forceinline__ R np_pow(R x, R e) {
   if (e == R(2)) return x * x;
   if (e == R(0.5)) return sqrt(x);
   if (e == R(-1)) return R(1) / x;
+  // Small integer exponents (the reference's alpha = 3 asks for x^4: transform.py:78-82 with NumPy's float32 power loop, i.e. glibc's powf, which is
+  // correctly rounded in nearly all cases).  In float32 the product is formed in float64 - x^2 is exact there, every further factor rounds at 53 bits - and
+  // rounded once to float32: the correctly rounded power up to double rounding, for two or three multiplications instead of a pow() of 100+ instructions.
+  // Measured against the reference's own K (tests/golden/construct.npz, scripts/construct_bits.py): see profiles/r06zr_construct_pow.log.
+  if constexpr (sizeof(R) == 4) {
+    if (e == R(3) || e == R(4) || e == R(5) || e == R(6) || e == R(8)) {
+      const double d = (double)x, d2 = d * d;
+      const double r = e == R(3) ? d2 * d : e == R(4) ? d2 * d2 : e == R(5) ? d2 * d2 * d : e == R(6) ? d2 * d2 * d2 : (d2 * d2) * (d2 * d2);
+      return (R)r;
+    }
+  }
   return pow(x, e);
 }
 
