@@ -29,6 +29,9 @@ ap.add_argument("--pipeline", action="store_true", help="exchange mode: the send
 ap.add_argument("--worlds", default="1,2,4,8")
 ap.add_argument("--seam", choices=["exchange", "recompute"], default="exchange")
 ap.add_argument("--ranks", default="", help="development sweeps: only these ranks of every world (comma-separated; default all)")
+ap.add_argument("--link-us", type=float, default=0.0,
+                help="model the link: the stand-in's send + receive of the seam rows together take about this long (narrow kernels on as few workgroups as it "
+                     "takes; 27 = 4 MiB over one xGMI link at 153 GB/s).  0: a plain device-to-device copy (3 us)")
 args = ap.parse_args()
 
 hip = ctypes.CDLL("libamdhip64.so")
@@ -45,14 +48,35 @@ class LocalLink:
         self.stream = self._plan.stream
 
     narrow = False  # --pipeline: the stand-in moves the rows with narrow grid-stride kernels, as RCCL's few send / recv channels do
+    workgroups = 64  # of those kernels (--link-us: calibrated below so that send + receive take the link's time)
+
+    def calibrate(self, floats, target_us):
+        """Fewest-workgroup setting whose send + receive of `floats` take at least `target_us` (measured here, on an idle GPU)."""
+        src = _native.DeviceBuffer(floats * 4)
+        best = None
+        for g in (64, 48, 32, 24, 16, 12, 8, 6, 4, 3, 2, 1):
+            self.workgroups = g
+            for _ in range(3):
+                self.seam_exchange(src.ptr, floats, src.ptr, floats)
+            self._plan.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                self.seam_exchange(src.ptr, floats, src.ptr, floats)
+            self._plan.synchronize()
+            us = 1e6 * (time.perf_counter() - t0) / 20
+            best = (g, us)
+            if us >= target_us:
+                break
+        self.workgroups = best[0]
+        return best
 
     def seam_exchange(self, send_ptr, send_count, recv_ptr, recv_count, stream=None):
         st = stream if stream is not None else self.stream
         if self.narrow:  # (adds instead of copies: the same bytes through the same few CUs)
             if send_count:
-                _native.add_rows(self.scratch.ptr, send_ptr, send_count, 0, st, max_workgroups=64)
+                _native.add_rows(self.scratch.ptr, send_ptr, send_count, 0, st, max_workgroups=self.workgroups)
             if recv_count:
-                _native.add_rows(recv_ptr, self.scratch.ptr, recv_count, 0, st, max_workgroups=64)
+                _native.add_rows(recv_ptr, self.scratch.ptr, recv_count, 0, st, max_workgroups=self.workgroups)
             return
         if send_count:
             assert hip.hipMemcpyAsync(self.scratch.ptr, send_ptr, send_count * 4, 3, st) == 0
@@ -71,7 +95,10 @@ coords = [tuple(int(v) for v in t) for t in calculate_covering((h, w), n)]
 kk = (rng.standard_normal((585, n, n), dtype=np.float32) + 1j * rng.standard_normal((585, n, n), dtype=np.float32)).astype(np.complex64)
 image = rng.standard_normal((h, w), dtype=np.float32)
 link = LocalLink(128 * w)
-link.narrow = args.pipeline
+link.narrow = args.pipeline or args.link_us > 0
+if args.link_us > 0:
+    g, us = link.calibrate(128 * w, args.link_us)
+    print(json.dumps({"link_model": f"send + receive of {128 * w * 4 >> 20} MiB by narrow kernels on {g} workgroups: {us:.1f} us per exchange on an idle GPU (asked: {args.link_us})"}), flush=True)
 base = None
 for world in [int(v) for v in args.worlds.split(",")]:
     times = []
