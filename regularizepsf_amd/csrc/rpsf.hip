@@ -1933,6 +1933,7 @@ static int host_one_frame_banded(rpsf_plan* p, const void* image, int in_f64, vo
     }
   };
   hipError_t err = hipSuccess;
+  const bool inline_mode = pool.width() < 2;  // (HostPool::run with one part runs `meanwhile` BEFORE the part: the conductor would wait for staging that has not begun)
   std::vector<Range> landed;  // D2H pieces in the order they were enqueued; event c is q.ev_chunk[c]
   double t_enqueued = 0.0, t_first_out = 0.0, t_last_out = 0.0;
   auto conductor = [&] {
@@ -1979,7 +1980,9 @@ static int host_one_frame_banded(rpsf_plan* p, const void* image, int in_f64, vo
         const hipError_t qe = c < chunks.size() ? hipEventQuery(q.ev_chunk[published]) : hipEventSynchronize(q.ev_chunk[published]);
         if (qe == hipSuccess) {
           if (published == 0) t_first_out = ms_since(t_start);
-          if (!direct_out) {
+          if (!direct_out && inline_mode) {  // (no workers: this thread widens the piece itself)
+            rpsf_host::widen_or_copy(out, out_f64 != 0, q.h_out[0], landed[published].lo, landed[published].hi);
+          } else if (!direct_out) {
             for (size_t a = landed[published].lo; a < landed[published].hi; a += PIECE) out_pieces[n_avail++] = {a, std::min(landed[published].hi, a + PIECE)};
             out_avail.store(n_avail, std::memory_order_release);
           }
@@ -1994,7 +1997,13 @@ static int host_one_frame_banded(rpsf_plan* p, const void* image, int in_f64, vo
     closed.store(1, std::memory_order_release);
   };
   if (direct_in && direct_out) conductor();  // nothing for the pool: the copy engines read and write the caller's pages
-  else {
+  else if (inline_mode) {  // RPSF_HOST_THREADS=1: no workers - stage everything, then conduct and widen on this thread (no overlap of the host's own steps)
+    for (size_t i = 0; i < n_in; ++i) {
+      rpsf_host::narrow_or_copy(q.h_in[0], image, in_f64 != 0, in_pieces[i].lo, in_pieces[i].hi);
+      chunk_done[piece_chunk[i]].fetch_add(1, std::memory_order_release);
+    }
+    conductor();
+  } else {
     // every second worker (one per CCD at the default width): sixteen threads streaming beside the copy engines slow the copies down more than they
     // gain (H2D busy 1.78 ms of a 67 MB frame with 16 workers, 1.48 with 8, 1.28 with 4 - which then cannot keep up: profiles/r06x_host_frame_matrix.log)
     const int every = frame_every > 0 ? frame_every : (pool.width() >= 16 ? 2 : 1);

@@ -2,6 +2,7 @@
 streams and the persistent worker pool - bit-identical to the frame-by-frame loop a user of the reference writes
 (`[transform.apply(image) for image in images]`, regularizepsf/transform.py:85-177), and against the oracle."""
 
+import pathlib
 import threading
 
 import numpy as np
@@ -10,6 +11,8 @@ import pytest
 import regularizepsf_amd as rp
 from oracle import regpsf_oracle as orc
 from regularizepsf_amd import _native
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
 
 pytestmark = pytest.mark.gpu
 
@@ -192,6 +195,43 @@ def test_a_large_frame_cut_into_row_bands_is_bit_identical_to_the_whole_frame(n,
     small = np.ascontiguousarray(image[: shape[0] - n // 2, : shape[1] - n // 2])
     check(t.apply(small, pad_mode=pad_mode), orc.apply_transfer(small, coords, k, pad_mode=pad_mode, workers=-1))
     assert np.array_equal(t.apply(image, pad_mode=pad_mode), whole)
+
+
+@pytest.mark.parametrize("threads", ["1", "2", "5"])
+def test_a_banded_frame_with_a_narrow_host_pool(threads):
+    """RPSF_HOST_THREADS = 1 leaves the host pool without workers: the calling thread stages, conducts and widens by itself (a pool job of one part runs its
+    `meanwhile` hook BEFORE the part - the conductor of a banded frame would wait for staging that has not begun); two and five threads take the pool's path
+    with an odd number of parts.  The pool is created once per process, so each width runs in a process of its own."""
+    import os
+    import subprocess
+    import sys
+
+    code = """
+import numpy as np, regularizepsf_amd as rp
+rng = np.random.default_rng(3)
+n, shape = 64, (1500, 1300)
+coords = [tuple(int(v) for v in c) for c in rp.calculate_covering(shape, n)]
+k = ((rng.standard_normal((len(coords), n, n)) + 1j * rng.standard_normal((len(coords), n, n))) * 0.2).astype(np.complex64)
+image = (rng.standard_normal(shape) * 10 + 100).astype(np.float32)
+t = rp.ArrayPSFTransform(rp.IndexedCube(coords, k))
+t._device_plan().set_option("host_bands", 0)
+whole = t.apply(image)
+for bands in (2, 5, 8):
+    t._device_plan().set_option("host_bands", bands)
+    assert np.array_equal(t.apply(image), whole), bands
+    assert np.array_equal(t.apply(image.astype(np.float64)), whole), bands
+    assert t._device_plan().host_bands() == bands
+pin, pout = rp.pinned_empty(shape, np.float32), rp.pinned_empty(shape, np.float32)
+pin[...] = image
+from regularizepsf_amd import _native
+t._device_plan().apply_host(pin, _native.PAD_MODES["symmetric"], out=pout)
+assert np.array_equal(pout, whole.astype(np.float32))
+print("ok", _native.host_threads())
+"""
+    env = dict(os.environ, RPSF_HOST_THREADS=threads)
+    done = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=str(ROOT))
+    assert done.returncode == 0, done.stderr[-2000:]
+    assert done.stdout.strip().endswith(f"ok {threads}"), done.stdout
 
 
 def test_long_sequences_of_large_frames_go_two_by_two_in_the_middle():
