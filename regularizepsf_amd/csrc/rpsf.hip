@@ -210,6 +210,9 @@ struct rpsf_plan {
   long slabs3 = 0, patch_slots3 = 0;
   float* d_k3 = nullptr;      // n_patches x Cfg3::K_FLOATS (a view shares its parent's)
   float* d_zero3 = nullptr;   // 16 bytes of zeros
+  uint32_t* h_err3 = nullptr;  // page-locked word the sweep kernel sets when a job waited for its predecessors beyond the bound (a view uses its parent's)
+  uint32_t* d_err3 = nullptr;  // ... as the device sees it
+  bool owns_err3 = false;
   unsigned long long* d_stamps3 = nullptr;  // development builds (-DRPSF3_STAMPS)
   size_t k3_floats = 0;
   float* d_planes = nullptr;
@@ -250,6 +253,16 @@ static int build_sweep_lists(rpsf_plan* p, int target_regions) {
   if (!p->d_zero3) {
     HIP_TRY(hipMalloc(&p->d_zero3, 64));
     HIP_TRY(hipMemset(p->d_zero3, 0, 64));
+  }
+  if (!p->h_err3) {
+    if (p->parent && p->parent->h_err3) {
+      p->h_err3 = p->parent->h_err3, p->d_err3 = p->parent->d_err3;
+    } else {
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->h_err3), 64, hipHostMallocMapped));
+      std::memset(p->h_err3, 0, 64);
+      HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&p->d_err3), p->h_err3, 0));
+      p->owns_err3 = true;
+    }
   }
   p->n_regions3 = (int)plan.regions.size(), p->ks3 = plan.ks, p->slabs3 = plan.slabs, p->patch_slots3 = plan.patch_slots;
   p->sweep_ok = true;
@@ -865,6 +878,7 @@ extern "C" void rpsf_plan_destroy(rpsf_plan* p) {
   (void)hipFree(p->d_jobs3);
   (void)hipFree(p->d_regions3);
   (void)hipFree(p->d_zero3);
+  if (p->owns_err3) (void)hipHostFree(p->h_err3);
   (void)hipFree(p->d_stamps3);
   if (!p->parent) (void)hipFree(p->d_k3);
   (void)hipFree(p->d_cover);
@@ -1350,7 +1364,7 @@ static int launch_sweep(rpsf_plan* p, const float* d_img, float* d_out, const rp
   sp.fl = Flush3{d_out, g.ld_out, g.out_row0, g.out_rows, g.height, g.width, aligned_out};
   sp.lat_r0 = (int)r0, sp.lat_c0 = (int)c0;
   sp.jobs = p->d_jobs3, sp.regions = p->d_regions3, sp.n_regions = p->n_regions3, sp.group = (p->n_regions3 + 7) / 8;
-  sp.k3 = p->d_k3, sp.win = p->d_win, sp.zeros = p->d_zero3, sp.err = reinterpret_cast<uint32_t*>(p->d_zero3 + 8), sp.stamps = p->d_stamps3;
+  sp.k3 = p->d_k3, sp.win = p->d_win, sp.zeros = p->d_zero3, sp.err = p->d_err3, sp.stamps = p->d_stamps3;
   sp.im_frame_floats = b.im_stride, sp.out_frame_floats = b.out_stride;
   // K by plain loads when frames share it or it is small enough to stay in the Infinity Cache from one apply to the next, else streamed
   const bool k_plain = b.frames > 1 || p->k3_floats * sizeof(float) <= ((size_t)96 << 20);
@@ -1801,6 +1815,14 @@ static bool all_pinned(const void* const* ptrs, int n) {
   return true;
 }
 
+// The sweep kernel bounds every wait of a job for its predecessors (a protocol error must not hang the GPU) and reports a wait that ran out through a
+// page-locked word; every entry point that has just waited for the plan's work looks at it, so such an apply fails instead of returning a wrong image.
+static int sweep_check(rpsf_plan* p) {
+  if (!p->h_err3 || *reinterpret_cast<volatile uint32_t*>(p->h_err3) == 0) return RPSF_OK;
+  *reinterpret_cast<volatile uint32_t*>(p->h_err3) = 0;
+  return fail(RPSF_E_HIP, "sweep kernel: a job waited for the jobs it follows beyond the bound (internal protocol error; the output of this apply is not valid)");
+}
+
 static int drain_after_error(rpsf_plan* p, hipError_t err, const char* where) {
   (void)hipStreamSynchronize(p->pipe->st_in);
   (void)hipStreamSynchronize(p->stream);
@@ -2013,7 +2035,7 @@ static int host_one_frame_banded(rpsf_plan* p, const void* image, int in_f64, vo
     std::fprintf(stderr, "[rpsf host frame] %zu chunks, %d bands, %zu + %zu pieces: last chunk enqueued %.3f ms, first piece back %.3f, last %.3f, total %.3f ms\\n",
                  chunks.size(), B, n_in, (size_t)out_avail.load(), t_enqueued, t_first_out, t_last_out, ms_since(t_start));
   if (err != hipSuccess) return drain_after_error(p, err, "host frame");
-  return RPSF_OK;
+  return sweep_check(p);
 }
 
 // One frame.  The conversions run chunk by chunk (>= 4 MiB) on the pool, each chunk's H2D copy starts as soon as it is staged,
@@ -2116,7 +2138,7 @@ static int host_one_frame(rpsf_plan* p, const void* image, int in_f64, void* out
                  "out: waits %.3f + conversions %.3f, total %.3f ms\n", n_chunks, T, B, t_enqueued, t_conv_in, t_in_done, t_kernel_done, t_wait_out,
                  t_conv_out, ms_since(t_start));
   if (err != hipSuccess) return drain_after_error(p, err, "host frame");
-  return RPSF_OK;
+  return sweep_check(p);
 }
 
 // Frames per group of the streamed pipeline: small frames go through the shared-K batch launch a few at a time (the packed K is
@@ -2255,7 +2277,7 @@ static int host_frames(rpsf_plan* p, const void* const* images, int in_f64, void
     std::fprintf(stderr, "[rpsf streamed] %d frames in %d groups of up to %d, depth %d, %d parts per job: staging jobs %.3f ms, enqueues %.3f ms, waits %.3f ms, total %.3f ms\n",
                  n_frames, n_groups, G, depth, T, t_jobs, t_enqueue, t_wait, ms_since(t_start));
   if (err != hipSuccess) return drain_after_error(p, err, "streamed frames");
-  return RPSF_OK;
+  return sweep_check(p);
 }
 
 static int check_host_call(rpsf_plan* p, const void* a, const void* b, int n_frames, int height, int width, int pad_mode, float pad_value,
@@ -2527,7 +2549,7 @@ extern "C" int rpsf_apply_host_saturated(rpsf_plan* p, const void* image_host, i
   hipError_t err = run.enqueue(0);
   if (err == hipSuccess) err = run.finish(0, out_host);
   if (err != hipSuccess) return drain_after_error(p, err, "saturated host frame");
-  return RPSF_OK;
+  return sweep_check(p);
 }
 
 extern "C" int rpsf_apply_frames_host_saturated(rpsf_plan* p, const void* const* images_host, int image_is_f64, int n_frames, int height, int width,
@@ -2549,7 +2571,7 @@ extern "C" int rpsf_apply_frames_host_saturated(rpsf_plan* p, const void* const*
   }
   if (err == hipSuccess) err = run.finish((n_frames - 1) & 1, outs_host[n_frames - 1]);
   if (err != hipSuccess) return drain_after_error(p, err, "saturated host frames");
-  return RPSF_OK;
+  return sweep_check(p);
 }
 
 // Self-test of the host worker pool (no GPU involved: the CPU test suite calls it): `jobs` jobs of `parts` parts from each of `callers` threads at
@@ -2665,7 +2687,7 @@ extern "C" int rpsf_apply_device_loop_ms(rpsf_plan* p, const void* image_dev, vo
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, p->ev[0], p->ev[3]));
   *ms_per_apply = (double)ms / iters;
-  return RPSF_OK;
+  return sweep_check(p);
 }
 
 // ------------------------------------------------------------------------------------------------

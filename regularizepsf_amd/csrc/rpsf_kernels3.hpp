@@ -224,13 +224,16 @@ __device__ __forceinline__ void sweep_body(const SweepParams& P) {
           if (__builtin_amdgcn_readfirstlane(seen) >= want) return;
           __builtin_amdgcn_s_sleep(1);
         }
-        if (lane0 == 0) atomicOr(P.err, 1u);
+        if (lane0 == 0) __hip_atomic_store(P.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (a word in page-locked host memory: rpsf.hip sweep_check)
       };
 #if !defined(RPSF3_ABL_NO_WAIT)  // ablation (races: wrong results): the adds are not ordered - what does the order cost?
       wait_for(d0);
       wait_for(d1);
 #endif
     }
+#if defined(RPSF3_ABL_FORCE_ERR)  // development: exercise the report path of a wait that ran out (scripts/sweep_force_error.py)
+    if (lane0 == 0 && j == 0 && region == 0) __hip_atomic_store(P.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
     __builtin_amdgcn_s_setprio(3);  // (the adds of a job are what the jobs after it wait for: they go first in the SIMD's arbitration)
     const int hs = (jflags & J3_RING_HALF) ? 1 : 0;
     {
