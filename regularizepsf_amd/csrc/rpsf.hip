@@ -2092,18 +2092,34 @@ static int host_one_frame(rpsf_plan* p, const void* image, int in_f64, void* out
     if (err == hipSuccess) err = hipEventRecord(q.ev_in[0], s_in);
     if (err == hipSuccess) err = hipStreamWaitEvent(p->stream, q.ev_in[0], 0);
   }
-  if (err == hipSuccess && launch_apply(p, q.d_in[0], q.d_out[0], g, p->stream, nullptr) != RPSF_OK) err = hipErrorUnknown;
+  // A small frame through the sweep kernel: the kernel's one store per output pixel goes straight to the page-locked result rows (the staging buffer, or
+  // the caller's own page-locked array) - no download behind the launch, whose start-up and 1 MiB are a fifth of such a frame's time (512^2 / 64:
+  // 0.140 -> see profiles/r06zu_small_frame_zero_copy_out.log).  Only where every pixel of the window is written by the launch (the lattice covers it).
+  float* zc_out = nullptr;
+  if (one_stream && err == hipSuccess && overlap_kind(p) == OV_SWEEP && p->sweep_ok && !dev_env("RPSF_NO_ZC_OUT")) {
+    const int half = p->N / 2;
+    const long r0 = (long)p->lat_r0 + g.origin_row, c0 = (long)p->lat_c0 + g.origin_col;
+    const bool covered = r0 <= g.out_row0 && r0 + (long)p->nti * half >= (long)g.out_row0 + g.out_rows && c0 <= 0 && c0 + (long)p->ntj * half >= g.width;
+    void* dev = nullptr;
+    if (covered && hipHostGetDevicePointer(&dev, direct_out ? out : static_cast<void*>(q.h_out[0]), 0) == hipSuccess) zc_out = static_cast<float*>(dev);
+    else (void)hipGetLastError();
+  }
+  if (err == hipSuccess && launch_apply(p, q.d_in[0], zc_out ? zc_out : q.d_out[0], g, p->stream, nullptr) != RPSF_OK) err = hipErrorUnknown;
+  if (zc_out && err == hipSuccess) {
+    err = hipEventRecord(q.ev_chunk[0], p->stream);
+    out_chunks.push_back({0, count});
+  }
   if (!one_stream || trace) {
     if (err == hipSuccess) err = hipEventRecord(q.ev_k[0], p->stream);
     if (err == hipSuccess && !one_stream) err = hipStreamWaitEvent(s_out, q.ev_k[0], 0);
     if (err == hipSuccess && one_stream) err = hipEventRecord(q.ev_in[0], p->stream);  // (trace only)
   }
-  if (direct_out && err == hipSuccess) {
+  if (direct_out && !zc_out && err == hipSuccess) {
     err = hipMemcpyAsync(out, q.d_out[0], bytes, hipMemcpyDeviceToHost, s_out);
     if (err == hipSuccess) err = hipEventRecord(q.ev_chunk[0], s_out);
     out_chunks.push_back({0, count});
   }
-  for (int c = 0; c < n_chunks && err == hipSuccess && !direct_out; ++c) {
+  for (int c = 0; c < n_chunks && err == hipSuccess && !direct_out && !zc_out; ++c) {
     size_t lo, hi;
     chunk_range(c, lo, hi);
     if (hi > lo) err = hipMemcpyAsync(q.h_out[0] + lo, q.d_out[0] + lo, (hi - lo) * sizeof(float), hipMemcpyDeviceToHost, s_out);

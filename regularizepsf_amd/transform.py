@@ -39,14 +39,19 @@ def _kernel_stamp(cube: IndexedCube) -> tuple:
         return ("deferred", id(cube), cube._edits)
     values = cube.values
     if values.ndim == 3 and values.flags.c_contiguous and values.itemsize in (8, 16) and values.size:
-        per = values.shape[1] * values.shape[2]
         words = values.reshape(-1).view(np.uint64)  # 1 (complex64) or 2 (complex128) words per element
-        wpp = per * (values.itemsize // 8)
-        patches = np.arange(0, values.shape[0], max(1, values.shape[0] // 4096), dtype=np.int64)
-        line = min(8, wpp)
-        offset = (patches * 104729) % max(1, wpp - line + 1)
-        index = (patches * wpp + offset)[:, None] + np.arange(line, dtype=np.int64)[None, :]
-        sample = words[index.reshape(-1)]
+        key = (values.shape, values.itemsize)
+        cached = getattr(cube, "_stamp_index", None)
+        if cached is None or cached[0] != key:  # (the sample's positions depend on the shape only: built once per cube, 10 us of every apply otherwise)
+            wpp = values.shape[1] * values.shape[2] * (values.itemsize // 8)
+            patches = np.arange(0, values.shape[0], max(1, values.shape[0] // 4096), dtype=np.int64)
+            line = min(8, wpp)
+            offset = (patches * 104729) % max(1, wpp - line + 1)
+            cached = (key, ((patches * wpp + offset)[:, None] + np.arange(line, dtype=np.int64)[None, :]).reshape(-1))
+            cube._stamp_index = cached
+        sample = words[cached[1]]
+        # (two wrap-around reductions of the sampled words instead of a cryptographic digest of their bytes: any change of one word changes both)
+        return (id(values), cube._edits, values.shape, values.dtype.str, int(np.bitwise_xor.reduce(sample)), int(np.add.reduce(sample)))
     elif values.flags.c_contiguous or values.flags.f_contiguous:
         flat = values.reshape(-1, order="A")
         sample = flat[:: max(1, flat.size // 4096)]
@@ -259,19 +264,30 @@ class ArrayPSFTransform:
     # ------------------------------------------------------------------ apply (transform.py:85-177)
     def apply(self, image: np.ndarray, workers: int | None = None, pad_mode: str = "symmetric",
               saturation_threshold: float = math.inf, saturation_dilation: int = 1,
-              neighborhood_width: int = 7) -> np.ndarray:
+              neighborhood_width: int = 7, *, out: np.ndarray | None = None) -> np.ndarray:
         """Apply the transform to an image and return the corrected image (float64, same shape).
 
         Parameters follow the reference: ``pad_mode`` is any ``np.pad`` mode; pixels brighter than
         ``saturation_threshold`` are replaced by their neighbourhood mean before correction and
         restored afterwards.  ``workers`` is accepted for compatibility and ignored (the FFTs run
         on the GPU).  The input is never modified.
+
+        ``out`` (keyword only, not in the reference): a C-contiguous float64 or float32 array of the image's shape to write the result
+        into and return - a caller's loop that reuses one result array spares every call the first touch of two megabytes of fresh pages
+        per 512 x 512 frame, which costs anything between 10 and 200 us on a busy host (`scripts/notebook_factors.py`).
         """
         del workers
         with self._lock:
-            return self._apply_locked(image, pad_mode, saturation_threshold, saturation_dilation, neighborhood_width)
+            result = self._apply_locked(image, pad_mode, saturation_threshold, saturation_dilation, neighborhood_width, out)
+        if out is not None and result is not out:  # (the branches that build their result on the host)
+            if out.shape != result.shape:
+                msg = "out must have the image's shape"
+                raise ValueError(msg)
+            out[...] = result
+            return out
+        return result
 
-    def _apply_locked(self, image, pad_mode, saturation_threshold, saturation_dilation, neighborhood_width) -> np.ndarray:
+    def _apply_locked(self, image, pad_mode, saturation_threshold, saturation_dilation, neighborhood_width, out=None) -> np.ndarray:
         image = np.asarray(image)
         if image.ndim != 2:
             msg = f"image must be two dimensional, got shape {image.shape}"
@@ -285,7 +301,7 @@ class ArrayPSFTransform:
         self._check_corners(n, height, width)
 
         if saturation_threshold == math.inf and pad_mode in _native.PAD_MODES:  # nothing can exceed +inf
-            return plan.apply_host(image, _native.PAD_MODES[pad_mode])  # float64 out; conversions inside the library
+            return plan.apply_host(image, _native.PAD_MODES[pad_mode], out=out)  # float64 out (or the caller's array); conversions inside the library
 
         if (pad_mode in _native.PAD_MODES and isinstance(saturation_dilation, numbers.Integral) and saturation_dilation >= 1
                 and isinstance(neighborhood_width, numbers.Integral) and neighborhood_width >= 0):

@@ -597,6 +597,33 @@ def test_the_fallback_adds_in_a_fixed_order_on_a_covering(n, shape):
     check(other.apply(image, pad).astype(np.float64), orc.apply_transfer(image, moved, k))
 
 
+def test_apply_into_a_callers_array():
+    """`apply(..., out=)` (keyword only; not in the reference): the result lands in the caller's array - float64 or float32 - on the library's default
+    path (a small frame through the sweep kernel: the kernel's stores go straight to the page-locked result rows), through the saturation branch and
+    through a host-padded mode; the array comes back, and a wrong shape is refused."""
+    n, shape = 32, (200, 264)
+    rng = np.random.default_rng(11)
+    coords = [tuple(int(v) for v in c) for c in rp.calculate_covering(shape, n)]
+    k = (rng.standard_normal((len(coords), n, n)) + 1j * rng.standard_normal((len(coords), n, n))).astype(np.complex64)
+    image = rng.standard_normal(shape) * 10 + 100
+    t = rp.ArrayPSFTransform(rp.IndexedCube(coords, k))
+    plain = t.apply(image)
+    check(plain, orc.apply_transfer(image, coords, k))
+    for dt in (np.float64, np.float32):
+        out = np.full(shape, np.nan, dt)
+        assert t.apply(image, out=out) is out
+        assert np.array_equal(out, plain.astype(dt))
+    hot = image.copy()
+    hot[50, 60] = 1e6
+    out = np.empty(shape)
+    assert t.apply(hot, saturation_threshold=5e5, out=out) is out
+    assert np.array_equal(out, t.apply(hot, saturation_threshold=5e5))
+    assert t.apply(image, pad_mode="linear_ramp", out=out) is out
+    assert np.array_equal(out, t.apply(image, pad_mode="linear_ramp"))
+    with pytest.raises(ValueError):
+        t.apply(image, out=np.empty((shape[0], shape[1] + 1)))
+
+
 def test_integration_stub_call_sequence():
     """The reference-side binding shown in INTEGRATION.md, call for call (raw ctypes, no helper layer)."""
     import ctypes
