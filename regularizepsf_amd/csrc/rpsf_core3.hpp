@@ -338,22 +338,52 @@ RPSF_HD void window_out(cf* v, float w_re, float w_im, bool valid) {
 // CU busy for 9,750 of a job's 12,600 clocks, profiles/r06c.)
 template <class C>
 RPSF_HD void accumulate3(const cf* v, float* ru, float* rl, int mode_u, int mode_l) {
-  auto half = [&](auto re_part, float* r, int mode) RPSF_AI {
-    if (mode == ACC_SKIP) return;
-    StaticFor<0, C::N / 4>::run([&]<int J>() RPSF_AI {
-      constexpr bool RE = decltype(re_part)::value;
-      const float x0 = RE ? v[4 * J].x : v[4 * J].y, x1 = RE ? v[4 * J + 1].x : v[4 * J + 1].y;
-      const float x2 = RE ? v[4 * J + 2].x : v[4 * J + 2].y, x3 = RE ? v[4 * J + 3].x : v[4 * J + 3].y;
-      f32x4 t = f32x4{x0, x1, x2, x3};
-      if (mode == ACC_ADD) {
-        const f32x4 o = lds_ld4(r + 4 * J);
-        t = f32x4{o.x + t.x, o.y + t.y, o.z + t.z, o.w + t.w};
-      }
-      lds_st4(r + 4 * J, t);
-    });
+  // The mode is decided ONCE per band, outside the loops: inside them it was a branch per 16-byte unit, which kept the reads from being issued back to back -
+  // every unit paid an LDS round trip of its own (1.9 us per job at N = 32, inside the section the jobs behind this one wait for; profiles/r06zw).  BATCH units
+  // are read together, added and written back (N = 64 has no registers for more than eight at a time).
+  constexpr int UNITS = C::N / 4, BATCH = UNITS < 8 ? UNITS : 8;
+  auto unit = [&]<bool RE, int J>() RPSF_AI {
+    const float x0 = RE ? v[4 * J].x : v[4 * J].y, x1 = RE ? v[4 * J + 1].x : v[4 * J + 1].y;
+    const float x2 = RE ? v[4 * J + 2].x : v[4 * J + 2].y, x3 = RE ? v[4 * J + 3].x : v[4 * J + 3].y;
+    return f32x4{x0, x1, x2, x3};
   };
-  half(std::true_type(), ru, mode_u);
-  half(std::false_type(), rl, mode_l);
+  if constexpr (UNITS <= 8) {
+    // N <= 32: both bands' reads in flight together - one round trip for the whole job
+    f32x4 ou[UNITS], ol[UNITS];
+    if (mode_u == ACC_ADD) StaticFor<0, UNITS>::run([&]<int J>() RPSF_AI { ou[J] = lds_ld4(ru + 4 * J); });
+    if (mode_l == ACC_ADD) StaticFor<0, UNITS>::run([&]<int J>() RPSF_AI { ol[J] = lds_ld4(rl + 4 * J); });
+    auto finish = [&](auto re_part, float* r, int mode, const f32x4* o) RPSF_AI {
+      constexpr bool RE = decltype(re_part)::value;
+      if (mode == ACC_ADD) {
+        StaticFor<0, UNITS>::run([&]<int J>() RPSF_AI {
+          const f32x4 t = unit.template operator()<RE, J>();
+          lds_st4(r + 4 * J, f32x4{o[J].x + t.x, o[J].y + t.y, o[J].z + t.z, o[J].w + t.w});
+        });
+      } else if (mode == ACC_STORE) {
+        StaticFor<0, UNITS>::run([&]<int J>() RPSF_AI { lds_st4(r + 4 * J, unit.template operator()<RE, J>()); });
+      }
+    };
+    finish(std::true_type(), ru, mode_u, ou);
+    finish(std::false_type(), rl, mode_l, ol);
+  } else {
+    auto half = [&](auto re_part, float* r, int mode) RPSF_AI {
+      constexpr bool RE = decltype(re_part)::value;
+      if (mode == ACC_ADD) {
+        StaticFor<0, UNITS / BATCH>::run([&]<int B>() RPSF_AI {
+          f32x4 o[BATCH];
+          StaticFor<0, BATCH>::run([&]<int I>() RPSF_AI { o[I] = lds_ld4(r + 4 * (B * BATCH + I)); });
+          StaticFor<0, BATCH>::run([&]<int I>() RPSF_AI {
+            const f32x4 t = unit.template operator()<RE, B * BATCH + I>();
+            lds_st4(r + 4 * (B * BATCH + I), f32x4{o[I].x + t.x, o[I].y + t.y, o[I].z + t.z, o[I].w + t.w});
+          });
+        });
+      } else if (mode == ACC_STORE) {
+        StaticFor<0, UNITS>::run([&]<int J>() RPSF_AI { lds_st4(r + 4 * J, unit.template operator()<RE, J>()); });
+      }
+    };
+    half(std::true_type(), ru, mode_u);
+    half(std::false_type(), rl, mode_l);
+  }
 }
 
 // ---- flush: H finished ring rows x the slab's 128 columns -> the output image (transform.py:174-177, float32 here) ------------------
@@ -369,10 +399,16 @@ RPSF_HD void flush3(int lane, const float* ring_band, const Flush3& f, int band_
   const int u = lane & 31, hf = lane >> 5;
   const int c = col0 + 4 * u;
   const int lo = oc0 > 0 ? oc0 : 0, hi = oc1 < f.Wimg ? oc1 : f.Wimg;
-  StaticFor<0, C::H / 2>::run([&]<int I>() RPSF_AI {
+  // (the band's units are read first, all of them, and stored afterwards: with the read inside the loop of conditional stores every unit paid an LDS round
+  // trip of its own - 0.8 us per flushing job at N = 32, inside the section the jobs behind it wait for)
+  constexpr int UNITS = C::H / 2, BATCH = UNITS < 8 ? UNITS : 8;
+  StaticFor<0, UNITS / BATCH>::run([&]<int B>() RPSF_AI {
+  f32x4 band[BATCH];
+  StaticFor<0, BATCH>::run([&]<int K>() RPSF_AI { band[K] = lds_ld4(ring_band + (2 * (B * BATCH + K) + hf) * C::RP + 4 * u); });
+  StaticFor<0, BATCH>::run([&]<int K>() RPSF_AI {
+    constexpr int I = B * BATCH + K;
     const int r = band_row + 2 * I + hf;
-    const float* src = ring_band + (2 * I + hf) * C::RP + 4 * u;
-    const f32x4 ab = lds_ld4(src);
+    const f32x4 ab = band[K];
     if (r >= f.row0 && r < f.row0 + f.rows && r >= 0 && r < f.Himg) {
       float* dst = f.out + (size_t)(r - f.row0) * f.ld + c;
       if (f.aligned && c >= lo && c + 4 <= hi) {
@@ -384,6 +420,7 @@ RPSF_HD void flush3(int lane, const float* ring_band, const Flush3& f, int band_
         if (c + 3 >= lo && c + 3 < hi) st1(dst + 3, ab.w);
       }
     }
+  });
   });
 }
 

@@ -36,6 +36,27 @@ __device__ __forceinline__ uint32_t lds_u32_offset(const void* p) {
   return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
 }
 
+// Development builds (-DRPSF3_STAMPS, scripts/stamps_sweep.py): 15 timestamps (10 ns ticks) of each of the first eight jobs of the first eight waves of
+// every region: [region][wave][job slot][16]
+#if defined(RPSF3_STAMPS)
+#define STAMP3(i)                                                                                                                         \
+  do { /* (scheduling barriers: the compiler must not move a phase's arithmetic across its stamp) */                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                                                    \
+    if (lane0 == 0 && wave < 8 && jslot < 8) P.stamps[(((size_t)region * 8 + wave) * 8 + jslot) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    __builtin_amdgcn_sched_barrier(0);                                                                                                    \
+  } while (0)
+// ... behind arithmetic on the lane's values: two of them are tied to the stamp, or the optimiser sinks a phase's transforms past it (they feed nothing before
+// the next transpose) and the phase reads 0.05 us
+#define STAMP3T(i)                                                      \
+  do {                                                                  \
+    asm volatile("" : "+v"(v[0].x), "+v"(v[N - 1].y) : : "memory");     \
+    STAMP3(i);                                                          \
+  } while (0)
+#else
+#define STAMP3(i) ((void)0)
+#define STAMP3T(i) ((void)0)
+#endif
+
 template <class C, bool NT>
 __device__ __forceinline__ void sweep_body(const SweepParams& P) {
   constexpr int N = C::N, H = C::H;
@@ -68,7 +89,10 @@ __device__ __forceinline__ void sweep_body(const SweepParams& P) {
     while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)(wave / RPSF3_STAGGER_GROUP) * RPSF3_STAGGER_TICKS) __builtin_amdgcn_s_sleep(8);
   }
 #endif
+  [[maybe_unused]] int jslot = -1;
   for (;;) {
+    ++jslot;
+    STAMP3(0);
     // (per-lane addresses are recomputed every pass: hoisted out of the loop - the compiler's choice otherwise - they stay live across the
     // whole body and cost registers)
     int ln = lane0;
@@ -88,6 +112,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& P) {
     }
     const int j = (int)__builtin_amdgcn_readfirstlane(drawn);
     if (j >= reg.njobs) break;
+    STAMP3(1);
     const Job3* jd = P.jobs + reg.job0 + j;
     // The descriptor this wave will most likely draw next (WAVES jobs on) is requested now and thrown away: a job's 64 bytes are read once per launch, so
     // they come from HBM (0.8 us of a 14 us job, profiles/r06k) unless somebody has asked for the line before.  The eight scalar registers stay reserved
@@ -108,6 +133,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& P) {
     const int jdep0 = jds[4], jdep1 = jds[5], jown0 = jds[6], jown1 = jds[7];
     const int row0 = P.lat_r0 + jrow, col0 = P.lat_c0 + jcol;
     if constexpr (C::DESC_PREFETCH) asm volatile("s_waitcnt lgkmcnt(0)" : : "s"(ahead), "s"(row0), "s"(col0) : "memory");
+    STAMP3(2);
 #if defined(RPSF3_ABL_ONE_K)  // ablation (wrong results): every patch multiplies by the transfer kernel of slot q - K comes from the caches
     const int kslot = q;
 #else
@@ -142,6 +168,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& P) {
     if constexpr (!C::KPRE_LATE) request_k();
     const f32x4 kbw = *reinterpret_cast<const f32x4*>(kp + C::KA_FLOATS + p * 4);
     cf v[N];
+    STAMP3(3);
     // ---- rows ----
     if constexpr (C::SPLIT_GATHER) {
       StaticFor<0, C::NSUB>::run([&]<int S>() RPSF_AI {
@@ -170,8 +197,10 @@ __device__ __forceinline__ void sweep_body(const SweepParams& P) {
         lds_fence_wave();
       });
     }
+    STAMP3T(4);
     window_in_fft_rows<C>(v, w_re, w_im);
     unpack_rows<C>(v);
+    STAMP3T(5);
     // ---- columns ----
     StaticFor<0, C::NSUB>::run([&]<int S>() RPSF_AI {
       t1_write<C, 0, S>(lane, v, xb);
@@ -183,19 +212,23 @@ __device__ __forceinline__ void sweep_body(const SweepParams& P) {
       t1_read<C, 1, S>(lane, v, xb);
       lds_fence_wave();
     });
+    STAMP3T(6);
     if constexpr (C::KPRE_LATE) request_k();
     lds_st4(side + 4 * lane, kbw);
     lds_fence_wave();
 #if !defined(RPSF3_ABL_NO_COLUMN_FFTS)  // ablation (wrong results): the two column transforms left out - how much of a job is arithmetic?
     FftSmall<C::LOGN, false>::run(v);
 #endif
+    STAMP3T(7);
     {
       const bool col0lane = p == 0;
       kmul3<C, NT>(v, ka, kp + p * 4, col0lane ? side + 4 * (q * H) : side + C::SIDE_ZERO, col0lane ? 4 : 0);
     }
+    STAMP3T(8);
 #if !defined(RPSF3_ABL_NO_COLUMN_FFTS)
     FftSmall<C::LOGN, true>::run(v);
 #endif
+    STAMP3T(9);
     // ---- back to rows ----
     StaticFor<0, C::NSUB>::run([&]<int S>() RPSF_AI {
       t2_write<C, 0, S>(lane, v, xb);
@@ -207,30 +240,34 @@ __device__ __forceinline__ void sweep_body(const SweepParams& P) {
       t2_read<C, 1, S>(lane, v, xb);
       lds_fence_wave();
     });
+    STAMP3T(10);
     repack_rows<C>(v);
     FftSmall<C::LOGN, true>::run(v);
     // second window before the wait: what follows the wait is what the jobs behind this one wait for
     window_out<C>(v, w_re, w_im, ((jflags >> (J3_VALID_SHIFT + q)) & 1u) != 0);
+    STAMP3T(11);
     // ---- wait for the jobs this one overlaps, then add ----
     {
       const int d0 = jdep0, d1 = jdep1;
       // (bounded: a protocol error must not hang the GPU - it is reported through P.err instead; 2^22 polls of ~0.1 us are far beyond any real wait)
-      auto wait_for = [&](int d) RPSF_AI {
-        if (d < 0) return;
-        const uint32_t a = flags_off + 4u * ((uint32_t)d & (C::NFLAGS - 1)), want = (uint32_t)d + 1;
+      // Both flags are read by one pair of LDS instructions and one wait (a job without a second - or any - predecessor asks slot 0 for "at least 0").
+      auto wait_for_both = [&](int da, int db) RPSF_AI {
+        if (da < 0 && db < 0) return;
+        const uint32_t a0 = flags_off + 4u * ((uint32_t)(da < 0 ? 0 : da) & (C::NFLAGS - 1)), want0 = da < 0 ? 0u : (uint32_t)da + 1;
+        const uint32_t a1 = flags_off + 4u * ((uint32_t)(db < 0 ? 0 : db) & (C::NFLAGS - 1)), want1 = db < 0 ? 0u : (uint32_t)db + 1;
         for (int spin = 0; spin < (1 << 22); ++spin) {
-          uint32_t seen;
-          asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(a) : "memory");
-          if (__builtin_amdgcn_readfirstlane(seen) >= want) return;
+          uint32_t s0, s1;
+          asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(s0), "=&v"(s1) : "v"(a0), "v"(a1) : "memory");
+          if (__builtin_amdgcn_readfirstlane(s0) >= want0 && __builtin_amdgcn_readfirstlane(s1) >= want1) return;
           __builtin_amdgcn_s_sleep(1);
         }
         if (lane0 == 0) __hip_atomic_store(P.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (a word in page-locked host memory: rpsf.hip sweep_check)
       };
 #if !defined(RPSF3_ABL_NO_WAIT)  // ablation (races: wrong results): the adds are not ordered - what does the order cost?
-      wait_for(d0);
-      wait_for(d1);
+      wait_for_both(d0, d1);
 #endif
     }
+    STAMP3T(12);
 #if defined(RPSF3_ABL_FORCE_ERR)  // development: exercise the report path of a wait that ran out (scripts/sweep_force_error.py)
     if (lane0 == 0 && j == 0 && region == 0) __hip_atomic_store(P.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #endif
@@ -241,6 +278,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& P) {
       float* rl = ring + ((hs ^ 1) * H + p) * C::RP + jring_col + q * N;
       accumulate3<C>(v, ru, rl, (int)((jflags >> J3_UPPER_SHIFT) & 3u), (int)((jflags >> J3_LOWER_SHIFT) & 3u));
     }
+    STAMP3T(13);
     // ---- phase B: the band(s) this slab has completed go to the output image ----
     // (read and stored unit by unit: a version that read the band into a register array first, released the flag and stored afterwards
     // gave wrong images on the GPU - and right ones in the emulator - in every form tried, profiles/r06i)
@@ -256,6 +294,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams& P) {
       if (jflags & J3_FLUSH_UPPER) flush3<C>(lane, ring + (hs * H) * C::RP + jring_col, fl, row0, col0, oc0, oc1, st4, st1);
       if (jflags & J3_FLUSH_LOWER) flush3<C>(lane, ring + ((hs ^ 1) * H) * C::RP + jring_col, fl, row0 + H, col0, oc0, oc1, st4, st1);
     }
+    STAMP3T(14);
     // ---- done: LDS executes a wave's instructions in order, so whoever sees the flag sees the adds (and the flush has read its rows) ----
     {  // (every lane stores the same word: no branch)
       const uint32_t a = flags_off + 4u * ((uint32_t)j & (C::NFLAGS - 1)), val = (uint32_t)j + 1;

@@ -1,5 +1,5 @@
 """Phase timestamps of the sweep kernel (development build with -DRPSF3_STAMPS):
-    RPSF_LIB=regularizepsf_amd/variants/librpsf_stamps3.so python scripts/stamps_sweep.py --n 32 --size 4096
+    python -m regularizepsf_amd.build --target=devlibs/librpsf_stamps3.so --only=k3_16,k3_32,k3_64,rpsf -DRPSF3_STAMPS; RPSF_LIB=$PWD/devlibs/librpsf_stamps3.so python scripts/stamps_sweep.py --n 32 --size 4096
 Prints, per phase, the mean time over the stamped jobs (the first 8 jobs of every wave of every region) in microseconds."""
 import argparse
 import pathlib
@@ -39,6 +39,8 @@ print(f"N = {a.n}, {a.size}^2: {st.shape[0]} regions stamped; times in us (10 ns
 ok = (st[:, :, :, :15] != 0).all(axis=3)
 ok[:, :, 0] = False
 d = np.diff(st[:, :, :, :15], axis=3)[ok] / 100.0
+if d.shape[0] == 0:
+    raise SystemExit("no wave ran a second job (a frame this small is one job per wave deep): nothing to average")
 print(f"jobs: {d.shape[0]}, mean job time {d.sum(axis=1).mean():.2f} us")
 for i in range(14):
     print(f"  {names[i]:42s} {d[:, i].mean():6.2f}   (p90 {np.percentile(d[:, i], 90):6.2f})")
