@@ -76,6 +76,14 @@ struct Cfg3 {
   static_assert(RP % 4 == 0 && (RP / 4) % 2 == 1, "ring pitch");
   static constexpr int RINGF = N * RP;
   static constexpr int NFLAGS = 256;
+  // The lanes reading their own rows straight into the R-layout (r3_load_*: no first transpose, a quarter less LDS traffic) LOSES: 64 different runs per load
+  // instruction through the texture path cost more than the transpose saves - 4096^2: +13 % at N = 32, +25 % at N = 64, 0 at N = 16, 512^2 frames +20 %
+  // (profiles/r06zy2_sweep_direct_gather.log).  Kept behind the switch.
+#if defined(RPSF3_DIRECT_GATHER)
+  static constexpr bool DIRECT_GATHER = true;
+#else
+  static constexpr bool DIRECT_GATHER = false;
+#endif
   static constexpr bool DESC_PREFETCH = N >= 32;  // (rpsf_kernels3.hpp: the job descriptor WAVES jobs ahead is touched early)
   // N = 64: the slab is requested half by half (128 registers of pixels beside 128 of the transform do not fit a lane)
   static constexpr bool SPLIT_GATHER = N == 64;
@@ -140,6 +148,39 @@ RPSF_HD void g3_load_generic(int lane, f32x4* g, const ImageView& im, int row0, 
       px[d] = (y < 0 || cx[d] < 0) ? im.pad_value : t;
     }
     g[PART * (C::H / 2) + I] = f32x4{px[0], px[1], px[2], px[3]};
+  });
+}
+
+// ---- direct gather: the lane's own two rows, straight into the R-layout (no first transpose) ---------------------------------------------------
+// (-DRPSF3_DIRECT_GATHER: measured, slower - see Cfg3::DIRECT_GATHER.)  Lane (q, p) reads row p (PART 0 -> real parts) or row p + H (PART 1 -> imaginary parts)
+// of patch q: N / 4 sixteen-byte loads of one 4 N-byte run.  The 64 lanes of an instruction touch 64 different runs - the texture path takes them line by line.
+template <class C, int PART>
+RPSF_HD void r3_load_fast(int lane, cf* v, const float* slab, int ld) {
+  const int q = lane / C::H, p = lane % C::H;
+  const float* base = slab + (size_t)(p + PART * C::H) * ld + q * C::N;
+  f32x4 t[C::N / 4];
+  StaticFor<0, C::N / 4>::run([&]<int J>() RPSF_AI { t[J] = *reinterpret_cast<const f32x4*>(base + 4 * J); });
+  StaticFor<0, C::N / 4>::run([&]<int J>() RPSF_AI {
+    if constexpr (PART == 0) v[4 * J].x = t[J].x, v[4 * J + 1].x = t[J].y, v[4 * J + 2].x = t[J].z, v[4 * J + 3].x = t[J].w;
+    else v[4 * J].y = t[J].x, v[4 * J + 1].y = t[J].y, v[4 * J + 2].y = t[J].z, v[4 * J + 3].y = t[J].w;
+  });
+}
+// any slab: np.pad's index maps, pixel by pixel
+template <class C, int PART>
+RPSF_HD void r3_load_generic(int lane, cf* v, const ImageView& im, int row0, int col0) {
+  const int q = lane / C::H, p = lane % C::H;
+  int y = pad_index(row0 + p + PART * C::H, im.H, im.pad_mode);
+  if (y >= 0) {
+    y -= im.row0;
+    if (y < 0 || y >= im.rows) y = -1;  // not resident: treated as fill (the launcher keeps every row a band needs resident)
+  }
+  const float* row = im.img + (size_t)(y < 0 ? 0 : y) * im.ld;
+  StaticFor<0, C::N>::run([&]<int K>() RPSF_AI {
+    const int cx = pad_index(col0 + q * C::N + K, im.W, im.pad_mode);
+    const float t = row[cx < 0 ? 0 : cx];  // always in bounds; select afterwards
+    const float px = (y < 0 || cx < 0) ? im.pad_value : t;
+    if constexpr (PART == 0) v[K].x = px;
+    else v[K].y = px;
   });
 }
 

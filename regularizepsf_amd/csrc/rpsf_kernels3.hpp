@@ -140,7 +140,8 @@ __device__ __forceinline__ void sweep_body(const SweepParams& P) {
     const int kslot = jd->kslot[q];
 #endif
     // ---- gather ----
-    f32x4 g[H];
+    f32x4 g[C::DIRECT_GATHER ? 1 : H];
+    cf v[N];
     const bool fast = P.aligned_in && row0 >= im.row0 && row0 + N <= im.row0 + im.rows && row0 >= 0 && row0 + N <= im.H && col0 >= 0 &&
                       col0 + C::SLABW <= im.W;
 #if defined(RPSF3_ABL_ONE_SLAB)  // ablation (wrong results): every job reads the image's first slab - pixels come from the caches
@@ -148,7 +149,14 @@ __device__ __forceinline__ void sweep_body(const SweepParams& P) {
 #else
     const float* slab = im.img + (size_t)(row0 - im.row0) * im.ld + col0;
 #endif
-    if constexpr (C::SPLIT_GATHER) {
+    if constexpr (C::DIRECT_GATHER) {
+      if (fast) r3_load_fast<C, 0>(lane, v, slab, im.ld);
+      else r3_load_generic<C, 0>(lane, v, im, row0, col0);
+      if constexpr (!C::SPLIT_GATHER) {
+        if (fast) r3_load_fast<C, 1>(lane, v, slab, im.ld);
+        else r3_load_generic<C, 1>(lane, v, im, row0, col0);
+      }
+    } else if constexpr (C::SPLIT_GATHER) {
       if (fast) g3_load_fast<C, 0, 1>(lane, g, slab, im.ld);
       else g3_load_generic<C, 0, 1>(lane, g, im, row0, col0);
     } else {
@@ -167,10 +175,14 @@ __device__ __forceinline__ void sweep_body(const SweepParams& P) {
     };
     if constexpr (!C::KPRE_LATE) request_k();
     const f32x4 kbw = *reinterpret_cast<const f32x4*>(kp + C::KA_FLOATS + p * 4);
-    cf v[N];
     STAMP3(3);
     // ---- rows ----
-    if constexpr (C::SPLIT_GATHER) {
+    if constexpr (C::DIRECT_GATHER) {
+      if constexpr (C::SPLIT_GATHER) {  // (N = 64: the second row of the lane only now - 64 registers of pixels in flight at a time)
+        if (fast) r3_load_fast<C, 1>(lane, v, slab, im.ld);
+        else r3_load_generic<C, 1>(lane, v, im, row0, col0);
+      }
+    } else if constexpr (C::SPLIT_GATHER) {
       StaticFor<0, C::NSUB>::run([&]<int S>() RPSF_AI {
         t0_write<C, 0, S>(lane, g, xb);
         lds_fence_wave();

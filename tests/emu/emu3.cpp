@@ -95,19 +95,26 @@ static int emu3_apply_t(int n_patches, const int32_t* coords, int Himg, int Wimg
       if (d.dep0 >= j || d.dep1 >= j) return -5;
       const int row0 = r0 + d.row, col0 = c0 + d.col;
       const bool fast = aligned && row0 >= 0 && row0 + N <= Himg && col0 >= 0 && col0 + C::SLABW <= Wimg;
-      for (int l = 0; l < 64; ++l) {
-        if (fast) g3_load_fast<C>(l, &g[(size_t)l * H], img + (size_t)row0 * Wimg + col0, Wimg);
-        else g3_load_generic<C>(l, &g[(size_t)l * H], im, row0, col0);
-      }
       auto lanes = [&](auto&& f) {
         for (int l = 0; l < 64; ++l) f(l, &g[(size_t)l * H], &v[(size_t)l * N]);
       };
-      StaticFor<0, C::NSUB>::run([&]<int S>() {
-        lanes([&](int l, f32x4* gl, cf*) { t0_write<C, 0, S>(l, gl, xb.data()); });
-        lanes([&](int l, f32x4*, cf* vl) { t0_read<C, 0, S>(l, vl, xb.data()); });
-        lanes([&](int l, f32x4* gl, cf*) { t0_write<C, 1, S>(l, gl, xb.data()); });
-        lanes([&](int l, f32x4*, cf* vl) { t0_read<C, 1, S>(l, vl, xb.data()); });
-      });
+      if constexpr (C::DIRECT_GATHER) {  // the lanes read their own rows (no first transpose)
+        lanes([&](int l, f32x4*, cf* vl) {
+          if (fast) r3_load_fast<C, 0>(l, vl, img + (size_t)row0 * Wimg + col0, Wimg), r3_load_fast<C, 1>(l, vl, img + (size_t)row0 * Wimg + col0, Wimg);
+          else r3_load_generic<C, 0>(l, vl, im, row0, col0), r3_load_generic<C, 1>(l, vl, im, row0, col0);
+        });
+      } else {
+        for (int l = 0; l < 64; ++l) {
+          if (fast) g3_load_fast<C>(l, &g[(size_t)l * H], img + (size_t)row0 * Wimg + col0, Wimg);
+          else g3_load_generic<C>(l, &g[(size_t)l * H], im, row0, col0);
+        }
+        StaticFor<0, C::NSUB>::run([&]<int S>() {
+          lanes([&](int l, f32x4* gl, cf*) { t0_write<C, 0, S>(l, gl, xb.data()); });
+          lanes([&](int l, f32x4*, cf* vl) { t0_read<C, 0, S>(l, vl, xb.data()); });
+          lanes([&](int l, f32x4* gl, cf*) { t0_write<C, 1, S>(l, gl, xb.data()); });
+          lanes([&](int l, f32x4*, cf* vl) { t0_read<C, 1, S>(l, vl, xb.data()); });
+        });
+      }
       lanes([&](int l, f32x4*, cf* vl) {
         window_in_fft_rows<C>(vl, win[l % H], win[l % H + H]);
         unpack_rows<C>(vl);

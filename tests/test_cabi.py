@@ -113,7 +113,7 @@ def test_development_switches_still_compile(tmp_path):
                         "-DRPSF2_ABL_NOVALU", "-DRPSF2_ABL_NOLDS", "-DRPSF2_ABL_NOBAR"],
         "k2_128p.hip": ["-DRPSF_STAMPS", "-DRPSF2_ABL_NOBAR_MASK=20"],
         "k2_128pcs.hip": ["-DRPSF2_SKEL_PRESUM"],  # the round-6 timing skeleton of a lattice-row pre-sum
-        "k3_32.hip": ["-DRPSF3_ABL_ONE_K", "-DRPSF3_ABL_ONE_SLAB", "-DRPSF3_ABL_NO_FLUSH", "-DRPSF3_ABL_NO_COLUMN_FFTS", "-DRPSF3_ABL_NO_WAIT", "-DRPSF3_ABL_FORCE_ERR"],  # the sweep kernel's ablations (5.8)
+        "k3_32.hip": ["-DRPSF3_ABL_ONE_K", "-DRPSF3_ABL_ONE_SLAB", "-DRPSF3_ABL_NO_FLUSH", "-DRPSF3_ABL_NO_COLUMN_FFTS", "-DRPSF3_ABL_NO_WAIT", "-DRPSF3_ABL_FORCE_ERR", "-DRPSF3_DIRECT_GATHER", "-DRPSF3_STAMPS"],  # the sweep kernel's ablations (5.8)
         "rpsf.hip": ["-DRPSF_DEV_ENV"],  # the environment knobs of the development sweeps
     }
     for source, defines in sets.items():
