@@ -311,7 +311,12 @@ RPSF_HD f32x4 load_k3(const float* p) {
 template <class C, bool NT>
 RPSF_HD void kmul3(cf* v, f32x4* ka_pre, const float* ka, const float* kb, int kb_stride) {
   constexpr int N = C::N, H = C::H, KP = C::KPRE;
+  // the b words come out of LDS eight at a time (N <= 32; N = 64 has no registers to spare: two at a time, as the compiler pairs them anyway) - read one by
+  // one where they are used they cost an LDS round trip each, sixteen per job at N = 32
+  constexpr int BB = H <= 16 ? (H < 8 ? H : 8) : 2;
+  f32x4 kbv[BB];
   StaticFor<0, H>::run([&]<int J>() RPSF_AI {
+    if constexpr (J % BB == 0) StaticFor<0, BB>::run([&]<int I>() RPSF_AI { kbv[I] = lds_ld4(kb + (size_t)(J + I) * kb_stride); });
     cf ae, ao, be, bo;
     if constexpr (KP > 0) {
       const f32x4 w = ka_pre[J % KP];
@@ -320,7 +325,7 @@ RPSF_HD void kmul3(cf* v, f32x4* ka_pre, const float* ka, const float* kb, int k
     } else {
       load_k16<NT>(ka + (size_t)J * (H * 4), ae, ao);
     }
-    load_k16<false>(kb + (size_t)J * kb_stride, be, bo);
+    be = cf{kbv[J % BB].x, kbv[J % BB].y}, bo = cf{kbv[J % BB].z, kbv[J % BB].w};
     constexpr int RE = k3_row<N, H>(J, 0), RO = k3_row<N, H>(J, 1);
     const cf x = v[RE], y = v[RO];
     if constexpr (J == 0) {  // v'[r] = a[r] v[r] + b[r] conj v[-r], -r = r for both rows
